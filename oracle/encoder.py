@@ -1,0 +1,157 @@
+"""CPU restatement of the reference encoder (TEST INFRASTRUCTURE -- see oracle/__init__.py).
+
+Follows `EncoderCNN` `/root/reference/models.py:9-29`:
+    resnet = torchvision resnet152, all params frozen (models.py:13-15)
+    resnet.fc = Linear(2048, embed_size), W ~ N(0, 0.02), b = 0 (models.py:16,22-23)     [trainable]
+    bn = BatchNorm1d(embed_size, momentum=0.01) (models.py:17)                           [trainable]
+    forward: bn(resnet(images)) (models.py:25-29)
+Nothing in the reference ever calls `.eval()` while training, so every BatchNorm (the 2-D ones inside
+the ResNet too) normalises with BATCH statistics and updates its running buffers.
+
+"parity unpinned": torchvision and its pretrained weights are not on disk (network fetch), and the
+reference holds no fixture for this half.  What is restated here is the published ResNet-152
+(torchvision "v1.5" bottleneck: stride on the 3x3 conv; stages [3,8,36,3]; expansion 4) using
+torch-CPU fp32 conv2d/batch-norm arithmetic with seeded weights.  State-dict key names are
+torchvision's, prefixed as the reference's module tree would (`resnet.`, `bn.`).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+RESNET152 = dict(layers=(3, 8, 36, 3), width=64)
+BN_EPS = 1e-5
+BN2D_MOMENTUM = 0.1
+BN1D_MOMENTUM = 0.01       # models.py:17
+
+
+def conv_specs(arch=RESNET152):
+    """Ordered list of every conv+bn in the stack: (name, bn_name, cin, cout, k, stride, pad)."""
+    w = arch["width"]
+    specs = [("conv1", "bn1", 3, w, 7, 2, 3)]
+    inplanes = w
+    for li, nblocks in enumerate(arch["layers"]):
+        planes = w * (2 ** li)
+        for b in range(nblocks):
+            stride = 2 if (li > 0 and b == 0) else 1
+            p = "layer%d.%d." % (li + 1, b)
+            specs.append((p + "conv1", p + "bn1", inplanes, planes, 1, 1, 0))
+            specs.append((p + "conv2", p + "bn2", planes, planes, 3, stride, 1))
+            specs.append((p + "conv3", p + "bn3", planes, planes * 4, 1, 1, 0))
+            if b == 0 and (stride != 1 or inplanes != planes * 4):
+                specs.append((p + "downsample.0", p + "downsample.1", inplanes, planes * 4, 1, stride, 0))
+            inplanes = planes * 4
+    return specs
+
+
+def feature_dim(arch=RESNET152):
+    return arch["width"] * 8 * 4
+
+
+def init_encoder_params(embed_size, arch=RESNET152, generator=None, randomize_bn=False):
+    """Returns (params, buffers), keys as EncoderCNN.state_dict() would have them.
+    conv: kaiming-normal fan_out (torchvision); BN gamma=1 beta=0 (or randomised to make tests sharper)."""
+    g = generator
+    params, buffers = {}, {}
+    for name, bn, cin, cout, k, _, _ in conv_specs(arch):
+        std = math.sqrt(2.0 / (cout * k * k))
+        params["resnet." + name + ".weight"] = torch.empty(cout, cin, k, k).normal_(0, std, generator=g)
+        if randomize_bn:
+            params["resnet." + bn + ".weight"] = torch.empty(cout).uniform_(0.5, 1.5, generator=g)
+            params["resnet." + bn + ".bias"] = torch.empty(cout).normal_(0, 0.1, generator=g)
+        else:
+            params["resnet." + bn + ".weight"] = torch.ones(cout)
+            params["resnet." + bn + ".bias"] = torch.zeros(cout)
+        buffers["resnet." + bn + ".running_mean"] = torch.zeros(cout)
+        buffers["resnet." + bn + ".running_var"] = torch.ones(cout)
+        buffers["resnet." + bn + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    fd = feature_dim(arch)
+    params["resnet.fc.weight"] = torch.empty(embed_size, fd).normal_(0.0, 0.02, generator=g)   # models.py:22
+    params["resnet.fc.bias"] = torch.zeros(embed_size)                                           # models.py:23
+    if randomize_bn:
+        params["bn.weight"] = torch.empty(embed_size).uniform_(0.5, 1.5, generator=g)
+        params["bn.bias"] = torch.empty(embed_size).normal_(0, 0.1, generator=g)
+    else:
+        params["bn.weight"] = torch.ones(embed_size)
+        params["bn.bias"] = torch.zeros(embed_size)
+    buffers["bn.running_mean"] = torch.zeros(embed_size)
+    buffers["bn.running_var"] = torch.ones(embed_size)
+    buffers["bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    return params, buffers
+
+
+def _bn2d(x, params, buffers, bn, training):
+    pre = "resnet." + bn
+    if training:
+        buffers[pre + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, buffers[pre + ".running_mean"], buffers[pre + ".running_var"],
+                        params[pre + ".weight"], params[pre + ".bias"], training, BN2D_MOMENTUM, BN_EPS)
+
+
+def resnet_forward(params, buffers, images, arch=RESNET152, training=True, taps=None):
+    """conv stack up to (and including) global average pooling: images f32[B,3,H,W] NCHW -> pooled [B, 2048].
+    `taps`: optional dict filled with intermediate NCHW activations (stem, pool, each block output)."""
+    def conv(x, name, stride, pad):
+        return F.conv2d(x, params["resnet." + name + ".weight"], None, stride, pad)
+    x = conv(images, "conv1", 2, 3)
+    if taps is not None:
+        taps["conv1_raw"] = x
+    x = F.relu(_bn2d(x, params, buffers, "bn1", training))
+    x = F.max_pool2d(x, 3, 2, 1)
+    if taps is not None:
+        taps["pool"] = x
+    w = arch["width"]
+    inplanes = w
+    for li, nblocks in enumerate(arch["layers"]):
+        planes = w * (2 ** li)
+        for b in range(nblocks):
+            stride = 2 if (li > 0 and b == 0) else 1
+            p = "layer%d.%d." % (li + 1, b)
+            out = F.relu(_bn2d(conv(x, p + "conv1", 1, 0), params, buffers, p + "bn1", training))
+            out = F.relu(_bn2d(conv(out, p + "conv2", stride, 1), params, buffers, p + "bn2", training))
+            out = _bn2d(conv(out, p + "conv3", 1, 0), params, buffers, p + "bn3", training)
+            if b == 0 and (stride != 1 or inplanes != planes * 4):
+                idt = _bn2d(conv(x, p + "downsample.0", stride, 0), params, buffers, p + "downsample.1", training)
+            else:
+                idt = x
+            x = F.relu(out + idt)
+            inplanes = planes * 4
+            if taps is not None:
+                taps[p[:-1]] = x
+    pooled = x.mean((2, 3))
+    return pooled, x
+
+
+def head_forward(params, buffers, pooled, training=True):
+    """resnet.fc then BatchNorm1d(momentum=0.01): models.py:16-17,27-28.  Returns (features, tape)."""
+    z = pooled @ params["resnet.fc.weight"].t() + params["resnet.fc.bias"]
+    if training:
+        B = z.shape[0]
+        mean = z.mean(0)
+        var = z.var(0, unbiased=False)
+        buffers["bn.running_mean"].mul_(1 - BN1D_MOMENTUM).add_(mean * BN1D_MOMENTUM)
+        buffers["bn.running_var"].mul_(1 - BN1D_MOMENTUM).add_(z.var(0, unbiased=True) * BN1D_MOMENTUM if B > 1 else var * BN1D_MOMENTUM)
+        buffers["bn.num_batches_tracked"] += 1
+    else:
+        mean, var = buffers["bn.running_mean"], buffers["bn.running_var"]
+    rstd = 1.0 / torch.sqrt(var + BN_EPS)
+    xhat = (z - mean) * rstd
+    y = xhat * params["bn.weight"] + params["bn.bias"]
+    return y, dict(pooled=pooled, xhat=xhat, rstd=rstd)
+
+
+def head_backward(params, tape, dy):
+    """Training-mode backward of head_forward for the trainable tensors (the conv stack is frozen)."""
+    xhat, rstd, pooled = tape["xhat"], tape["rstd"], tape["pooled"]
+    B = dy.shape[0]
+    dgamma = (dy * xhat).sum(0)
+    dbeta = dy.sum(0)
+    dz = (params["bn.weight"] * rstd / B) * (B * dy - dbeta - xhat * dgamma)
+    return {"bn.weight": dgamma, "bn.bias": dbeta,
+            "resnet.fc.weight": dz.t() @ pooled, "resnet.fc.bias": dz.sum(0)}
+
+
+def encoder_forward(params, buffers, images, arch=RESNET152, training=True):
+    """EncoderCNN.forward (models.py:25-29)."""
+    pooled, _ = resnet_forward(params, buffers, images, arch, training)
+    return head_forward(params, buffers, pooled, training)[0]

@@ -1,0 +1,92 @@
+"""CPU: the oracle (oracle/decoder.py, oracle/train_step.py) against the golden vectors produced by the
+imported reference `models.DecoderRNN` + train.py arithmetic (tests/golden/make_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder as OD
+from oracle import train_step as OT
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: z[k] for k in z.files}
+
+
+def params_from_seed(g):
+    E, H, V, L, B, T = [int(x) for x in g["dims"]]
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    return OD.init_decoder_params(E, H, V, L, generator=gen), (E, H, V, L, B, T)
+
+
+@pytest.mark.parametrize("name", ["G1_dec_fwd_bwd_small.npz", "G2_dec_varlen_small.npz", "G5_dec_L2.npz"])
+def test_forward_backward_matches_reference(golden_dir, name):
+    g = load(golden_dir, name)
+    params, (E, H, V, L, B, T) = params_from_seed(g)
+    feats = torch.from_numpy(g["features"])
+    caps = torch.from_numpy(g["captions"])
+    lengths = [int(x) for x in g["lengths"]]
+    targets, l1 = OT.pack_targets(caps, lengths)
+    assert np.array_equal(targets.numpy(), g["targets"])            # packed time-major row order
+    loss, grads, d_feat, logits = OT.decoder_loss_and_grads(params, feats, caps, lengths, L)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=2e-6)
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    np.testing.assert_allclose(d_feat.numpy(), g["d_features"], rtol=1e-4, atol=2e-8)
+    for k in grads:
+        np.testing.assert_allclose(grads[k].numpy(), g["grad." + k], rtol=1e-4, atol=2e-8, err_msg=k)
+
+
+def test_clamp_adam_three_steps(golden_dir):
+    g = load(golden_dir, "G1_dec_fwd_bwd_small.npz")
+    params, (E, H, V, L, B, T) = params_from_seed(g)
+    feats, caps = torch.from_numpy(g["features"]), torch.from_numpy(g["captions"])
+    lengths = [int(x) for x in g["lengths"]]
+    state = {}
+    for it in range(3):
+        loss, grads, _, _ = OT.decoder_loss_and_grads(params, feats, caps, lengths, L)
+        assert abs(loss.item() - float(g["losses"][it])) < 5e-6
+        OT.clamp_(grads, 0.1)
+        OT.adam_step_(params, grads, state, lr=1e-3)
+        if it + 1 in (1, 3):
+            for k in params:
+                np.testing.assert_allclose(params[k].numpy(), g["param_after%d.%s" % (it + 1, k)],
+                                           rtol=0, atol=3e-7, err_msg="%s after %d" % (k, it + 1))
+
+
+def test_cfg1_summary(golden_dir):
+    g = load(golden_dir, "G3_dec_cfg1_summary.npz")
+    params, (E, H, V, L, B, T) = params_from_seed(g)
+    feats, caps = torch.from_numpy(g["features"]), torch.from_numpy(g["captions"])
+    lengths = [int(x) for x in g["lengths"]]
+    loss, grads, d_feat, logits = OT.decoder_loss_and_grads(params, feats, caps, lengths, L)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    assert np.array_equal(logits.argmax(1).numpy(), g["argmax"])
+    np.testing.assert_allclose(logits[:, :64].numpy(), g["logits_head"], rtol=0, atol=2e-6)
+    for k in grads:
+        n = float(np.sqrt((grads[k].double().numpy() ** 2).sum()))
+        assert abs(n - float(g["gradnorm." + k])) <= 1e-5 * float(g["gradnorm." + k]) + 1e-9, k
+
+
+@pytest.mark.parametrize("name", ["G1_dec_fwd_bwd_small.npz", "G3_dec_cfg1_summary.npz", "G5_dec_L2.npz"])
+def test_greedy_ids_bit_exact(golden_dir, name):
+    g = load(golden_dir, name)
+    params, (E, H, V, L, B, T) = params_from_seed(g)
+    ids = OD.greedy_sample(params, torch.from_numpy(g["features"]), L)
+    assert ids.shape == (B, 20) and ids.dtype == torch.int64
+    assert np.array_equal(ids.numpy(), g["greedy_ids"])
+
+
+def test_lr_schedule():
+    # train.py:101-107 with config.py defaults (decay_start 1, every 3, rate 0.8)
+    assert OT.lr_for_epoch(1) == 1e-3
+    assert OT.lr_for_epoch(2) == 1e-3
+    assert abs(OT.lr_for_epoch(4) - 0.8e-3) < 1e-12
+    assert abs(OT.lr_for_epoch(7) - 0.64e-3) < 1e-12
+
+
+def test_batch_sizes_and_errors():
+    assert OD.batch_sizes([5, 3, 3, 1]) == [4, 3, 3, 1, 1]
+    with pytest.raises(AssertionError):
+        OD.batch_sizes([3, 5])
