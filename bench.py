@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one Show-and-Tell training step (the reference's hot-loop window
+`/root/reference/train.py:123-149`: forward, CE, backward, elementwise clamp, Adam) on synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): per-GPU batch 64, 224x224x3 images, length-20 captions, embed 256,
+hidden 512, vocab 10000, 1 LSTM layer, ResNet-152 encoder (frozen, train-mode batch statistics).
+Conv stack in bf16 MFMA (f32 accumulate), head/decoder/optimizer in exact-f32 MFMA.  Inputs are resident in
+HBM when the timed region starts.  Weak scaling: the per-GPU batch is fixed, gradients are all-reduced over RCCL.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CFG = dict(batch=64, image=224, embed=256, hidden=512, vocab=10000, layers=1, cap_len=20)
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(B, V, T, H, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)          # SURVEY 8d synthetic inputs
+    images = torch.randn(B, 3, H, H, generator=g)
+    caps = torch.randint(4, V, (B, T), generator=g)
+    caps[:, 0], caps[:, T - 1] = 1, 2
+    return images.to(device), caps.to(device), [T] * B
+
+
+def conv_only_time_ms(sat, model, images, reps=3):
+    """Average duration of ONE pass over every implicit-GEMM conv launch of the stack (the dominant kernel),
+    timed with HIP events on the stream the kernels are launched on."""
+    L = sat._lib
+    prog = model.encoder._program(images)
+    conv_ops = [prog.ops[i] for i in range(prog.n_ops) if prog.ops[i].kind == L.OP_CONV]
+    arr = (L.SatOp * len(conv_ops))(*conv_ops)
+    lib = L.load()
+    prog.run(images)                                   # fills the activation buffers with real data
+    L.check(lib.sat_run_ops(arr, len(conv_ops), L.stream()))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.check(lib.sat_run_ops(arr, len(conv_ops), L.stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, len(conv_ops)
+
+
+def cpu_baseline(seed):
+    """The CPU oracle (a port of the reference path, validated against the reference's goldens) timed on this
+    host's cores on a bounded sample of the same workload: batch 8 of the cfg-2 shapes, 1 warm-up + 2 steps."""
+    from oracle import decoder as OD
+    from oracle import encoder as OE
+    from oracle import train_step as OT
+    threads = torch.get_num_threads()
+    B = 8
+    gen = torch.Generator().manual_seed(seed)
+    ep, eb = OE.init_encoder_params(CFG["embed"], OE.RESNET152, generator=gen)
+    dp = OD.init_decoder_params(CFG["embed"], CFG["hidden"], CFG["vocab"], CFG["layers"], generator=gen)
+    images = torch.randn(B, 3, CFG["image"], CFG["image"], generator=gen)
+    caps = torch.randint(4, CFG["vocab"], (B, CFG["cap_len"]), generator=gen)
+    caps[:, 0], caps[:, -1] = 1, 2
+    lengths = [CFG["cap_len"]] * B
+    state = {}
+    OT.full_step(ep, eb, dp, images, caps, lengths, state)
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        OT.full_step(ep, eb, dp, images, caps, lengths, state)
+    dt = time.perf_counter() - t0
+    return {"value": B * n / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "CPU oracle (oracle/train_step.py full_step, torch-CPU fp32), batch %d of the same shapes, 1 warm-up + %d timed steps" % (B, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    sat = importlib.import_module("show-and-tell_amd")
+    torch.manual_seed(123)                                           # config.py:15; same weights on every rank
+    model = sat.ShowAndTell(CFG["embed"], CFG["hidden"], CFG["vocab"], CFG["layers"], compute_dtype="bf16").to(dev).train()
+    ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+    dp = sat.DataParallelStep(ts)
+    images, caps, lengths = synth_batch(CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 123 + rank)
+    global_tokens = world * sum(l - 1 for l in lengths)
+
+    for _ in range(args.warmup):
+        loss = dp.step((images, caps, lengths), global_tokens)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = dp.step((images, caps, lengths), global_tokens)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * CFG["batch"] * args.steps / dt
+        conv_ms, n_conv = conv_only_time_ms(sat, model, images)
+        conv_flops = sat.conv_flops(sat.RESNET152, CFG["image"], CFG["image"]) * CFG["batch"]
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        out = {
+            "metric": "images/sec (train step)", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=64/GPU 224x224x3 + len-20 captions, ResNet-152 encoder (frozen, train-mode BN), embed=256 hidden=512 vocab=10000 L=1; fwd+CE+bwd+clamp+Adam",
+                       "global_batch": world * CFG["batch"], "parallelism": "dp%d" % world,
+                       "precision": "conv stack bf16 MFMA / f32 accumulate; head, LSTM, vocab, CE, Adam f32 (exact-f32 MFMA)",
+                       "final_loss": round(final_loss, 4)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16,128,{128|64},conv,nt> (implicit-GEMM conv, %d launches/step)" % n_conv,
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step_in_kernel": round(conv_ms, 3)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(123)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

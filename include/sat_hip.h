@@ -1,0 +1,182 @@
+/*
+ * sat_hip.h -- C ABI of libsat_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the Show-and-Tell
+ * training hot path of incredible-vision/show-and-tell.
+ *
+ * The reference has NO native code and NO FFI: its hot path is a chain of torch operator
+ * call sites.  Each entry point below replaces the call site cited next to it, so a maintainer can bind
+ * it from Python with ctypes.  Conventions:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked [host];
+ *   - the caller owns every buffer (inputs, outputs, tapes, workspaces): nothing here allocates or frees;
+ *   - every launch goes to `stream` (a hipStream_t); no host synchronisation, safe to capture in a hipGraph;
+ *   - return 0 on success, SAT_ERR_* (>= 1001) for argument errors, otherwise a hipError_t value;
+ *   - packed sequences are TIME-MAJOR: rows of step t are [prefix[t], prefix[t]+batch_sizes[t]),
+ *     batch_sizes non-increasing (pack_padded_sequence with lengths sorted descending, models.py:51).
+ */
+#ifndef SAT_HIP_H
+#define SAT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAT_ABI_VERSION 1
+
+#define SAT_OK 0
+#define SAT_ERR_ARG 1001
+#define SAT_ERR_WORKSPACE 1002
+#define SAT_ERR_UNSUPPORTED 1003
+
+#define SAT_F32 0
+#define SAT_BF16 1
+
+typedef void* sat_stream_t; /* hipStream_t */
+
+int sat_version(void);
+const char* sat_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic dense f32 GEMM on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): C[M,N] = op(A) op(B) + bias + bias2
+ *   amode 0: A[m*lda + k]          amode 2: A[k*lda + m]
+ *   bmode 0: B[n*ldb + k]  ("NT")  bmode 1: B[k*ldb + n]
+ * Replaces the cuBLAS/MKL GEMMs under nn.Linear / nn.LSTM (models.py:52-53) and their backward.
+ * Requires K%4==0, lda/ldb%4==0 (+ M%4 for amode 2, N%4 for bmode 1), 16-byte aligned bases.
+ */
+int sat_gemm_f32(int amode, int bmode, const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc, const float* bias, const float* bias2,
+                 int M, int N, int K, sat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder op program (models.py:25-29 `self.resnet(images)`): the host describes the frozen conv stack
+ * as an array of sat_op and one call launches all of it.  Activations are NHWC, dtype f32 or bf16.
+ */
+enum {
+    SAT_OP_IMAGE_PREP = 1, /* NCHW f32 image -> zero-padded NHWC4 (in0 -> out); H/W = Hin/Win, pad = border */
+    SAT_OP_CONV = 2,       /* implicit-GEMM conv: in0 (NHWC) * w [Cout][KH*KW*Cin] -> out [M][Cout] (+ stat_partial) */
+    SAT_OP_BN_FINALIZE = 3,/* partials -> scale/shift (+ running stats update) */
+    SAT_OP_BN_RELU = 4,    /* out = relu(in0*scale0 + shift0) */
+    SAT_OP_BN_ADD_RELU = 5,/* out = relu(in0*scale0+shift0 + (in1*scale1+shift1 | in1)) */
+    SAT_OP_BN_RELU_MAXPOOL = 6, /* out = maxpool3x3/2(relu(in0*scale0+shift0)) */
+    SAT_OP_AVGPOOL = 7     /* out f32 [N][C] = mean over Hin*Win of in0 */
+};
+
+typedef struct sat_op {
+    int32_t kind;
+    int32_t dtype;            /* SAT_F32 / SAT_BF16 : element type of in0/in1/out/w */
+    const void* in0;
+    const void* in1;
+    void* out;
+    const void* w;
+    const float* scale0;
+    const float* shift0;
+    const float* scale1;      /* NULL => in1 used as is */
+    const float* shift1;
+    float* stat_partial;      /* [tiles_m][2][Cout] f32 : per-tile column sum / sum of squares */
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* scale_out;
+    float* shift_out;
+    int32_t N, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad;
+    int32_t training;         /* BN_FINALIZE: 1 = batch statistics (+running update), 0 = running statistics */
+    int32_t tiles_m;          /* number of partial rows in stat_partial (= ceil(M/128)) */
+    int64_t sN, sH, sW;       /* element strides of in0 for SAT_OP_CONV (lets the stem read a padded NHWC4 image) */
+    int64_t count;            /* BN_FINALIZE: elements per channel (N*Hout*Wout) */
+    float momentum, eps;
+} sat_op;
+
+int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
+/* conv + batch-stat finalize + normalise/ReLU as one call (three ops) -- `conv -> bn -> relu` of a bottleneck */
+int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, const sat_op* bnrelu, sat_stream_t stream);
+/* rows of SAT_OP_CONV partials the conv kernel writes for M output pixels */
+int sat_conv_tiles_m(int64_t M);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder head: resnet.fc (Linear 2048->E) + BatchNorm1d(E, momentum=0.01)  (models.py:16-17,27-28)
+ */
+int sat_fc_bn1d_fwd(const float* pooled /*[B,F]*/, const float* w_fc /*[E,F]*/, const float* b_fc /*[E]*/,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, int training, int B, int F, int E,
+                    float* feats /*[B,E]*/, float* xhat /*[B,E]*/, float* rstd /*[E]*/,
+                    float* workspace, int64_t ws_bytes, sat_stream_t stream);
+int64_t sat_fc_bn1d_ws_bytes(int B, int F, int E);
+int sat_fc_bn1d_bwd(const float* dy /*[B,E]*/, const float* pooled, const float* xhat, const float* rstd,
+                    const float* gamma, int B, int F, int E,
+                    float* dw_fc /*[E,F]*/, float* db_fc, float* dgamma, float* dbeta,
+                    float* workspace /* >= B*E floats */, int64_t ws_bytes, sat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decoder (models.py:47-54).
+ */
+/* embed + cat(features) + pack (models.py:49-51): X[N,E], row (t,b): t==0 ? features[b] : embed[captions[b][t-1]] */
+int sat_embed_concat_fwd(const float* features /*[B,E]*/, const float* embed /*[V,E]*/,
+                         const int64_t* captions /*[B][cap_stride]*/, int64_t cap_stride,
+                         const int32_t* prefix /*[T+1] device*/, int T, int N /*=prefix[T]*/, int B, int E, int V,
+                         float* X /*[N,E]*/, sat_stream_t stream);
+/* backward of the above: d_embed (dense, zeroed here, deterministic order) and d_features */
+int sat_embed_concat_bwd(const float* dX /*[N,E]*/, const int64_t* captions, int64_t cap_stride,
+                         const int32_t* prefix /*device*/, int T, int N, int B, int E, int V,
+                         float* d_embed /*[V,E]*/, float* d_features /*[B,E]*/, sat_stream_t stream);
+
+/* targets = pack_padded_sequence(captions[:,1:], lengths-1).data (train.py:134-135); prefix/T/N describe lengths-1 */
+int sat_pack_targets(const int64_t* captions /*[B][cap_stride]*/, int64_t cap_stride, const int32_t* prefix /*device*/,
+                     int T, int N, int64_t* targets /*[N]*/, sat_stream_t stream);
+
+/* one nn.LSTM layer over a packed batch (models.py:52), zero initial state, gate order i,f,g,o.
+ * Tapes for the backward: GA[N,4H] post-activation gates, CS[N,H] cell states, HS[N,H] outputs,
+ * HP[N,H] previous hidden state per row.  c_state/h_state: [B,H] scratch. */
+int sat_lstm_fwd(const float* X /*[N,In]*/, const float* w_ih /*[4H,In]*/, const float* w_hh /*[4H,H]*/,
+                 const float* b_ih, const float* b_hh, const int32_t* batch_sizes /*[T] host*/, int T,
+                 int In, int H, float* GA, float* CS, float* HS, float* HP, float* c_state,
+                 sat_stream_t stream);
+int64_t sat_lstm_bwd_ws_bytes(int B, int H);
+int sat_lstm_bwd(const float* dHS /*[N,H]*/, const float* X, const float* w_ih, const float* w_hh,
+                 const float* GA, const float* CS, const float* HP,
+                 const int32_t* batch_sizes /*[T] host*/, int T, int In, int H,
+                 float* DG /*[N,4H] out*/, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
+                 float* dX /*[N,In] or NULL*/, float* workspace, int64_t ws_bytes, sat_stream_t stream);
+
+/* vocab projection (models.py:53) */
+int sat_vocab_logits_fwd(const float* Hs /*[N,H]*/, const float* w /*[V,H]*/, const float* b /*[V]*/,
+                         int N, int H, int V, float* logits /*[N,V]*/, sat_stream_t stream);
+/* row-wise softmax cross entropy (train.py:53,143): row_loss[n] = lse - logit[target]; loss_out[0] =
+ * inv_denom * sum(row_loss) (fixed-order reduction).  write_grad: logits are overwritten IN PLACE with
+ * d(loss)/d(logits) = (softmax - onehot) * inv_denom. */
+int sat_ce_rows(float* logits /*[N,V]*/, const int64_t* targets /*[N]*/, int N, int V, float inv_denom,
+                int write_grad, float* row_loss /*[N]*/, float* loss_out /*[1]*/, sat_stream_t stream);
+/* fused: logits + CE (+ in-place grad) */
+int sat_vocab_ce_fwd(const float* Hs, const float* w, const float* b, const int64_t* targets,
+                     int N, int H, int V, float inv_denom, int write_grad,
+                     float* logits, float* row_loss, float* loss_out, sat_stream_t stream);
+/* backward of the projection given dlogits: dW[V,H], db[V], dHs[N,H] */
+int sat_vocab_ce_bwd(const float* dlogits /*[N,V]*/, const float* Hs, const float* w, int N, int H, int V,
+                     float* dw, float* db, float* dHs, sat_stream_t stream);
+/* greedy argmax of one decode step (models.py:61-63): ids[b*ids_stride] = first argmax_v (h[b] . w[v] + b[v]) */
+int sat_vocab_argmax(const float* h /*[B,H]*/, const float* w, const float* b, int B, int H, int V,
+                     int64_t* ids, int64_t ids_stride, float* workspace, int64_t ws_bytes, sat_stream_t stream);
+int64_t sat_vocab_argmax_ws_bytes(int B, int V);
+/* one greedy decode step of one LSTM layer, state in place: x[B,In] -> h_out[B,H]; c[B,H] updated */
+int sat_lstm_step(const float* x, const float* h_in, float* c, const float* w_ih, const float* w_hh,
+                  const float* b_ih, const float* b_hh, int B, int In, int H, float* h_out, sat_stream_t stream);
+/* rows of an embedding table: out[b] = embed[ids[b*ids_stride]] */
+int sat_embed_rows(const float* embed, const int64_t* ids, int64_t ids_stride, int B, int E, int V,
+                   float* out, sat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * clip_gradient (train.py:88-91) + optim.Adam step (train.py:56,146) over one flat buffer.
+ * clip <= 0 disables the clamp.  step is the 1-based Adam step count.
+ */
+int sat_clamp_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float clip, int step, sat_stream_t stream);
+
+/* column sums: out[c] = sum_r x[r*ld + c]  (bias gradients) */
+int sat_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, sat_stream_t stream);
+/* f32 -> bf16 / bf16 -> f32 casts (weight shadow copies) */
+int sat_cast_f32_bf16(const float* in, void* out, int64_t n, sat_stream_t stream);
+int sat_cast_bf16_f32(const void* in, float* out, int64_t n, sat_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

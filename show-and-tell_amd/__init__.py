@@ -1,0 +1,11 @@
+"""show-and-tell_amd: MI355X-native (gfx950) Show-and-Tell training hot path behind the reference's model API.
+
+The directory name is not a Python identifier; import it with
+    sat = importlib.import_module("show-and-tell_amd")
+or through the repo-root `models.py` drop-in shim (`from models import EncoderCNN, DecoderRNN`).
+"""
+from . import _lib  # noqa: F401
+from .models import (CaptionModel, Decoder, DecoderRNN, Encoder, EncoderCNN, ShowAndTell)  # noqa: F401
+from .pack import PackInfo, pack_targets  # noqa: F401
+from .resnet import RESNET152, conv_flops  # noqa: F401
+from .trainer import DataParallelStep, FlatParams, TrainStep, dp_shard, lr_for_epoch  # noqa: F401

@@ -1,0 +1,109 @@
+"""ctypes binding of libsat_hip.so (C ABI: include/sat_hip.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback.  If it is missing or a kernel call
+fails, a RuntimeError is raised -- nothing is computed another way.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsat_hip.so")
+
+SAT_F32, SAT_BF16 = 0, 1
+OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class SatOp(C.Structure):
+    """mirror of `struct sat_op` (include/sat_hip.h)"""
+    _fields_ = [
+        ("kind", C.c_int32), ("dtype", C.c_int32),
+        ("in0", _vp), ("in1", _vp), ("out", _vp), ("w", _vp),
+        ("scale0", _vp), ("shift0", _vp), ("scale1", _vp), ("shift1", _vp),
+        ("stat_partial", _vp), ("gamma", _vp), ("beta", _vp),
+        ("running_mean", _vp), ("running_var", _vp), ("scale_out", _vp), ("shift_out", _vp),
+        ("N", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32),
+        ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("training", C.c_int32), ("tiles_m", C.c_int32),
+        ("sN", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64), ("count", C.c_int64),
+        ("momentum", C.c_float), ("eps", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/sat_hip.h declares
+SIGNATURES = {
+    "sat_version": (_i, []),
+    "sat_error_string": (C.c_char_p, [_i]),
+    "sat_gemm_f32": (_i, [_i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
+    "sat_run_ops": (_i, [C.POINTER(SatOp), _i, _vp]),
+    "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
+    "sat_conv_tiles_m": (_i, [_i64]),
+    "sat_fc_bn1d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sat_fc_bn1d_ws_bytes": (_i64, [_i, _i, _i]),
+    "sat_fc_bn1d_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sat_embed_concat_fwd": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sat_embed_concat_bwd": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sat_pack_targets": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
+    "sat_lstm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sat_lstm_bwd_ws_bytes": (_i64, [_i, _i]),
+    "sat_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i,
+                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sat_vocab_logits_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sat_ce_rows": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "sat_vocab_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "sat_vocab_ce_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sat_vocab_argmax": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _i64, _vp]),
+    "sat_vocab_argmax_ws_bytes": (_i64, [_i, _i]),
+    "sat_lstm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sat_embed_rows": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "sat_clamp_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
+    "sat_colsum_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    "sat_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),
+    "sat_cast_bf16_f32": (_i, [_vp, _vp, _i64, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libsat_hip.so once; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "show-and-tell_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.sat_version() != 1:
+            raise RuntimeError("libsat_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sat_error_string(rc)
+        raise RuntimeError("libsat_hip %s failed: [%d] %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    """torch's current HIP stream as a raw hipStream_t: every kernel is launched on it."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError("show-and-tell_amd: %s must live on the MI355X (got a %s tensor); the HIP path has no CPU fallback"
+                           % (name, t.device))

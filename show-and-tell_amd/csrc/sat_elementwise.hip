@@ -1,0 +1,736 @@
+// HBM-bound kernels of the Show-and-Tell hot path: every access is a 16-byte-per-lane coalesced stream
+// (NHWC activations, flat parameter buffers), reductions are fixed-order (bitwise reproducible), no atomics.
+//   encoder : image prep, batch-norm finalize / apply (+ReLU, +residual, +maxpool), global average pool
+//   decoder : embedding gather / deterministic scatter, row-wise softmax-CE, column sums, LSTM backward
+//             pointwise step, BatchNorm1d forward/backward
+//   trainer : fused elementwise clamp + Adam over one flat buffer (train.py:88-91,146)
+#include "sat_common.h"
+#include "../../include/sat_hip.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline int ew_grid(long n_items) {
+    long b = (n_items + EW_BLOCK - 1) / EW_BLOCK;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));   // cap and grid-stride the rest
+}
+
+template <typename T> struct Vec;   // 16-byte vector of T
+template <> struct Vec<float> { static constexpr int N = 4; };
+template <> struct Vec<bf16_t> { static constexpr int N = 8; };
+
+template <typename T> __device__ __forceinline__ void load_chunk(const T* p, float (&v)[Vec<T>::N]);
+template <> __device__ __forceinline__ void load_chunk<float>(const float* p, float (&v)[4]) {
+    const f32x4 x = *(const f32x4*)p;
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+template <> __device__ __forceinline__ void load_chunk<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 x = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+}
+template <typename T> __device__ __forceinline__ void store_chunk(T* p, const float (&v)[Vec<T>::N]);
+template <> __device__ __forceinline__ void store_chunk<float>(float* p, const float (&v)[4]) {
+    f32x4 x = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)p = x;
+}
+template <> __device__ __forceinline__ void store_chunk<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    bf16x8 x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (bf16_t)v[i];
+    *(bf16x8*)p = x;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// image prep: NCHW f32 -> zero-bordered NHWC4 (channel 3 = 0).  Border/extra pixels are never written:
+// the caller zero-fills the buffer once.
+template <typename T>
+__global__ void image_prep_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int H, int W,
+                                  int Hp, int Wp, int pad) {
+    const long total = (long)N * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const long t = i / W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const long plane = (long)H * W;
+        const float* src = in + (long)n * 3 * plane + (long)h * W + w;
+        T* dst = out + (((long)n * Hp + h + pad) * Wp + w + pad) * 4;
+        dst[0] = from_f32<T>(src[0]);
+        dst[1] = from_f32<T>(src[plane]);
+        dst[2] = from_f32<T>(src[2 * plane]);
+        dst[3] = from_f32<T>(0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// batch-norm finalize: per-tile partial (sum, sumsq) -> scale/shift; running-stat update (momentum).
+// block = 32 channels x 8 partial groups; f64 accumulation, fixed order.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int tiles_m, int C,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* running_mean,
+                                                          float* running_var, float momentum, float eps,
+                                                          int training, float* scale, float* shift) {
+    __shared__ double ss[8][32], sq[8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (training && c < C) {
+        for (int t = rg; t < tiles_m; t += 8) {
+            s += (double)partial[((long)t * 2 + 0) * C + c];
+            q += (double)partial[((long)t * 2 + 1) * C + c];
+        }
+    }
+    ss[rg][cl] = s; sq[rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        double mean, var;
+        if (training) {
+            double S = 0.0, Q = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { S += ss[g][cl]; Q += sq[g][cl]; }
+            mean = S / count;
+            var = Q / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+            }
+        } else {
+            mean = running_mean[c];
+            var = running_var[c];
+        }
+        const float invstd = 1.0f / sqrtf((float)var + eps);
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+    }
+}
+
+// out = relu(in0*s0 + t0)  /  out = relu(in0*s0 + t0 + (in1*s1 + t1 | in1)); NHWC, C % chunk == 0
+template <typename T, bool ADD>
+__global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ in1, T* __restrict__ out,
+                              const float* __restrict__ s0, const float* __restrict__ t0,
+                              const float* __restrict__ s1, const float* __restrict__ t1, long nchunks, int C) {
+    constexpr int V = Vec<T>::N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)((i * V) % C);
+        float x[V], y[V];
+        load_chunk<T>(in0 + i * V, x);
+#pragma unroll
+        for (int k = 0; k < V; ++k) y[k] = x[k] * s0[c0 + k] + t0[c0 + k];
+        if constexpr (ADD) {
+            float z[V];
+            load_chunk<T>(in1 + i * V, z);
+            if (s1) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) y[k] += z[k] * s1[c0 + k] + t1[c0 + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) y[k] += z[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) y[k] = fmaxf(y[k], 0.0f);
+        store_chunk<T>(out + i * V, y);
+    }
+}
+
+// out[n][ho][wo][c] = max_{3x3, stride 2, pad 1} relu(in*s + t)
+template <typename T>
+__global__ void bn_relu_maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ s,
+                                       const float* __restrict__ t, int N, int Hin, int Win, int C, int Hout, int Wout) {
+    constexpr int V = Vec<T>::N;
+    const int cch = C / V;
+    const long total = (long)N * Hout * Wout * cch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cch);
+        long r = i / cch;
+        const int wo = (int)(r % Wout); r /= Wout;
+        const int ho = (int)(r % Hout);
+        const int n = (int)(r / Hout);
+        const int c0 = cc * V;
+        float sc[V], sh[V], best[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { sc[k] = s[c0 + k]; sh[k] = t[c0 + k]; best[k] = 0.0f; }  // relu >= 0
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hi = ho * 2 - 1 + dh;
+            if ((unsigned)hi >= (unsigned)Hin) continue;
+            for (int dw = 0; dw < 3; ++dw) {
+                const int wi = wo * 2 - 1 + dw;
+                if ((unsigned)wi >= (unsigned)Win) continue;
+                float x[V];
+                load_chunk<T>(in + (((long)n * Hin + hi) * Win + wi) * C + c0, x);
+#pragma unroll
+                for (int k = 0; k < V; ++k) best[k] = fmaxf(best[k], x[k] * sc[k] + sh[k]);
+            }
+        }
+        store_chunk<T>(out + i * V, best);
+    }
+}
+
+// global average pool: in [N][HW][C] -> out f32 [N][C]
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ in, float* __restrict__ out, int N, int HW, int C) {
+    constexpr int V = Vec<T>::N;
+    const int cch = C / V;
+    const long total = (long)N * cch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cch);
+        const int n = (int)(i / cch);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.0f;
+        for (int p = 0; p < HW; ++p) {
+            float x[V];
+            load_chunk<T>(in + ((long)n * HW + p) * C + cc * V, x);
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[k] += x[k];
+        }
+        const float inv = 1.0f / (float)HW;
+#pragma unroll
+        for (int k = 0; k < V; ++k) out[(long)n * C + cc * V + k] = acc[k] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// embedding
+__device__ __forceinline__ int find_step(const int* prefix, int T, int row) {
+    int t = 0;
+    while (t + 1 < T && row >= prefix[t + 1]) ++t;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void embed_concat_fwd_kernel(const float* __restrict__ features,
+                                                               const float* __restrict__ embed,
+                                                               const int64_t* __restrict__ captions, long cap_stride,
+                                                               const int* __restrict__ prefix, int T, int E, int V,
+                                                               float* __restrict__ X) {
+    const int row = blockIdx.x;
+    const int t = find_step(prefix, T, row);
+    const int b = row - prefix[t];
+    const float* src;
+    if (t == 0) {
+        src = features + (long)b * E;
+    } else {
+        long tok = captions[(long)b * cap_stride + (t - 1)];
+        tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+        src = embed + tok * E;
+    }
+    float* dst = X + (long)row * E;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) dst[e] = src[e];
+}
+
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ embed, const int64_t* __restrict__ ids,
+                                                         long ids_stride, int E, int V, float* __restrict__ out) {
+    const int b = blockIdx.x;
+    long tok = ids[(long)b * ids_stride];
+    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+    for (int e = threadIdx.x; e < E; e += blockDim.x) out[(long)b * E + e] = embed[tok * E + e];
+}
+
+// deterministic scatter-add: the block of the FIRST occurrence of a token sums all its rows in row order.
+__global__ __launch_bounds__(256) void embed_concat_bwd_kernel(const float* __restrict__ dX,
+                                                               const int64_t* __restrict__ captions, long cap_stride,
+                                                               const int* __restrict__ prefix, int T, int B, int E, int V,
+                                                               int Nrows, float* __restrict__ d_embed,
+                                                               float* __restrict__ d_features) {
+    extern __shared__ __attribute__((aligned(16))) int tok[];   // [Nrows]; -1 for step-0 rows
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < Nrows; i += blockDim.x) {
+        const int t = find_step(prefix, T, i);
+        int v = -1;
+        if (t > 0) {
+            long x = captions[(long)(i - prefix[t]) * cap_stride + (t - 1)];
+            v = (int)(x < 0 ? 0 : (x >= V ? V - 1 : x));
+        }
+        tok[i] = v;
+    }
+    __syncthreads();
+    const int v = tok[row];
+    if (v < 0) {   // feature rows (t == 0): b == row
+        for (int e = threadIdx.x; e < E; e += blockDim.x) d_features[(long)row * E + e] = dX[(long)row * E + e];
+        return;
+    }
+    int dup = 0;
+    for (int i = threadIdx.x; i < row; i += blockDim.x) dup |= (tok[i] == v);
+    if (__syncthreads_or(dup)) return;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        float acc = 0.0f;
+        for (int i = row; i < Nrows; ++i)
+            if (tok[i] == v) acc += dX[(long)i * E + e];
+        d_embed[(long)v * E + e] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// row-wise softmax cross entropy, optionally overwriting the row with its gradient
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void ce_rows_kernel(float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                      int V, float inv_denom, int write_grad, float* __restrict__ row_loss) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;
+    float* x = logits + (long)row * V;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += 256) m = fmaxf(m, x[i]);
+    m = block_reduce(m, true, sh);
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < V; i += 256) s += expf(x[i] - m);
+    s = block_reduce(s, false, sh);
+    const float lse = m + logf(s);
+    long tgt = targets[row];
+    tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+    if (threadIdx.x == 0) row_loss[row] = lse - x[tgt];
+    if (write_grad) {
+        __syncthreads();   // x[tgt] read above before any overwrite
+        for (int i = threadIdx.x; i < V; i += 256) {
+            const float pr = expf(x[i] - lse);
+            x[i] = (pr - (i == (int)tgt ? 1.0f : 0.0f)) * inv_denom;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ v, int n, float scale, float* out) {
+    __shared__ float sh[256];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0] * scale;
+}
+
+// out[c] = sum_r x[r*ld + c]; block = 32 columns x 8 row groups, fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, int rows, int cols,
+                                                     float* __restrict__ out) {
+    __shared__ float sh[8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.0f;
+    if (c < cols)
+        for (int r = rg; r < rows; r += 8) s += x[(long)r * ld + c];
+    sh[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        float t = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sh[g][cl];
+        out[c] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fused clamp + Adam (torch.optim.Adam single-tensor arithmetic, train.py:88-91,146)
+__global__ void clamp_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long n, float beta1, float beta2, float eps, float clip,
+                                  float step_size, float bc2_sqrt) {
+    const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pp = ((f32x4*)p)[i], gg = ((f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gk = gg[k];
+            if (clip > 0.0f) gk = fminf(fmaxf(gk, -clip), clip);
+            gg[k] = gk;
+            mm[k] = mm[k] + w1 * (gk - mm[k]);
+            vv[k] = vv[k] * beta2 + (w2 * gk) * gk;
+            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+            pp[k] = pp[k] + (-step_size * mm[k]) / denom;
+        }
+        ((f32x4*)p)[i] = pp; ((f32x4*)g)[i] = gg; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+    }
+    // tail (n % 4)
+    const long base = n4 << 2;
+    const long i = base + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float gk = g[i];
+        if (clip > 0.0f) gk = fminf(fmaxf(gk, -clip), clip);
+        g[i] = gk;
+        const float mk = m[i] + w1 * (gk - m[i]);
+        const float vk = v[i] * beta2 + (w2 * gk) * gk;
+        m[i] = mk; v[i] = vk;
+        p[i] = p[i] + (-step_size * mk) / (sqrtf(vk) / bc2_sqrt + eps);
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (bf16_t)in[i];
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LSTM backward, pointwise part of step t (rows b < n = batch_sizes[t]):
+//   dh = dHS[row] + sum_z dh_part[z][b]  (rows b < n_next only)      dc = dh*o*(1-tc^2) + dc_state[b]
+//   DG[row] = (di*i*(1-i), df*f*(1-f), dg*(1-g^2), do*o*(1-o));      dc_state[b] = dc*f
+__global__ void lstm_bwd_point_kernel(const float* __restrict__ dHS, const float* __restrict__ dh_part, int nz,
+                                      long slab_stride, int n_next, const float* __restrict__ GA,
+                                      const float* __restrict__ CS, const float* __restrict__ CS_prev,
+                                      float* __restrict__ dc_state, float* __restrict__ DG, int n, int H) {
+    const long total = (long)n * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % H);
+        const int b = (int)(i / H);
+        float dh = dHS[i];
+        float dcn = 0.0f;
+        if (b < n_next) {
+            for (int z = 0; z < nz; ++z) dh += dh_part[(long)z * slab_stride + i];
+            dcn = dc_state[i];
+        }
+        const float* ga = GA + (long)b * 4 * H;
+        const float gi = ga[j], gf = ga[H + j], gg = ga[2 * H + j], go = ga[3 * H + j];
+        const float tc = sat_tanh(CS[i]);
+        const float c_prev = CS_prev ? CS_prev[i] : 0.0f;
+        const float d_o = dh * tc;
+        const float dc = dh * go * (1.0f - tc * tc) + dcn;
+        float* dg = DG + (long)b * 4 * H;
+        dg[j] = dc * gg * gi * (1.0f - gi);
+        dg[H + j] = dc * c_prev * gf * (1.0f - gf);
+        dg[2 * H + j] = dc * gi * (1.0f - gg * gg);
+        dg[3 * H + j] = d_o * go * (1.0f - go);
+        dc_state[i] = dc * gf;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// BatchNorm1d head: block = 32 features x 8 row groups
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ part, int nz, long slab_stride,
+                                                       const float* __restrict__ b_fc, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* running_mean,
+                                                       float* running_var, float momentum, float eps, int training,
+                                                       int B, int E, float* __restrict__ zbuf, float* __restrict__ feats,
+                                                       float* __restrict__ xhat, float* __restrict__ rstd_out) {
+    __shared__ float sh[8][32];
+    __shared__ float bc[2][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + cl;
+    const bool ok = e < E;
+    float s = 0.0f;
+    if (ok)
+        for (int b = rg; b < B; b += 8) {
+            float z = b_fc[e];
+            for (int k = 0; k < nz; ++k) z += part[(long)k * slab_stride + (long)b * E + e];
+            zbuf[(long)b * E + e] = z;
+            s += z;
+        }
+    sh[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.0f;
+        for (int g = 0; g < 8; ++g) t += sh[g][cl];
+        bc[0][cl] = t / (float)B;
+    }
+    __syncthreads();
+    float mean = bc[0][cl];
+    float q = 0.0f;
+    if (ok)
+        for (int b = rg; b < B; b += 8) {
+            const float d = zbuf[(long)b * E + e] - mean;
+            q += d * d;
+        }
+    __syncthreads();
+    sh[rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && ok) {
+        float t = 0.0f;
+        for (int g = 0; g < 8; ++g) t += sh[g][cl];
+        float var = t / (float)B;
+        if (training) {
+            const float unb = B > 1 ? t / (float)(B - 1) : var;
+            running_mean[e] = (1.0f - momentum) * running_mean[e] + momentum * mean;
+            running_var[e] = (1.0f - momentum) * running_var[e] + momentum * unb;
+        } else {
+            mean = running_mean[e];
+            var = running_var[e];
+        }
+        const float rs = 1.0f / sqrtf(var + eps);
+        bc[0][cl] = mean;
+        bc[1][cl] = rs;
+        rstd_out[e] = rs;
+    }
+    __syncthreads();
+    if (ok) {
+        const float mu = bc[0][cl], rs = bc[1][cl], ga = gamma[e], be = beta[e];
+        for (int b = rg; b < B; b += 8) {
+            const float xh = (zbuf[(long)b * E + e] - mu) * rs;
+            xhat[(long)b * E + e] = xh;
+            feats[(long)b * E + e] = xh * ga + be;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       int B, int E, float* __restrict__ dz, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, float* __restrict__ db_fc) {
+    __shared__ float s1[8][32], s2[8][32];
+    __shared__ float bc[2][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + cl;
+    const bool ok = e < E;
+    float a = 0.0f, c = 0.0f;
+    if (ok)
+        for (int b = rg; b < B; b += 8) {
+            const float d = dy[(long)b * E + e];
+            a += d * xhat[(long)b * E + e];
+            c += d;
+        }
+    s1[rg][cl] = a; s2[rg][cl] = c;
+    __syncthreads();
+    if (rg == 0) {
+        float ta = 0.0f, tc = 0.0f;
+        for (int g = 0; g < 8; ++g) { ta += s1[g][cl]; tc += s2[g][cl]; }
+        bc[0][cl] = ta; bc[1][cl] = tc;
+        if (ok) { dgamma[e] = ta; dbeta[e] = tc; }
+    }
+    __syncthreads();
+    float zs = 0.0f;
+    if (ok) {
+        const float dga = bc[0][cl], dbe = bc[1][cl];
+        const float k = gamma[e] * rstd[e] / (float)B;
+        for (int b = rg; b < B; b += 8) {
+            const float v = k * ((float)B * dy[(long)b * E + e] - dbe - xhat[(long)b * E + e] * dga);
+            dz[(long)b * E + e] = v;
+            zs += v;
+        }
+    }
+    __syncthreads();
+    s1[rg][cl] = zs;
+    __syncthreads();
+    if (rg == 0 && ok) {
+        float t = 0.0f;
+        for (int g = 0; g < 8; ++g) t += s1[g][cl];
+        db_fc[e] = t;
+    }
+}
+
+}  // namespace
+
+// ======================================================================================================
+// host launchers
+int sat_image_prep_launch(const sat_op* op, hipStream_t s) {
+    if (!op->in0 || !op->out) return SAT_ERR_ARG;
+    const long total = (long)op->N * op->Hin * op->Win;
+    if (op->dtype == SAT_BF16)
+        hipLaunchKernelGGL(image_prep_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const float*)op->in0,
+                           (bf16_t*)op->out, op->N, op->Hin, op->Win, op->Hout, op->Wout, op->pad);
+    else
+        hipLaunchKernelGGL(image_prep_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const float*)op->in0,
+                           (float*)op->out, op->N, op->Hin, op->Win, op->Hout, op->Wout, op->pad);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+int sat_bn_finalize_launch(const sat_op* op, hipStream_t s) {
+    if (!op->gamma || !op->beta || !op->scale_out || !op->shift_out) return SAT_ERR_ARG;
+    if (op->training && !op->stat_partial) return SAT_ERR_ARG;
+    if (!op->training && (!op->running_mean || !op->running_var)) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sat_cdiv(op->Cout, 32)), dim3(256), 0, s, op->stat_partial, op->tiles_m,
+                       op->Cout, (double)op->count, op->gamma, op->beta, op->running_mean, op->running_var,
+                       op->momentum, op->eps, op->training, op->scale_out, op->shift_out);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+template <typename T>
+static int bn_act_launch_t(const sat_op* op, bool add, hipStream_t s) {
+    constexpr int V = Vec<T>::N;
+    const int C = op->Cout;
+    if (C % V) return SAT_ERR_ARG;
+    const long n = (long)op->N * op->Hout * op->Wout * C;
+    const long nch = n / V;
+    if (add)
+        hipLaunchKernelGGL((bn_act_kernel<T, true>), dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, s, (const T*)op->in0,
+                           (const T*)op->in1, (T*)op->out, op->scale0, op->shift0, op->scale1, op->shift1, nch, C);
+    else
+        hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, s, (const T*)op->in0,
+                           (const T*)nullptr, (T*)op->out, op->scale0, op->shift0, (const float*)nullptr,
+                           (const float*)nullptr, nch, C);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+int sat_bn_act_launch(const sat_op* op, bool add, hipStream_t s) {
+    if (!op->in0 || !op->out || !op->scale0 || !op->shift0 || (add && !op->in1)) return SAT_ERR_ARG;
+    return op->dtype == SAT_BF16 ? bn_act_launch_t<bf16_t>(op, add, s) : bn_act_launch_t<float>(op, add, s);
+}
+
+int sat_bn_relu_maxpool_launch(const sat_op* op, hipStream_t s) {
+    if (!op->in0 || !op->out || !op->scale0 || !op->shift0) return SAT_ERR_ARG;
+    const int C = op->Cout;
+    if (op->dtype == SAT_BF16) {
+        if (C % 8) return SAT_ERR_ARG;
+        const long total = (long)op->N * op->Hout * op->Wout * (C / 8);
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const bf16_t*)op->in0,
+                           (bf16_t*)op->out, op->scale0, op->shift0, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
+    } else {
+        if (C % 4) return SAT_ERR_ARG;
+        const long total = (long)op->N * op->Hout * op->Wout * (C / 4);
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const float*)op->in0,
+                           (float*)op->out, op->scale0, op->shift0, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
+    }
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+int sat_avgpool_launch(const sat_op* op, hipStream_t s) {
+    if (!op->in0 || !op->out) return SAT_ERR_ARG;
+    const int C = op->Cout, HW = op->Hin * op->Win;
+    if (op->dtype == SAT_BF16) {
+        if (C % 8) return SAT_ERR_ARG;
+        hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(ew_grid((long)op->N * C / 8)), dim3(EW_BLOCK), 0, s,
+                           (const bf16_t*)op->in0, (float*)op->out, op->N, HW, C);
+    } else {
+        if (C % 4) return SAT_ERR_ARG;
+        hipLaunchKernelGGL(avgpool_kernel<float>, dim3(ew_grid((long)op->N * C / 4)), dim3(EW_BLOCK), 0, s,
+                           (const float*)op->in0, (float*)op->out, op->N, HW, C);
+    }
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+int sat_lstm_bwd_point_launch(const float* dHS, const float* dh_part, int nz, long slab_stride, int n_next,
+                              const float* GA, const float* CS, const float* CS_prev, float* dc_state, float* DG,
+                              int n, int H, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(ew_grid((long)n * H)), dim3(EW_BLOCK), 0, s, dHS, dh_part, nz,
+                       slab_stride, n_next, GA, CS, CS_prev, dc_state, DG, n, H);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+int sat_bn1d_fwd_launch(const float* part, int nz, long slab_stride, const float* b_fc, const float* gamma,
+                        const float* beta, float* rm, float* rv, float momentum, float eps, int training, int B, int E,
+                        float* zbuf, float* feats, float* xhat, float* rstd, hipStream_t s) {
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(sat_cdiv(E, 32)), dim3(256), 0, s, part, nz, slab_stride, b_fc, gamma, beta,
+                       rm, rv, momentum, eps, training, B, E, zbuf, feats, xhat, rstd);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+int sat_bn1d_bwd_launch(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int E,
+                        float* dz, float* dgamma, float* dbeta, float* db_fc, hipStream_t s) {
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(sat_cdiv(E, 32)), dim3(256), 0, s, dy, xhat, rstd, gamma, B, E, dz, dgamma,
+                       dbeta, db_fc);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_embed_concat_fwd(const float* features, const float* embed, const int64_t* captions,
+                                    int64_t cap_stride, const int32_t* prefix, int T, int N, int B, int E, int V,
+                                    float* X, sat_stream_t stream) {
+    if (!features || !embed || !prefix || !X || T < 1 || B < 1 || N < B) return SAT_ERR_ARG;
+    if (T > 1 && !captions) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(embed_concat_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, features, embed, captions,
+                       (long)cap_stride, prefix, T, E, V, X);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_embed_concat_bwd(const float* dX, const int64_t* captions, int64_t cap_stride,
+                                    const int32_t* prefix, int T, int N, int B, int E, int V, float* d_embed,
+                                    float* d_features, sat_stream_t stream) {
+    if (!dX || !prefix || !d_embed || !d_features || T < 1 || B < 1 || N < B) return SAT_ERR_ARG;
+    if (T > 1 && !captions) return SAT_ERR_ARG;
+    if ((long)N * 4 > 150 * 1024) return SAT_ERR_UNSUPPORTED;   // token list is LDS resident
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_embed, 0, (size_t)V * E * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(embed_concat_bwd_kernel, dim3(N), dim3(256), (size_t)N * 4, s, dX, captions, (long)cap_stride,
+                       prefix, T, B, E, V, N, d_embed, d_features);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_embed_rows(const float* embed, const int64_t* ids, int64_t ids_stride, int B, int E, int V,
+                              float* out, sat_stream_t stream) {
+    if (!embed || !ids || !out) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, embed, ids, (long)ids_stride, E, V, out);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_ce_rows(float* logits, const int64_t* targets, int N, int V, float inv_denom, int write_grad,
+                           float* row_loss, float* loss_out, sat_stream_t stream) {
+    if (!logits || !targets || !row_loss || N < 1 || V < 1) return SAT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(N), dim3(256), 0, s, logits, targets, V, inv_denom, write_grad, row_loss);
+    SAT_LAUNCH_CHECK();
+    if (loss_out) {
+        hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, s, row_loss, N, inv_denom, loss_out);
+        SAT_LAUNCH_CHECK();
+    }
+    return SAT_OK;
+}
+
+extern "C" int sat_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, sat_stream_t stream) {
+    if (!x || !out || rows < 1 || cols < 1) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(colsum_kernel, dim3(sat_cdiv(cols, 32)), dim3(256), 0, (hipStream_t)stream, x, (long)ld, rows, cols, out);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_clamp_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                   float beta2, float eps, float clip, int step, sat_stream_t stream) {
+    if (!p || !g || !m || !v || n < 1 || step < 1) return SAT_ERR_ARG;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return SAT_ERR_ARG;
+    // bias corrections in double on the host, exactly as torch.optim.Adam does with python floats
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(clamp_adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v,
+                       (long)n, beta1, beta2, eps, clip, step_size, bc2_sqrt);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_cast_f32_bf16(const float* in, void* out, int64_t n, sat_stream_t stream) {
+    if (!in || !out || n < 1) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, in, (bf16_t*)out, (long)n);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+extern "C" int sat_cast_bf16_f32(const void* in, float* out, int64_t n, sat_stream_t stream) {
+    if (!in || !out || n < 1) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)in, out, (long)n);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+// targets = pack_padded_sequence(captions[:,1:], lengths-1).data (train.py:134-135): out[row(t,b)] = captions[b][t+1]
+namespace {
+__global__ void pack_targets_kernel(const int64_t* __restrict__ captions, long cap_stride, const int* __restrict__ prefix,
+                                    int T, int N, int64_t* __restrict__ out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    const int t = find_step(prefix, T, row);
+    out[row] = captions[(long)(row - prefix[t]) * cap_stride + t + 1];
+}
+}  // namespace
+
+extern "C" int sat_pack_targets(const int64_t* captions, int64_t cap_stride, const int32_t* prefix, int T, int N,
+                                int64_t* targets, sat_stream_t stream) {
+    if (!captions || !prefix || !targets || T < 1 || N < 1) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(pack_targets_kernel, dim3(sat_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, captions,
+                       (long)cap_stride, prefix, T, N, targets);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}

@@ -1,0 +1,198 @@
+// Host-side orchestration of the hot path: the encoder op program (models.py:25-29), one LSTM layer
+// forward / backward over a packed batch (models.py:52, train.py:144), the vocab projection + CE
+// (models.py:53, train.py:143) and the encoder head.  Launch-only code: no allocation, no host sync,
+// so a whole training step can be captured into one hipGraph by the caller.
+#include "sat_internal.h"
+#include <stdio.h>
+
+extern "C" int sat_version(void) { return SAT_ABI_VERSION; }
+
+extern "C" const char* sat_error_string(int code) {
+    switch (code) {
+        case SAT_OK: return "ok";
+        case SAT_ERR_ARG: return "sat: bad argument (null pointer, shape or alignment)";
+        case SAT_ERR_WORKSPACE: return "sat: workspace too small";
+        case SAT_ERR_UNSUPPORTED: return "sat: unsupported configuration";
+        default: return hipGetErrorString((hipError_t)code);
+    }
+}
+
+extern "C" int sat_run_ops(const sat_op* ops, int n_ops, sat_stream_t stream) {
+    if (!ops || n_ops < 0) return SAT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n_ops; ++i) {
+        const sat_op* op = ops + i;
+        int rc;
+        switch (op->kind) {
+            case SAT_OP_IMAGE_PREP: rc = sat_image_prep_launch(op, s); break;
+            case SAT_OP_CONV: rc = sat_conv_launch(op, s); break;
+            case SAT_OP_BN_FINALIZE: rc = sat_bn_finalize_launch(op, s); break;
+            case SAT_OP_BN_RELU: rc = sat_bn_act_launch(op, false, s); break;
+            case SAT_OP_BN_ADD_RELU: rc = sat_bn_act_launch(op, true, s); break;
+            case SAT_OP_BN_RELU_MAXPOOL: rc = sat_bn_relu_maxpool_launch(op, s); break;
+            case SAT_OP_AVGPOOL: rc = sat_avgpool_launch(op, s); break;
+            default: rc = SAT_ERR_UNSUPPORTED;
+        }
+        if (rc != SAT_OK) return rc;
+    }
+    return SAT_OK;
+}
+
+extern "C" int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, const sat_op* bnrelu,
+                                    sat_stream_t stream) {
+    if (!conv || !finalize || !bnrelu) return SAT_ERR_ARG;
+    if (conv->kind != SAT_OP_CONV || finalize->kind != SAT_OP_BN_FINALIZE || bnrelu->kind != SAT_OP_BN_RELU)
+        return SAT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    SAT_TRY(sat_conv_launch(conv, s));
+    SAT_TRY(sat_bn_finalize_launch(finalize, s));
+    return sat_bn_act_launch(bnrelu, false, s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// encoder head
+static int fc_split(int F) { return F >= 1024 ? 8 : (F >= 256 ? 4 : 1); }
+
+extern "C" int64_t sat_fc_bn1d_ws_bytes(int B, int F, int E) {
+    return (int64_t)(fc_split(F) + 1) * B * E * sizeof(float);
+}
+
+extern "C" int sat_fc_bn1d_fwd(const float* pooled, const float* w_fc, const float* b_fc, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               int training, int B, int F, int E, float* feats, float* xhat, float* rstd,
+                               float* workspace, int64_t ws_bytes, sat_stream_t stream) {
+    if (!pooled || !w_fc || !b_fc || !gamma || !beta || !running_mean || !running_var || !feats || !xhat || !rstd ||
+        !workspace)
+        return SAT_ERR_ARG;
+    if (ws_bytes < sat_fc_bn1d_ws_bytes(B, F, E)) return SAT_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nz = fc_split(F);
+    float* part = workspace;                     // [nz][B][E]
+    float* zbuf = workspace + (long)nz * B * E;  // [B][E]
+    SAT_TRY(sat_skinny_store(pooled, F, w_fc, F, 0, B, E, F, nz, part, E, (long)B * E, nullptr, s));
+    return sat_bn1d_fwd_launch(part, nz, (long)B * E, b_fc, gamma, beta, running_mean, running_var, momentum, eps,
+                               training, B, E, zbuf, feats, xhat, rstd, s);
+}
+
+extern "C" int sat_fc_bn1d_bwd(const float* dy, const float* pooled, const float* xhat, const float* rstd,
+                               const float* gamma, int B, int F, int E, float* dw_fc, float* db_fc, float* dgamma,
+                               float* dbeta, float* workspace, int64_t ws_bytes, sat_stream_t stream) {
+    if (!dy || !pooled || !xhat || !rstd || !gamma || !dw_fc || !db_fc || !dgamma || !dbeta || !workspace)
+        return SAT_ERR_ARG;
+    if (ws_bytes < (int64_t)B * E * (int64_t)sizeof(float)) return SAT_ERR_WORKSPACE;
+    if ((E & 3) || (F & 3)) return SAT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    float* dz = workspace;
+    SAT_TRY(sat_bn1d_bwd_launch(dy, xhat, rstd, gamma, B, E, dz, dgamma, dbeta, db_fc, s));
+    // dW_fc[E,F] = dz^T[E,B] * pooled[B,F]
+    return sat_gemm_f32(2, 1, dz, E, pooled, F, dw_fc, F, nullptr, nullptr, E, F, B, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LSTM layer over a packed batch
+extern "C" int sat_lstm_fwd(const float* X, const float* w_ih, const float* w_hh, const float* b_ih,
+                            const float* b_hh, const int32_t* batch_sizes, int T, int In, int H, float* GA,
+                            float* CS, float* HS, float* HP, float* c_state, sat_stream_t stream) {
+    if (!X || !w_ih || !w_hh || !b_ih || !b_hh || !batch_sizes || !GA || !CS || !HS || !HP || !c_state || T < 1)
+        return SAT_ERR_ARG;
+    if ((In & 3) || (H & 3)) return SAT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = batch_sizes[0];
+    long N = 0;
+    for (int t = 0; t < T; ++t) {
+        if (batch_sizes[t] < 1 || (t > 0 && batch_sizes[t] > batch_sizes[t - 1])) return SAT_ERR_ARG;
+        N += batch_sizes[t];
+    }
+    // x-gates for every packed row in one batched MFMA GEMM: GA = X * W_ih^T + b_ih + b_hh
+    SAT_TRY(sat_gemm_f32(0, 0, X, In, w_ih, In, GA, 4L * H, b_ih, b_hh, (int)N, 4 * H, In, stream));
+    hipError_t e = hipMemsetAsync(c_state, 0, (size_t)B * H * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(HP, 0, (size_t)B * H * sizeof(float), s);   // h_{-1} = 0 for the rows of step 0
+    if (e != hipSuccess) return (int)e;
+    long off = 0;
+    for (int t = 0; t < T; ++t) {
+        const int n = batch_sizes[t];
+        const int n_next = (t + 1 < T) ? batch_sizes[t + 1] : 0;
+        float* ga = GA + off * 4 * H;
+        // recurrent step: gates = x-gates + h_{t-1} * W_hh^T; activated gates overwrite the x-gates in place
+        SAT_TRY(sat_skinny_lstm(HP + off * H, w_hh, nullptr, nullptr, 0, nullptr, nullptr, ga, 4L * H, n, H, c_state,
+                                ga, 4L * H, CS + off * H, HS + off * H, n_next ? HP + (off + n) * H : nullptr, n_next, s));
+        off += n;
+    }
+    return SAT_OK;
+}
+
+static int lstm_bwd_split(int H) {
+    const int ncg = sat_cdiv(H, 16);
+    int nz = 256 / (ncg > 0 ? ncg : 1);
+    return nz < 1 ? 1 : (nz > 16 ? 16 : nz);
+}
+
+extern "C" int64_t sat_lstm_bwd_ws_bytes(int B, int H) {
+    return (int64_t)(lstm_bwd_split(H) + 1) * B * H * sizeof(float);
+}
+
+extern "C" int sat_lstm_bwd(const float* dHS, const float* X, const float* w_ih, const float* w_hh, const float* GA,
+                            const float* CS, const float* HP, const int32_t* batch_sizes, int T, int In, int H,
+                            float* DG, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dX,
+                            float* workspace, int64_t ws_bytes, sat_stream_t stream) {
+    if (!dHS || !X || !w_ih || !w_hh || !GA || !CS || !HP || !batch_sizes || !DG || !dw_ih || !dw_hh || !db_ih ||
+        !db_hh || !workspace || T < 1)
+        return SAT_ERR_ARG;
+    if ((In & 3) || (H & 3)) return SAT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = batch_sizes[0];
+    if (ws_bytes < sat_lstm_bwd_ws_bytes(B, H)) return SAT_ERR_WORKSPACE;
+    long N = 0;
+    for (int t = 0; t < T; ++t) N += batch_sizes[t];
+    const int nz = lstm_bwd_split(H);
+    const long slab = (long)B * H;
+    float* dh_part = workspace;              // [nz][B][H]
+    float* dc_state = workspace + nz * slab; // [B][H]
+    hipError_t e = hipMemsetAsync(dc_state, 0, (size_t)slab * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    long off = N;
+    for (int t = T - 1; t >= 0; --t) {
+        const int n = batch_sizes[t];
+        off -= n;
+        const int n_next = (t + 1 < T) ? batch_sizes[t + 1] : 0;
+        const float* cs_prev = (t > 0) ? CS + (off - batch_sizes[t - 1]) * H : nullptr;
+        SAT_TRY(sat_lstm_bwd_point_launch(dHS + off * H, dh_part, nz, slab, n_next, GA + off * 4 * H, CS + off * H,
+                                          cs_prev, dc_state, DG + off * 4 * H, n, H, s));
+        if (t > 0)   // dh_{t-1} partial slabs = DG_t * W_hh   (K = 4H split over nz workgroup slices)
+            SAT_TRY(sat_skinny_store(DG + off * 4 * H, 4L * H, w_hh, H, 1, n, H, 4 * H, nz, dh_part, H, slab, nullptr, s));
+    }
+    // batched weight gradients over all packed rows
+    SAT_TRY(sat_gemm_f32(2, 1, DG, 4L * H, X, In, dw_ih, In, nullptr, nullptr, 4 * H, In, (int)N, stream));
+    SAT_TRY(sat_gemm_f32(2, 1, DG, 4L * H, HP, H, dw_hh, H, nullptr, nullptr, 4 * H, H, (int)N, stream));
+    SAT_TRY(sat_colsum_f32(DG, 4L * H, (int)N, 4 * H, db_ih, stream));
+    e = hipMemcpyAsync(db_hh, db_ih, (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    if (dX) SAT_TRY(sat_gemm_f32(0, 1, DG, 4L * H, w_ih, In, dX, In, nullptr, nullptr, (int)N, In, 4 * H, stream));
+    return SAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// vocab projection + CE
+extern "C" int sat_vocab_logits_fwd(const float* Hs, const float* w, const float* b, int N, int H, int V,
+                                    float* logits, sat_stream_t stream) {
+    if (!Hs || !w || !b || !logits) return SAT_ERR_ARG;
+    return sat_gemm_f32(0, 0, Hs, H, w, H, logits, V, b, nullptr, N, V, H, stream);
+}
+
+extern "C" int sat_vocab_ce_fwd(const float* Hs, const float* w, const float* b, const int64_t* targets, int N,
+                                int H, int V, float inv_denom, int write_grad, float* logits, float* row_loss,
+                                float* loss_out, sat_stream_t stream) {
+    SAT_TRY(sat_vocab_logits_fwd(Hs, w, b, N, H, V, logits, stream));
+    return sat_ce_rows(logits, targets, N, V, inv_denom, write_grad, row_loss, loss_out, stream);
+}
+
+extern "C" int sat_vocab_ce_bwd(const float* dlogits, const float* Hs, const float* w, int N, int H, int V,
+                                float* dw, float* db, float* dHs, sat_stream_t stream) {
+    if (!dlogits || !Hs || !w || !dw || !db || !dHs) return SAT_ERR_ARG;
+    if ((V & 3) || (H & 3)) return SAT_ERR_UNSUPPORTED;
+    // dW[V,H] = dlogits^T * Hs ;  db = colsum(dlogits) ;  dHs[N,H] = dlogits * W
+    SAT_TRY(sat_gemm_f32(2, 1, dlogits, V, Hs, H, dw, H, nullptr, nullptr, V, H, N, stream));
+    SAT_TRY(sat_colsum_f32(dlogits, V, N, V, db, stream));
+    return sat_gemm_f32(0, 1, dlogits, V, w, H, dHs, H, nullptr, nullptr, N, H, V, stream);
+}

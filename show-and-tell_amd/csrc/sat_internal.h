@@ -1,0 +1,32 @@
+// Host-side launchers shared between the translation units of libsat_hip.so (not part of the C ABI).
+#pragma once
+#include "sat_common.h"
+#include "../../include/sat_hip.h"
+
+int sat_conv_launch(const sat_op* op, hipStream_t s);
+int sat_image_prep_launch(const sat_op* op, hipStream_t s);
+int sat_bn_finalize_launch(const sat_op* op, hipStream_t s);
+int sat_bn_act_launch(const sat_op* op, bool add, hipStream_t s);
+int sat_bn_relu_maxpool_launch(const sat_op* op, hipStream_t s);
+int sat_avgpool_launch(const sat_op* op, hipStream_t s);
+
+int sat_skinny_store(const float* A, long lda, const float* W, long ldw, int wkm, int M, int N, int K, int nz,
+                     float* out, long ldo, long slab_stride, const float* bias, hipStream_t s);
+int sat_skinny_lstm(const float* h_prev, const float* w_hh, const float* x, const float* w_ih, int In,
+                    const float* bias, const float* bias2, const float* xg, long ldxg, int M, int H,
+                    float* c_state, float* ga, long ldga, float* cs, float* h_out, float* h_out2, int m2,
+                    hipStream_t s);
+int sat_lstm_bwd_point_launch(const float* dHS, const float* dh_part, int nz, long slab_stride, int n_next,
+                              const float* GA, const float* CS, const float* CS_prev, float* dc_state, float* DG,
+                              int n, int H, hipStream_t s);
+int sat_bn1d_fwd_launch(const float* part, int nz, long slab_stride, const float* b_fc, const float* gamma,
+                        const float* beta, float* rm, float* rv, float momentum, float eps, int training, int B, int E,
+                        float* zbuf, float* feats, float* xhat, float* rstd, hipStream_t s);
+int sat_bn1d_bwd_launch(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int E,
+                        float* dz, float* dgamma, float* dbeta, float* db_fc, hipStream_t s);
+
+#define SAT_TRY(expr)                 \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__ != SAT_OK) return rc__; \
+    } while (0)

@@ -1,0 +1,366 @@
+"""Drop-in `models` module: `EncoderCNN` / `DecoderRNN` with the reference's constructor and forward()/sample()
+signatures (`/root/reference/models.py:9-67`), every tensor op behind them a libsat_hip.so kernel.
+
+    EncoderCNN(embed_size).forward(images f32[B,3,H,W]) -> f32[B,embed_size]              (models.py:10,25)
+    DecoderRNN(embed_size, hidden_size, vocab_size, num_layers)
+        .forward(features, captions i64[B,T'], lengths list[int] desc) -> f32[sum(lengths), V]   (models.py:47-54)
+        .sample(features, states=None) -> i64[B,20]                                        (models.py:56-67)
+    ShowAndTell(...)(images, captions, lengths) / .sample(images, state): the single-module contract the
+        reference trainer uses (train.py:139, eval.py:93,99).
+
+`state_dict()` key names equal the reference's (`resnet.*`, `bn.*`, `embed.weight`, `lstm.weight_ih_l{k}`, ...,
+`linear.weight`, `linear.bias`).  Parameters are ordinary nn.Parameters with `.grad`, so the reference's
+`clip_gradient` + `optim.Adam` loop works unchanged; `trainer.TrainStep` is the fused HIP replacement.
+The modules run on the GPU only: there is no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .pack import PackInfo
+from .resnet import RESNET152, ConvStackProgram, ResNetStack
+
+BN1D_MOMENTUM = 0.01   # models.py:17
+BN_EPS = 1e-5
+
+
+def _f32c(t, name):
+    L.require_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32" % name)
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------
+# encoder
+class _HeadFn(torch.autograd.Function):
+    """resnet.fc + BatchNorm1d (models.py:16-17,27-28) -- sat_fc_bn1d_fwd / sat_fc_bn1d_bwd."""
+
+    @staticmethod
+    def forward(ctx, pooled, w_fc, b_fc, gamma, beta, running_mean, running_var, training):
+        lib = L.load()
+        B, F = pooled.shape
+        E = w_fc.shape[0]
+        dev = pooled.device
+        feats = torch.empty(B, E, device=dev)
+        xhat = torch.empty(B, E, device=dev)
+        rstd = torch.empty(E, device=dev)
+        wsb = lib.sat_fc_bn1d_ws_bytes(B, F, E)
+        ws = torch.empty(wsb // 4, device=dev)
+        L.check(lib.sat_fc_bn1d_fwd(L.ptr(pooled), L.ptr(w_fc), L.ptr(b_fc), L.ptr(gamma), L.ptr(beta),
+                                    L.ptr(running_mean), L.ptr(running_var), BN1D_MOMENTUM, BN_EPS,
+                                    1 if training else 0, B, F, E, L.ptr(feats), L.ptr(xhat), L.ptr(rstd),
+                                    L.ptr(ws), wsb, L.stream()), "sat_fc_bn1d_fwd")
+        ctx.save_for_backward(pooled, xhat, rstd, gamma)
+        ctx.training = training
+        return feats
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("EncoderCNN backward is only defined in training mode (batch statistics)")
+        lib = L.load()
+        pooled, xhat, rstd, gamma = ctx.saved_tensors
+        B, F = pooled.shape
+        E = gamma.shape[0]
+        dev = pooled.device
+        dy = dy.contiguous()
+        dw = torch.empty(E, F, device=dev)
+        db = torch.empty(E, device=dev)
+        dg = torch.empty(E, device=dev)
+        dbe = torch.empty(E, device=dev)
+        ws = torch.empty(B * E, device=dev)
+        L.check(lib.sat_fc_bn1d_bwd(L.ptr(dy), L.ptr(pooled), L.ptr(xhat), L.ptr(rstd), L.ptr(gamma), B, F, E,
+                                    L.ptr(dw), L.ptr(db), L.ptr(dg), L.ptr(dbe), L.ptr(ws), B * E * 4, L.stream()),
+                "sat_fc_bn1d_bwd")
+        return None, dw, db, dg, dbe, None, None, None
+
+
+class _BN1d(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
+
+
+class EncoderCNN(nn.Module):
+    """models.py:9-29.  `arch`/`compute_dtype` are build extensions (defaults = the reference: ResNet-152).
+    compute_dtype: 'bf16' (MFMA bf16, f32 accumulate; throughput) or 'f32' (exact-f32 MFMA; parity)."""
+
+    def __init__(self, embed_size, arch=RESNET152, compute_dtype="bf16"):
+        super().__init__()
+        self.resnet = ResNetStack(embed_size, arch)         # frozen stack + trainable fc (models.py:13-16)
+        self.bn = _BN1d(embed_size)                         # models.py:17
+        self.compute_dtype = compute_dtype
+        self._programs = {}
+        self.register_load_state_dict_post_hook(lambda m, k: m._programs.clear())
+
+    def init_weights(self):
+        """models.py:20-23."""
+        self.resnet.fc.weight.data.normal_(0.0, 0.02)
+        self.resnet.fc.bias.data.fill_(0)
+
+    def _apply(self, fn, *a, **k):
+        self._programs.clear()      # device / dtype moves invalidate cached device pointers
+        return super()._apply(fn, *a, **k)
+
+    def _program(self, images):
+        N, _, H, W = images.shape
+        dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
+        key = (N, H, W, dt, self.training, str(images.device), self.resnet.conv1.weight.data_ptr())
+        prog = self._programs.get(key)
+        if prog is None:
+            if len(self._programs) >= 4:
+                self._programs.clear()
+            prog = self._programs[key] = ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device)
+        return prog
+
+    def pooled_features(self, images):
+        """conv stack + global average pool: f32 [B, 2048] (no autograd: the stack is frozen, models.py:14-15)."""
+        L.require_gpu(images, "images")
+        with torch.no_grad():
+            return self._program(images).run(images)
+
+    def forward(self, images):
+        """Extract the image feature vectors (models.py:25-29)."""
+        pooled = self.pooled_features(images)
+        out = _HeadFn.apply(pooled, self.resnet.fc.weight, self.resnet.fc.bias, self.bn.weight, self.bn.bias,
+                            self.bn.running_mean, self.bn.running_var, self.training)
+        if self.training:
+            self.bn.num_batches_tracked += 1
+        return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# decoder
+class _LSTMParams(nn.Module):
+    """Parameter holder with nn.LSTM's names and default init U(-1/sqrt(H), 1/sqrt(H)) (models.py:36)."""
+
+    def __init__(self, input_size, hidden_size, num_layers):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        k = 1.0 / (hidden_size ** 0.5)
+        for l in range(num_layers):
+            in_sz = input_size if l == 0 else hidden_size
+            for name, shape in (("weight_ih", (4 * hidden_size, in_sz)), ("weight_hh", (4 * hidden_size, hidden_size)),
+                                ("bias_ih", (4 * hidden_size,)), ("bias_hh", (4 * hidden_size,))):
+                setattr(self, "%s_l%d" % (name, l), nn.Parameter(torch.empty(*shape).uniform_(-k, k)))
+
+    def layer(self, l):
+        return tuple(getattr(self, "%s_l%d" % (n, l)) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+
+
+class _Weight(nn.Module):
+    def __init__(self, *shape, bias=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape))
+        if bias is not None:
+            self.bias = nn.Parameter(torch.zeros(bias))
+
+
+def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, captions, pi, logits=None):
+    """embed+cat+pack -> L x LSTM -> vocab logits (models.py:49-53).  Returns (logits, tapes)."""
+    dev = features.device
+    E = embed_w.shape[1]
+    V = lin_w.shape[0]
+    N, T, B = pi.N, pi.T, pi.B
+    st = L.stream()
+    X = torch.empty(N, E, device=dev)
+    cap_ptr, cap_stride = (None, 0)
+    if T > 1:
+        if captions.dtype != torch.int64 or captions.stride(1) != 1:
+            captions = captions.long().contiguous()
+        if captions.shape[1] < T - 1:
+            raise ValueError("captions has %d columns but lengths need %d" % (captions.shape[1], T - 1))
+        cap_ptr, cap_stride = captions.data_ptr(), captions.stride(0)
+    L.check(lib.sat_embed_concat_fwd(L.ptr(features), L.ptr(embed_w), cap_ptr, cap_stride, L.ptr(pi.prefix_dev),
+                                     T, N, B, E, embed_w.shape[0], L.ptr(X), st), "sat_embed_concat_fwd")
+    tapes = {"X": [X], "layers": [], "captions": captions}
+    inp = X
+    for (w_ih, w_hh, b_ih, b_hh) in lstm_layers:
+        H = w_hh.shape[1]
+        In = w_ih.shape[1]
+        GA = torch.empty(N, 4 * H, device=dev)
+        CS = torch.empty(N, H, device=dev)
+        HS = torch.empty(N, H, device=dev)
+        HP = torch.empty(N, H, device=dev)
+        cst = torch.empty(B, H, device=dev)
+        L.check(lib.sat_lstm_fwd(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), pi.bs_c, T, In, H,
+                                 L.ptr(GA), L.ptr(CS), L.ptr(HS), L.ptr(HP), L.ptr(cst), st), "sat_lstm_fwd")
+        tapes["layers"].append((GA, CS, HP))
+        tapes["X"].append(HS)
+        inp = HS
+    if logits is None:
+        logits = torch.empty(N, V, device=dev)
+    L.check(lib.sat_vocab_logits_fwd(L.ptr(inp), L.ptr(lin_w), L.ptr(lin_b), N, lin_w.shape[1], V, L.ptr(logits), st),
+            "sat_vocab_logits_fwd")
+    return logits, tapes
+
+
+def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi, grads_out, on_stage=None):
+    """Backward of decoder_forward_tapes.  grads_out: dict name -> preallocated f32 tensor to fill:
+    'embed', ('w_ih',l), ('w_hh',l), ('b_ih',l), ('b_hh',l), 'lin_w', 'lin_b', 'features'.
+    on_stage(i) is called when gradient group i is final (0 vocab projection, 1 LSTM) -- the data-parallel
+    wrapper launches that bucket's all-reduce there, under the remaining backward kernels."""
+    dev = dlogits.device
+    st = L.stream()
+    N, T, B = pi.N, pi.T, pi.B
+    V, Hl = lin_w.shape
+    Xtop = tapes["X"][-1]
+    dH = torch.empty(N, Hl, device=dev)
+    L.check(lib.sat_vocab_ce_bwd(L.ptr(dlogits), L.ptr(Xtop), L.ptr(lin_w), N, Hl, V, L.ptr(grads_out["lin_w"]),
+                                 L.ptr(grads_out["lin_b"]), L.ptr(dH), st), "sat_vocab_ce_bwd")
+    if on_stage is not None:
+        on_stage(0)
+    for l in reversed(range(len(lstm_layers))):
+        w_ih, w_hh, _, _ = lstm_layers[l]
+        H, In = w_hh.shape[1], w_ih.shape[1]
+        GA, CS, HP = tapes["layers"][l]
+        DG = torch.empty(N, 4 * H, device=dev)
+        dX = torch.empty(N, In, device=dev)
+        wsb = lib.sat_lstm_bwd_ws_bytes(B, H)
+        ws = torch.empty(wsb // 4, device=dev)
+        L.check(lib.sat_lstm_bwd(L.ptr(dH), L.ptr(tapes["X"][l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(GA), L.ptr(CS),
+                                 L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
+                                 L.ptr(grads_out[("w_hh", l)]), L.ptr(grads_out[("b_ih", l)]),
+                                 L.ptr(grads_out[("b_hh", l)]), L.ptr(dX), L.ptr(ws), wsb, st), "sat_lstm_bwd")
+        dH = dX
+    if on_stage is not None:
+        on_stage(1)
+    E = embed_w.shape[1]
+    caps = tapes["captions"]
+    cap_ptr, cap_stride = (None, 0) if T <= 1 else (caps.data_ptr(), caps.stride(0))
+    L.check(lib.sat_embed_concat_bwd(L.ptr(dH), cap_ptr, cap_stride, L.ptr(pi.prefix_dev), T, N, B, E,
+                                     embed_w.shape[0], L.ptr(grads_out["embed"]), L.ptr(grads_out["features"]), st),
+            "sat_embed_concat_bwd")
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, captions, pi, num_layers, embed_w, lin_w, lin_b, *lstm_flat):
+        lib = L.load()
+        layers = [tuple(lstm_flat[4 * l:4 * l + 4]) for l in range(num_layers)]
+        logits, tapes = decoder_forward_tapes(lib, features, embed_w, layers, lin_w, lin_b, captions, pi)
+        ctx.tapes, ctx.pi, ctx.layers = tapes, pi, layers
+        ctx.embed_w, ctx.lin_w = embed_w, lin_w
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = L.load()
+        dev = dlogits.device
+        dlogits = dlogits.contiguous()
+        layers = ctx.layers
+        g = {"embed": torch.empty_like(ctx.embed_w), "lin_w": torch.empty_like(ctx.lin_w),
+             "lin_b": torch.empty(ctx.lin_w.shape[0], device=dev),
+             "features": torch.empty(ctx.pi.B, ctx.embed_w.shape[1], device=dev)}
+        for l, (w_ih, w_hh, b_ih, b_hh) in enumerate(layers):
+            g[("w_ih", l)], g[("w_hh", l)] = torch.empty_like(w_ih), torch.empty_like(w_hh)
+            g[("b_ih", l)], g[("b_hh", l)] = torch.empty_like(b_ih), torch.empty_like(b_hh)
+        decoder_backward_tapes(lib, dlogits, ctx.tapes, ctx.embed_w, layers, ctx.lin_w, ctx.pi, g)
+        flat = []
+        for l in range(len(layers)):
+            flat += [g[("w_ih", l)], g[("w_hh", l)], g[("b_ih", l)], g[("b_hh", l)]]
+        return (g["features"], None, None, None, g["embed"], g["lin_w"], g["lin_b"], *flat)
+
+
+class DecoderRNN(nn.Module):
+    """models.py:31-67."""
+
+    def __init__(self, embed_size, hidden_size, vocab_size, num_layers):
+        super().__init__()
+        self.embed = _Weight(vocab_size, embed_size)                     # nn.Embedding (models.py:35)
+        self.lstm = _LSTMParams(embed_size, hidden_size, num_layers)     # nn.LSTM(batch_first) (models.py:36)
+        self.linear = _Weight(vocab_size, hidden_size, bias=vocab_size)  # nn.Linear (models.py:37)
+        self.embed_size, self.hidden_size, self.vocab_size, self.num_layers = embed_size, hidden_size, vocab_size, num_layers
+        self.ss_prob = 0                                                 # inert in the reference too (models.py:38)
+        self.init_weights()
+
+    def init_weights(self):
+        """models.py:41-45."""
+        self.embed.weight.data.uniform_(-0.1, 0.1)
+        self.linear.weight.data.uniform_(-0.1, 0.1)
+        self.linear.bias.data.fill_(0)
+
+    def _lstm_flat(self):
+        flat = []
+        for l in range(self.num_layers):
+            flat += list(self.lstm.layer(l))
+        return flat
+
+    def forward(self, features, captions, lengths):
+        """Decode image feature vectors and generate caption logits (models.py:47-54): f32 [sum(lengths), V],
+        rows in time-major packed order."""
+        features = _f32c(features, "features")
+        L.require_gpu(captions, "captions")
+        if len(lengths) != features.shape[0]:
+            raise ValueError("len(lengths) != batch size")
+        pi = PackInfo.get(lengths, features.device)
+        if pi.T > captions.shape[1] + 1:
+            raise ValueError("a length exceeds captions.shape[1] + 1")
+        return _DecoderFn.apply(features, captions, pi, self.num_layers, self.embed.weight, self.linear.weight,
+                                self.linear.bias, *self._lstm_flat())
+
+    @torch.no_grad()
+    def sample(self, features, states=None):
+        """Greedy search, 20 steps (models.py:56-67; torch-0.1 keepdim semantics): i64 [B,20].
+        `states`: None (zeros, as eval.py:82-83 passes) or (h0, c0) each [num_layers, B, H]."""
+        lib = L.load()
+        features = _f32c(features, "features")
+        dev = features.device
+        B = features.shape[0]
+        H, V, E = self.hidden_size, self.vocab_size, self.embed_size
+        st = L.stream()
+        h = [torch.zeros(B, H, device=dev) for _ in range(self.num_layers)]
+        h2 = [torch.empty(B, H, device=dev) for _ in range(self.num_layers)]
+        c = [torch.zeros(B, H, device=dev) for _ in range(self.num_layers)]
+        if states is not None and isinstance(states, (tuple, list)) and states[0].dim() == 3:
+            for l in range(self.num_layers):
+                h[l].copy_(states[0][l])
+                c[l].copy_(states[1][l])
+        ids = torch.empty(B, 20, dtype=torch.int64, device=dev)
+        wsb = lib.sat_vocab_argmax_ws_bytes(B, V)
+        ws = torch.empty(wsb // 4, device=dev)
+        x = features
+        xe = torch.empty(B, E, device=dev)
+        for i in range(20):
+            inp = x
+            for l in range(self.num_layers):
+                w_ih, w_hh, b_ih, b_hh = self.lstm.layer(l)
+                L.check(lib.sat_lstm_step(L.ptr(inp), L.ptr(h[l]), L.ptr(c[l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih),
+                                          L.ptr(b_hh), B, w_ih.shape[1], H, L.ptr(h2[l]), st), "sat_lstm_step")
+                h[l], h2[l] = h2[l], h[l]
+                inp = h[l]
+            col = ids[:, i]
+            L.check(lib.sat_vocab_argmax(L.ptr(inp), L.ptr(self.linear.weight), L.ptr(self.linear.bias), B, H, V,
+                                         col.data_ptr(), ids.stride(0), L.ptr(ws), wsb, st), "sat_vocab_argmax")
+            L.check(lib.sat_embed_rows(L.ptr(self.embed.weight), col.data_ptr(), ids.stride(0), B, E, V, L.ptr(xe), st),
+                    "sat_embed_rows")
+            x = xe
+        return ids
+
+
+class ShowAndTell(nn.Module):
+    """Encoder + decoder behind the reference trainer's single-module call contract (train.py:37,139;
+    eval.py:93,99): `model(images, captions, lengths)` and `model.sample(images, state)`.
+    state_dict keys: `encoder.*`, `decoder.*`."""
+
+    def __init__(self, embed_size, hidden_size, vocab_size, num_layers=1, arch=RESNET152, compute_dtype="bf16"):
+        super().__init__()
+        self.encoder = EncoderCNN(embed_size, arch, compute_dtype)
+        self.decoder = DecoderRNN(embed_size, hidden_size, vocab_size, num_layers)
+
+    def forward(self, images, captions, lengths):
+        return self.decoder(self.encoder(images), captions, lengths)
+
+    @torch.no_grad()
+    def sample(self, images, state=None):
+        return self.decoder.sample(self.encoder(images), None)
+
+
+Encoder = EncoderCNN      # names BASELINE.json uses
+Decoder = DecoderRNN
+CaptionModel = ShowAndTell

@@ -1,0 +1,313 @@
+"""The frozen ResNet conv stack of `EncoderCNN` (`/root/reference/models.py:13-15,27`) as an op program for
+libsat_hip.so.
+
+Host side only: this module owns the parameters (torchvision key names, so a `resnet152` state_dict loads
+as is), lays the weights out for the kernels (OHWI, optional bf16 shadow), carves the activation
+workspace and emits the `sat_op` array that `sat_run_ops` launches in ONE call per forward.  All arithmetic
+is in the HIP kernels (csrc/sat_gemm.hip implicit-GEMM conv, csrc/sat_elementwise.hip batch-norm / pooling).
+
+Layout: activations NHWC (channels contiguous -> the implicit-GEMM K axis is contiguous), dtype bf16
+(throughput) or f32 (parity).  Per bottleneck (torchvision v1.5: stride on the 3x3):
+    c1 = conv1x1(y)      stats -> (s1,t1)    a1 = relu(c1*s1+t1)
+    c2 = conv3x3(a1)     stats -> (s2,t2)    a2 = relu(c2*s2+t2)
+    c3 = conv1x1(a2)     stats -> (s3,t3)    [cd = conv1x1(y), stats -> (sd,td)]
+    y' = relu(c3*s3+t3 + (cd*sd+td | y))
+Batch statistics come out of the conv epilogue as per-tile column sums (fixed-order reduction, no atomics).
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+RESNET152 = dict(layers=(3, 8, 36, 3), width=64)
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, stride, pad):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")     # torchvision resnet init
+        self.weight = nn.Parameter(w, requires_grad=False)                  # models.py:14-15 (frozen)
+
+
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(c), requires_grad=False)
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1, self.bn1 = _Conv(inplanes, planes, 1, 1, 0), _BN(planes)
+        self.conv2, self.bn2 = _Conv(planes, planes, 3, stride, 1), _BN(planes)
+        self.conv3, self.bn3 = _Conv(planes, planes * 4, 1, 1, 0), _BN(planes * 4)
+        if downsample:
+            self.downsample = nn.ModuleList([_Conv(inplanes, planes * 4, 1, stride, 0), _BN(planes * 4)])
+        else:
+            self.downsample = None
+
+
+class _FC(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.in_features, self.out_features = fin, fout
+        self.weight = nn.Parameter(torch.empty(fout, fin).normal_(0.0, 0.02))   # models.py:22
+        self.bias = nn.Parameter(torch.zeros(fout))                             # models.py:23
+
+
+class ResNetStack(nn.Module):
+    """Parameter tree with torchvision's names: conv1, bn1, layer{1..4}.{i}.{conv,bn}{1,2,3}, downsample.{0,1}, fc."""
+
+    def __init__(self, embed_size, arch=RESNET152):
+        super().__init__()
+        self.arch = dict(arch)
+        w = arch["width"]
+        self.conv1, self.bn1 = _Conv(3, w, 7, 2, 3), _BN(w)
+        inplanes = w
+        for li, nblocks in enumerate(arch["layers"]):
+            planes = w * (2 ** li)
+            blocks = []
+            for b in range(nblocks):
+                stride = 2 if (li > 0 and b == 0) else 1
+                ds = b == 0 and (stride != 1 or inplanes != planes * 4)
+                blocks.append(_Bottleneck(inplanes, planes, stride, ds))
+                inplanes = planes * 4
+            setattr(self, "layer%d" % (li + 1), nn.ModuleList(blocks))
+        self.feature_dim = inplanes
+        self.fc = _FC(inplanes, embed_size)
+
+    def blocks(self):
+        for li in range(len(self.arch["layers"])):
+            for blk in getattr(self, "layer%d" % (li + 1)):
+                yield blk
+
+    def bns(self):
+        yield self.bn1
+        for blk in self.blocks():
+            yield blk.bn1
+            yield blk.bn2
+            yield blk.bn3
+            if blk.downsample is not None:
+                yield blk.downsample[1]
+
+
+def _tdtype(dtype):
+    return torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
+
+
+class ConvStackProgram:
+    """Device buffers + sat_op array for one (batch, H, W, dtype, training) configuration."""
+
+    def __init__(self, stack, N, H, W, dtype, training, device):
+        self.N, self.H, self.W, self.dtype, self.training = N, H, W, dtype, training
+        self.keep = []      # tensors the op array points into
+        td = _tdtype(dtype)
+        ch = 8 if dtype == L.SAT_BF16 else 4
+        width = stack.arch["width"]
+        if width % ch:
+            raise ValueError("conv stack width must be a multiple of %d for this dtype" % ch)
+        ops = []
+
+        def alloc(shape, dt=td, zero=False):
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dt, device=device)
+            self.keep.append(t)
+            return t
+
+        # ---- weights in kernel layout ([Cout][KH][KW][Cin]) ----
+        def prep_w(conv):
+            w = conv.weight.detach().to(device=device, dtype=torch.float32)
+            return w.permute(0, 2, 3, 1).contiguous().to(td)
+
+        # stem: 7x7/2 on a zero-bordered NHWC4 image; per kh one contiguous run of 8 pixels x 4 channels
+        Hp, Wp = H + 6, (W + 8 + 1) // 2 * 2
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        w1 = stack.conv1.weight.detach().to(device=device, dtype=torch.float32)     # [w,3,7,7]
+        wst = torch.zeros(width, 7, 8, 4, device=device, dtype=torch.float32)
+        wst[:, :, :7, :3] = w1.permute(0, 2, 3, 1)
+        wst = wst.reshape(width, 7 * 32).contiguous().to(td)
+        self.keep.append(wst)
+        self.images = None
+        self.img_pad = alloc((N, Hp, Wp, 4), zero=True)
+        self.bn_list = []
+        self.stack = stack
+        bns = list(stack.bns())
+        nbn = len(bns)
+        # one flat int64 counter tensor behind every bn.num_batches_tracked: one increment per forward
+        flat = getattr(stack, "_nbt_flat", None)
+        if flat is None or flat.device != torch.device(device) or \
+                any(bn.num_batches_tracked.data_ptr() != flat[i].data_ptr() for i, bn in enumerate(bns)):
+            flat = torch.stack([bn.num_batches_tracked.detach().to(device) for bn in bns])
+            for i, bn in enumerate(bns):
+                bn.num_batches_tracked = flat[i]
+            object.__setattr__(stack, "_nbt_flat", flat)
+        cmax = stack.feature_dim
+        self.scale_shift = alloc((nbn, 2, cmax), torch.float32)
+        bn_idx = [0]
+
+        def new_scale_shift(c):
+            i = bn_idx[0]
+            bn_idx[0] += 1
+            return self.scale_shift[i, 0, :c], self.scale_shift[i, 1, :c]
+
+        # geometry pass to size scratch buffers
+        geo = []
+        h, w_ = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+        hp_, wp_ = h, w_
+        inpl = width
+        max_in = N * h * w_ * inpl
+        max_c1 = max_c2 = max_c3 = 0
+        for li, nblocks in enumerate(stack.arch["layers"]):
+            planes = width * (2 ** li)
+            for b in range(nblocks):
+                stride = 2 if (li > 0 and b == 0) else 1
+                h2, w2 = (h + 2 - 3) // stride + 1, (w_ + 2 - 3) // stride + 1
+                geo.append((h, w_, h2, w2, inpl, planes, stride))
+                max_c1 = max(max_c1, N * h * w_ * planes)
+                max_c2 = max(max_c2, N * h2 * w2 * planes)
+                max_c3 = max(max_c3, N * h2 * w2 * planes * 4)
+                h, w_, inpl = h2, w2, planes * 4
+        max_part = max([L.load().sat_conv_tiles_m(N * Ho * Wo) * 2 * width] +
+                       [L.load().sat_conv_tiles_m(N * g[0] * g[1]) * 2 * g[5] for g in geo] +
+                       [L.load().sat_conv_tiles_m(N * g[2] * g[3]) * 2 * g[5] * 4 for g in geo])
+        self.partial = alloc((max_part,), torch.float32)
+        self.c0 = alloc((N * Ho * Wo * width,))
+        self.ybuf = [alloc((max(max_in, max_c3),)), alloc((max(max_in, max_c3),))]
+        self.c1, self.a1 = alloc((max_c1,)), alloc((max_c1,))
+        self.c2, self.a2 = alloc((max_c2,)), alloc((max_c2,))
+        self.c3, self.cd = alloc((max_c3,)), alloc((max_c3,))
+        self.pooled = alloc((N, stack.feature_dim), torch.float32)
+
+        def conv_op(x, wt, out, n, hin, win, cin, hout, wout, cout, kh, kw, stride, pad, sN, sH, sW):
+            o = L.SatOp()
+            o.kind, o.dtype = L.OP_CONV, dtype
+            o.in0, o.w, o.out = x.data_ptr(), wt.data_ptr(), out.data_ptr()
+            o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = n, hin, win, cin, hout, wout, cout
+            o.KH, o.KW, o.stride, o.pad = kh, kw, stride, pad
+            o.sN, o.sH, o.sW = sN, sH, sW
+            if training:
+                o.stat_partial = self.partial.data_ptr()
+                o.tiles_m = L.load().sat_conv_tiles_m(n * hout * wout)
+            return o
+
+        def fin_op(bn, c, count, tiles_m):
+            s, t = new_scale_shift(c)
+            o = L.SatOp()
+            o.kind, o.dtype = L.OP_BN_FINALIZE, dtype
+            o.stat_partial = self.partial.data_ptr() if training else None
+            o.gamma, o.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+            o.running_mean, o.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            o.scale_out, o.shift_out = s.data_ptr(), t.data_ptr()
+            o.Cout, o.count, o.tiles_m, o.training = c, count, tiles_m, 1 if training else 0
+            o.momentum, o.eps = BN_MOMENTUM, BN_EPS
+            self.bn_list.append(bn)
+            return o, s, t
+
+        def act_op(kind, x, s, t, out, n, h_, w__, c, x1=None, s1=None, t1=None):
+            o = L.SatOp()
+            o.kind, o.dtype = kind, dtype
+            o.in0, o.out = x.data_ptr(), out.data_ptr()
+            o.scale0, o.shift0 = s.data_ptr(), t.data_ptr()
+            if x1 is not None:
+                o.in1 = x1.data_ptr()
+                if s1 is not None:
+                    o.scale1, o.shift1 = s1.data_ptr(), t1.data_ptr()
+            o.N, o.Hout, o.Wout, o.Cout = n, h_, w__, c
+            return o
+
+        def std_conv(conv, x, out, n, hin, win, hout, wout):
+            wt = prep_w(conv).reshape(conv.cout, -1)
+            self.keep.append(wt)
+            cin = conv.cin
+            return conv_op(x, wt, out, n, hin, win, cin, hout, wout, conv.cout, conv.k, conv.k, conv.stride, conv.pad,
+                           hin * win * cin, win * cin, cin)
+
+        # ---- program ----
+        o = L.SatOp()
+        o.kind, o.dtype = L.OP_IMAGE_PREP, dtype
+        o.out = self.img_pad.data_ptr()
+        o.N, o.Hin, o.Win, o.Hout, o.Wout, o.pad = N, H, W, Hp, Wp, 3
+        ops.append(o)
+        self._prep_index = 0
+        ops.append(conv_op(self.img_pad, wst, self.c0, N, Hp, Wp, 32, Ho, Wo, width, 7, 1, 2, 0, Hp * Wp * 4, Wp * 4, 4))
+        f, s, t = fin_op(stack.bn1, width, N * Ho * Wo, L.load().sat_conv_tiles_m(N * Ho * Wo))
+        ops.append(f)
+        y, ynext = self.ybuf
+        mp = L.SatOp()
+        mp.kind, mp.dtype = L.OP_BN_RELU_MAXPOOL, dtype
+        mp.in0, mp.out, mp.scale0, mp.shift0 = self.c0.data_ptr(), y.data_ptr(), s.data_ptr(), t.data_ptr()
+        mp.N, mp.Hin, mp.Win, mp.Cout, mp.Hout, mp.Wout = N, Ho, Wo, width, hp_, wp_
+        ops.append(mp)
+        for blk, (h, w_, h2, w2, inpl, planes, stride) in zip(stack.blocks(), geo):
+            tm1 = L.load().sat_conv_tiles_m(N * h * w_)
+            tm2 = L.load().sat_conv_tiles_m(N * h2 * w2)
+            ops.append(std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_))
+            f, s1, t1 = fin_op(blk.bn1, planes, N * h * w_, tm1)
+            ops.append(f)
+            ops.append(act_op(L.OP_BN_RELU, self.c1, s1, t1, self.a1, N, h, w_, planes))
+            ops.append(std_conv(blk.conv2, self.a1, self.c2, N, h, w_, h2, w2))
+            f, s2, t2 = fin_op(blk.bn2, planes, N * h2 * w2, tm2)
+            ops.append(f)
+            ops.append(act_op(L.OP_BN_RELU, self.c2, s2, t2, self.a2, N, h2, w2, planes))
+            ops.append(std_conv(blk.conv3, self.a2, self.c3, N, h2, w2, h2, w2))
+            f, s3, t3 = fin_op(blk.bn3, planes * 4, N * h2 * w2, tm2)
+            ops.append(f)
+            if blk.downsample is not None:
+                ops.append(std_conv(blk.downsample[0], y, self.cd, N, h, w_, h2, w2))
+                f, sd, td_ = fin_op(blk.downsample[1], planes * 4, N * h2 * w2, tm2)
+                ops.append(f)
+                ops.append(act_op(L.OP_BN_ADD_RELU, self.c3, s3, t3, ynext, N, h2, w2, planes * 4, self.cd, sd, td_))
+            else:
+                ops.append(act_op(L.OP_BN_ADD_RELU, self.c3, s3, t3, ynext, N, h2, w2, planes * 4, y))
+            y, ynext = ynext, y
+        ap = L.SatOp()
+        ap.kind, ap.dtype = L.OP_AVGPOOL, dtype
+        ap.in0, ap.out = y.data_ptr(), self.pooled.data_ptr()
+        ap.N, ap.Hin, ap.Win, ap.Cout = N, geo[-1][2], geo[-1][3], stack.feature_dim
+        ops.append(ap)
+        self.final_map = (y, N, geo[-1][2], geo[-1][3], stack.feature_dim)
+        self.ops = (L.SatOp * len(ops))(*ops)
+        self.n_ops = len(ops)
+
+    def run(self, images):
+        """images f32 [N,3,H,W] NCHW on the device -> pooled f32 [N, feature_dim] (owned by the program)."""
+        L.require_gpu(images, "images")
+        if images.dtype != torch.float32 or tuple(images.shape) != (self.N, 3, self.H, self.W):
+            raise ValueError("images must be float32 [%d,3,%d,%d]" % (self.N, self.H, self.W))
+        images = images.contiguous()
+        self.ops[self._prep_index].in0 = images.data_ptr()
+        L.check(L.load().sat_run_ops(self.ops, self.n_ops, L.stream()), "sat_run_ops")
+        if self.training:
+            self.stack._nbt_flat += 1
+        return self.pooled
+
+
+def conv_flops(arch, H=224, W=224):
+    """Algorithmic FLOPs (2*MAC) per image of the conv stack (23.02 GFLOP at 224x224 for ResNet-152)."""
+    width = arch["width"]
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    fl = 2.0 * Ho * Wo * 3 * 49 * width
+    h, w_ = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+    inpl = width
+    for li, nblocks in enumerate(arch["layers"]):
+        planes = width * (2 ** li)
+        for b in range(nblocks):
+            stride = 2 if (li > 0 and b == 0) else 1
+            h2, w2 = (h + 2 - 3) // stride + 1, (w_ + 2 - 3) // stride + 1
+            fl += 2.0 * h * w_ * inpl * planes
+            fl += 2.0 * h2 * w2 * planes * planes * 9
+            fl += 2.0 * h2 * w2 * planes * planes * 4
+            if b == 0 and (stride != 1 or inpl != planes * 4):
+                fl += 2.0 * h2 * w2 * inpl * planes * 4
+            h, w_, inpl = h2, w2, planes * 4
+    return fl

@@ -1,0 +1,225 @@
+"""Fused training step: the body of the reference's hot loop (`/root/reference/train.py:126-146`) for the
+Show-and-Tell model, with every tensor op a libsat_hip.so kernel and no autograd:
+
+    lengths-1, targets = pack(captions[:,1:])            train.py:134-135   sat_pack_targets
+    outputs = model(images, captions[:,:-1], lengths)     train.py:139       sat_run_ops / sat_fc_bn1d_fwd /
+                                                                             sat_embed_concat_fwd / sat_lstm_fwd / sat_vocab_logits_fwd
+    loss = CrossEntropyLoss()(outputs, targets)           train.py:143       sat_ce_rows (gradient written in place)
+    loss.backward()                                       train.py:144       sat_vocab_ce_bwd / sat_lstm_bwd / sat_embed_concat_bwd / sat_fc_bn1d_bwd
+    clip_gradient (elementwise clamp) + Adam step         train.py:145-146   sat_clamp_adam_step (one launch)
+
+MI355X-first layout: all trainable parameters live in ONE flat f32 buffer (module parameters are views of it),
+with matching flat grad / Adam-m / Adam-v buffers.  The optimizer is one HBM-bound launch over 28 B/param and
+the data-parallel gradient exchange is a handful of large RCCL all-reduces over contiguous buckets, launched
+as each bucket's gradients become final and overlapped with the rest of the backward (`DataParallelStep`).
+"""
+import torch
+
+from . import _lib as L
+from .models import BN1D_MOMENTUM, BN_EPS, ShowAndTell, decoder_backward_tapes, decoder_forward_tapes
+from .pack import PackInfo
+
+
+def lr_for_epoch(epoch, learning_rate=1e-3, decay_start=1, decay_every=3, decay_rate=0.8):
+    """Epoch step decay of the reference trainer (train.py:101-107; defaults config.py:38-46)."""
+    if epoch > decay_start and decay_start >= 1:
+        return learning_rate * decay_rate ** ((epoch - decay_start) // decay_every)
+    return learning_rate
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class FlatParams:
+    """Trainable parameters re-homed into one flat f32 buffer, in gradient-completion order:
+    bucket 0 = vocab projection, bucket 1 = LSTM (top layer first), bucket 2 = encoder head + embedding."""
+
+    def __init__(self, model):
+        dec, enc = model.decoder, model.encoder
+        groups = [[("decoder.linear.weight", dec.linear.weight), ("decoder.linear.bias", dec.linear.bias)], [], []]
+        for l in reversed(range(dec.num_layers)):
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                groups[1].append(("decoder.lstm.%s_l%d" % (n, l), getattr(dec.lstm, "%s_l%d" % (n, l))))
+        groups[2] = [("encoder.resnet.fc.weight", enc.resnet.fc.weight), ("encoder.resnet.fc.bias", enc.resnet.fc.bias),
+                     ("encoder.bn.weight", enc.bn.weight), ("encoder.bn.bias", enc.bn.bias),
+                     ("decoder.embed.weight", dec.embed.weight)]
+        dev = dec.linear.weight.device
+        self.slices, self.buckets = {}, []
+        off = 0
+        for g in groups:
+            start = off
+            for name, p in g:
+                self.slices[name] = (off, p.numel(), tuple(p.shape))
+                off += _pad4(p.numel())
+            self.buckets.append((start, off))
+        self.n = off
+        # 4 trailing floats: slot 0 carries this rank's loss term through the last bucket's all-reduce
+        self.loss_slot = off
+        self.buckets[-1] = (self.buckets[-1][0], off + 4)
+        self.params = torch.zeros(off, device=dev)
+        self.grads = torch.zeros(off + 4, device=dev)
+        self.m = torch.zeros(off, device=dev)
+        self.v = torch.zeros(off, device=dev)
+        for g in groups:
+            for name, p in g:
+                o, n, shape = self.slices[name]
+                self.params[o:o + n].copy_(p.data.reshape(-1))
+                p.data = self.params[o:o + n].view(shape)
+                p.grad = self.grads[o:o + n].view(shape)
+
+    def grad(self, name):
+        o, n, shape = self.slices[name]
+        return self.grads[o:o + n].view(shape)
+
+
+class TrainStep:
+    """One object = model + flat optimizer state; `step()` = one train.py:126-146 iteration on this GPU."""
+
+    def __init__(self, model, lr=1e-3, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8):
+        if not isinstance(model, ShowAndTell):
+            raise TypeError("TrainStep drives a ShowAndTell model")
+        L.require_gpu(model.decoder.linear.weight, "model")
+        self.lib = L.load()
+        self.model = model
+        self.flat = FlatParams(model)
+        self.lr, self.grad_clip, self.betas, self.eps = lr, grad_clip, betas, eps
+        self.step_count = 0
+        self.buckets = self.flat.buckets
+        self.flat_grad = self.flat.grads
+        self._bufs = {}
+
+    # -- engine interface used by DataParallelStep ----------------------------------------------------
+    def forward_backward(self, batch, inv_denom, on_bucket_ready=None):
+        """batch = (images f32[B,3,H,W], captions i64[B,T], lengths list[int] desc).  Fills the flat grad buffer
+        (gradients of sum-CE * inv_denom) and the loss slot; returns the loss slot tensor (device, 1 elem)."""
+        images, captions, lengths = batch
+        lib, model, flat = self.lib, self.model, self.flat
+        enc, dec = model.encoder, model.decoder
+        if not model.training:
+            raise RuntimeError("TrainStep needs model.train() (batch-statistics BatchNorm, train.py never calls eval())")
+        L.require_gpu(captions, "captions")
+        dev = images.device
+        st = L.stream()
+        B = images.shape[0]
+        if captions.dtype != torch.int64 or captions.stride(1) != 1:
+            captions = captions.long().contiguous()
+        l1 = [int(l) - 1 for l in lengths]                                   # train.py:134
+        pi = PackInfo.get(l1, dev)
+        N, V, E = pi.N, dec.vocab_size, dec.embed_size
+        key = (B, N)
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            self._bufs.clear()
+            F = enc.resnet.feature_dim
+            wsb = lib.sat_fc_bn1d_ws_bytes(B, F, E)
+            bufs = self._bufs[key] = dict(
+                targets=torch.empty(N, dtype=torch.int64, device=dev), logits=torch.empty(N, V, device=dev),
+                row_loss=torch.empty(N, device=dev), feats=torch.empty(B, E, device=dev),
+                xhat=torch.empty(B, E, device=dev), rstd=torch.empty(E, device=dev),
+                head_ws=torch.empty(max(wsb // 4, B * E), device=dev), d_feat=torch.empty(B, E, device=dev))
+        # targets = pack(captions[:,1:], lengths-1)                           train.py:135
+        L.check(lib.sat_pack_targets(captions.data_ptr(), captions.stride(0), L.ptr(pi.prefix_dev), pi.T, N,
+                                     L.ptr(bufs["targets"]), st), "sat_pack_targets")
+        # ---- forward (train.py:139) ----
+        cached_features = images.dim() == 2      # [B,E] precomputed encoder features: decoder-only training
+        if cached_features:
+            feats_in = images.contiguous()
+            pooled = None
+        else:
+            pooled = enc.pooled_features(images)
+            F = pooled.shape[1]
+            fc, bn = enc.resnet.fc, enc.bn
+            L.check(lib.sat_fc_bn1d_fwd(L.ptr(pooled), L.ptr(fc.weight), L.ptr(fc.bias), L.ptr(bn.weight), L.ptr(bn.bias),
+                                        L.ptr(bn.running_mean), L.ptr(bn.running_var), BN1D_MOMENTUM, BN_EPS, 1, B, F, E,
+                                        L.ptr(bufs["feats"]), L.ptr(bufs["xhat"]), L.ptr(bufs["rstd"]),
+                                        L.ptr(bufs["head_ws"]), bufs["head_ws"].numel() * 4, st), "sat_fc_bn1d_fwd")
+            bn.num_batches_tracked += 1
+            feats_in = bufs["feats"]
+        layers = [dec.lstm.layer(l) for l in range(dec.num_layers)]
+        logits, tapes = decoder_forward_tapes(lib, feats_in, dec.embed.weight, layers, dec.linear.weight,
+                                              dec.linear.bias, captions[:, :-1], pi, logits=bufs["logits"])
+        # ---- loss + d(loss)/d(logits) in place (train.py:143) ----
+        loss_slot = flat.grads[flat.loss_slot:flat.loss_slot + 1]
+        L.check(lib.sat_ce_rows(L.ptr(logits), L.ptr(bufs["targets"]), N, V, float(inv_denom), 1,
+                                L.ptr(bufs["row_loss"]), L.ptr(loss_slot), st), "sat_ce_rows")
+        # ---- backward (train.py:144): gradients land directly in the flat buffer ----
+        g = {"embed": flat.grad("decoder.embed.weight"), "lin_w": flat.grad("decoder.linear.weight"),
+             "lin_b": flat.grad("decoder.linear.bias"), "features": bufs["d_feat"]}
+        for l in range(dec.num_layers):
+            for short, n in (("w_ih", "weight_ih"), ("w_hh", "weight_hh"), ("b_ih", "bias_ih"), ("b_hh", "bias_hh")):
+                g[(short, l)] = flat.grad("decoder.lstm.%s_l%d" % (n, l))
+        decoder_backward_tapes(lib, logits, tapes, dec.embed.weight, layers, dec.linear.weight, pi, g,
+                               on_stage=on_bucket_ready)
+        if not cached_features:
+            fc, bn = enc.resnet.fc, enc.bn
+            L.check(lib.sat_fc_bn1d_bwd(L.ptr(bufs["d_feat"]), L.ptr(pooled), L.ptr(bufs["xhat"]), L.ptr(bufs["rstd"]),
+                                        L.ptr(bn.weight), B, pooled.shape[1], E, L.ptr(flat.grad("encoder.resnet.fc.weight")),
+                                        L.ptr(flat.grad("encoder.resnet.fc.bias")), L.ptr(flat.grad("encoder.bn.weight")),
+                                        L.ptr(flat.grad("encoder.bn.bias")), L.ptr(bufs["head_ws"]),
+                                        bufs["head_ws"].numel() * 4, st), "sat_fc_bn1d_bwd")
+        self.last_d_features = bufs["d_feat"]
+        if on_bucket_ready is not None:
+            on_bucket_ready(2)   # encoder head + embedding gradients (and the loss slot) are final
+        return loss_slot
+
+    def optimizer_step(self, lr=None):
+        """clip_gradient + Adam (train.py:145-146) as one launch over the flat buffers."""
+        self.step_count += 1
+        f = self.flat
+        L.check(self.lib.sat_clamp_adam_step(L.ptr(f.params), L.ptr(f.grads), L.ptr(f.m), L.ptr(f.v), f.n,
+                                             float(self.lr if lr is None else lr), self.betas[0], self.betas[1],
+                                             self.eps, float(self.grad_clip), self.step_count, L.stream()),
+                "sat_clamp_adam_step")
+
+    # -- single-GPU convenience ----------------------------------------------------------------------
+    def step(self, images, captions, lengths, lr=None):
+        """One whole iteration; returns the mean-CE loss as a 1-element device tensor (no host sync)."""
+        n_tokens = sum(int(l) - 1 for l in lengths)
+        loss = self.forward_backward((images, captions, lengths), 1.0 / n_tokens)
+        self.optimizer_step(lr)
+        return loss
+
+
+def dp_shard(images, captions, lengths, rank, world):
+    """Interleaved shard of a length-sorted global batch: rank r takes rows r, r+world, ...  Every shard stays
+    sorted by decreasing length (pack_padded_sequence's requirement) and shards are balanced in tokens.
+    Returns (images_r, captions_r, lengths_r, global_tokens) with global_tokens = sum(lengths-1) over ALL rows."""
+    idx = list(range(rank, len(lengths), world))
+    sel = torch.as_tensor(idx, device=captions.device)
+    return (images.index_select(0, sel.to(images.device)), captions.index_select(0, sel), [lengths[i] for i in idx],
+            sum(int(l) - 1 for l in lengths))
+
+
+class DataParallelStep:
+    """One process per GPU; replaces `nn.DataParallel` (train.py:43-44).  Semantics:
+      * the minibatch is sharded along dim 0, parameters replicated, forward/backward rank-local;
+      * gradients are those of the GLOBAL mean CE: every rank scales by 1/(global token count), then one
+        all-reduce(sum) per bucket over RCCL/xGMI, launched as soon as the bucket is final and overlapped with
+        the remaining backward kernels; the loss rides in the last bucket;
+      * clamp + Adam run AFTER the reduction (train.py:144-146 order), identically on every rank;
+      * BatchNorm uses per-rank batch statistics (what nn.DataParallel replicas do as well).
+    `engine` needs: .flat_grad, .buckets, .forward_backward(batch, inv_denom, on_bucket_ready), .optimizer_step(lr).
+    """
+
+    def __init__(self, engine, process_group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.engine = engine
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+
+    def step(self, batch, global_tokens, lr=None):
+        eng, dist = self.engine, self.dist
+        works = []
+
+        def ready(i):
+            if self.world > 1:
+                s, e = eng.buckets[i]
+                works.append(dist.all_reduce(eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+        loss = eng.forward_backward(batch, 1.0 / float(global_tokens), ready)
+        for w in works:
+            w.wait()
+        eng.optimizer_step(lr)
+        return loss

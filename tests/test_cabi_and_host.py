@@ -1,0 +1,118 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sat_hip.h declares (no compute calls without a
+GPU), the ctypes struct mirrors the C struct, and the host-side logic (packing, sharding, LR schedule, flat
+parameter layout errors) behaves like the reference's (`train.py:101-107,134-135`, `data_loader.py:48-62`)."""
+import ctypes as C
+import importlib
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sat = importlib.import_module("show-and-tell_amd")
+L = sat._lib
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "sat_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sat_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    names = header_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libsat_hip.so does not export %s" % n
+        assert n in L.SIGNATURES, "no ctypes signature for %s" % n
+    assert set(L.SIGNATURES) == set(names)
+    assert lib.sat_version() == 1
+    assert b"workspace" in lib.sat_error_string(1002)
+
+
+def test_sat_op_struct_layout_matches_c():
+    """compile a 3-line C program against the header and compare sizeof/offsetof with the ctypes mirror"""
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "sat_hip.h"
+int main(){printf("%zu %zu %zu %zu %zu\n", sizeof(sat_op), offsetof(sat_op,N), offsetof(sat_op,sN), offsetof(sat_op,count), offsetof(sat_op,eps));return 0;}
+'''
+    d = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(d, exist_ok=True)
+    open(os.path.join(d, "layout.c"), "w").write(prog)
+    exe = os.path.join(d, "layout")
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "layout.c"), "-o", exe])
+    out = subprocess.check_output([exe]).decode().split()
+    S = L.SatOp
+    assert [int(x) for x in out] == [C.sizeof(S), S.N.offset, S.sN.offset, S.count.offset, S.eps.offset]
+
+
+def test_argument_errors_are_reported_not_computed():
+    lib = L.load()
+    # null pointers / bad shapes are rejected before any launch (works without a GPU)
+    assert lib.sat_gemm_f32(0, 0, None, 4, None, 4, None, 4, None, None, 4, 4, 4, None) == 1001
+    assert lib.sat_clamp_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.1, 1, None) == 1001
+    assert lib.sat_run_ops(None, 1, None) == 1001
+    with pytest.raises(RuntimeError):
+        L.check(1003, "x")
+
+
+def test_modules_refuse_cpu_tensors():
+    dec = sat.DecoderRNN(8, 16, 50, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dec(torch.zeros(2, 8), torch.zeros(2, 5, dtype=torch.long), [6, 4])
+    enc = sat.EncoderCNN(8, arch=dict(layers=(1, 1, 1, 1), width=8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        enc(torch.zeros(1, 3, 32, 32))
+
+
+def test_packinfo_matches_pack_padded_sequence():
+    from torch.nn.utils.rnn import pack_padded_sequence
+    lengths = [7, 5, 5, 2, 1]
+    pi = sat.PackInfo(lengths, "cpu")
+    x = torch.arange(5 * 7).view(5, 7)
+    ref = pack_padded_sequence(x, lengths, batch_first=True)
+    assert pi.batch_sizes == ref.batch_sizes.tolist() and pi.N == ref.data.numel()
+    caps = torch.randint(0, 9, (5, 8))
+    tg, l1 = sat.pack_targets(caps, [8, 6, 6, 3, 2])
+    ref_t = pack_padded_sequence(caps[:, 1:], l1, batch_first=True)[0]
+    assert torch.equal(tg, ref_t)
+    with pytest.raises(ValueError):
+        sat.PackInfo([3, 5], "cpu")
+    with pytest.raises(ValueError):
+        sat.PackInfo([3, 0], "cpu")
+
+
+def test_dp_shard_keeps_sorted_and_covers_batch():
+    lengths = [20, 19, 19, 15, 12, 9, 9, 4]
+    imgs, caps = torch.arange(8).float().view(8, 1), torch.arange(8).view(8, 1)
+    seen = []
+    for r in range(2):
+        im, cp, ln, tok = sat.dp_shard(imgs, caps, lengths, r, 2)
+        assert ln == sorted(ln, reverse=True) and tok == sum(l - 1 for l in lengths)
+        seen += cp.flatten().tolist()
+    assert sorted(seen) == list(range(8))
+
+
+def test_lr_schedule_matches_train_py():
+    assert sat.lr_for_epoch(1) == 1e-3 and sat.lr_for_epoch(3) == 1e-3
+    assert abs(sat.lr_for_epoch(4) - 8e-4) < 1e-15 and abs(sat.lr_for_epoch(10) - 1e-3 * 0.8 ** 3) < 1e-15
+
+
+def test_state_dict_keys_equal_reference_names():
+    dec = sat.DecoderRNN(8, 16, 50, 2)
+    assert list(dec.state_dict()) == ["embed.weight", "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0",
+                                      "lstm.bias_hh_l0", "lstm.weight_ih_l1", "lstm.weight_hh_l1", "lstm.bias_ih_l1",
+                                      "lstm.bias_hh_l1", "linear.weight", "linear.bias"]
+    enc = sat.EncoderCNN(8)
+    keys = list(enc.state_dict())
+    assert keys[0] == "resnet.conv1.weight" and "resnet.layer3.35.bn3.running_var" in keys
+    assert "resnet.layer1.0.downsample.0.weight" in keys and keys[-5:] == ["bn.weight", "bn.bias", "bn.running_mean",
+                                                                           "bn.running_var", "bn.num_batches_tracked"]
+    trainable = [k for k, p in enc.named_parameters() if p.requires_grad]
+    assert trainable == ["resnet.fc.weight", "resnet.fc.bias", "bn.weight", "bn.bias"]      # models.py:14-17
+    assert abs(sat.conv_flops(sat.RESNET152) / 1e9 - 23.02) < 0.1

@@ -1,0 +1,123 @@
+"""CPU, world_size 2, gloo: the data-parallel wrapper (`DataParallelStep`, `dp_shard`) reproduces the single-process
+result on the concatenated batch: token-count-weighted loss/gradient scaling, bucketed all-reduce,
+clamp + Adam AFTER the reduction.  The local compute engine here is the CPU oracle (test infrastructure); on the
+GPU the same wrapper drives `TrainStep` over RCCL."""
+import importlib
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import decoder as OD
+from oracle import train_step as OT
+
+sat = importlib.import_module("show-and-tell_amd")
+
+DIMS = dict(E=16, H=24, V=120, L=1)
+LENGTHS = [12, 12, 11, 9, 9, 7, 5, 3]
+
+
+class OracleEngine:
+    """Same engine interface as show-and-tell_amd.trainer.TrainStep, arithmetic from oracle/ (tests only)."""
+
+    def __init__(self, params):
+        self.params = params
+        self.names = list(params)
+        self.offsets, off = {}, 0
+        groups = [[n for n in self.names if n.startswith("linear")], [n for n in self.names if n.startswith("lstm")],
+                  [n for n in self.names if n.startswith("embed")]]
+        self.buckets = []
+        for g in groups:
+            s = off
+            for n in g:
+                self.offsets[n] = off
+                off += params[n].numel()
+            self.buckets.append((s, off))
+        self.buckets[-1] = (self.buckets[-1][0], off + 4)
+        self.flat_grad = torch.zeros(off + 4)
+        self.state = {}
+        self.calls = []
+
+    def forward_backward(self, batch, inv_denom, on_bucket_ready=None):
+        feats, caps, lengths = batch
+        loss, grads, _, _ = OT.decoder_loss_and_grads(self.params, feats, caps, lengths, DIMS["L"], denom=1.0 / inv_denom)
+        for n, g in grads.items():
+            o = self.offsets[n]
+            self.flat_grad[o:o + g.numel()] = g.reshape(-1)
+        self.flat_grad[-4] = loss
+        for i in range(len(self.buckets)):
+            self.calls.append(i)
+            if on_bucket_ready:
+                on_bucket_ready(i)
+        return self.flat_grad[-4:-3]
+
+    def optimizer_step(self, lr=None):
+        grads = {n: self.flat_grad[self.offsets[n]:self.offsets[n] + p.numel()].view(p.shape).clone()
+                 for n, p in self.params.items()}
+        OT.clamp_(grads, 0.1)
+        OT.adam_step_(self.params, grads, self.state, lr=1e-3 if lr is None else lr)
+
+
+def make_batch():
+    g = torch.Generator().manual_seed(7)
+    B, T = len(LENGTHS), LENGTHS[0]
+    caps = torch.zeros(B, T, dtype=torch.long)
+    for b, l in enumerate(LENGTHS):
+        caps[b, 0] = 1
+        caps[b, 1:l - 1] = torch.randint(4, DIMS["V"], (l - 2,), generator=g)
+        caps[b, l - 1] = 2
+    feats = torch.randn(B, DIMS["E"], generator=g)
+    return feats, caps
+
+
+def fresh_params():
+    return OD.init_decoder_params(DIMS["E"], DIMS["H"], DIMS["V"], DIMS["L"], generator=torch.Generator().manual_seed(5))
+
+
+def worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    feats, caps = make_batch()
+    eng = OracleEngine(fresh_params())
+    dp = sat.DataParallelStep(eng)
+    losses = []
+    for _ in range(2):
+        f, c, ln, tokens = sat.dp_shard(feats, caps, LENGTHS, rank, world)
+        losses.append(float(dp.step((f, c, ln), tokens)))
+    if rank == 0:
+        torch.save({"params": eng.params, "losses": losses, "calls": eng.calls}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    feats, caps = make_batch()
+    params, state, ref_losses = fresh_params(), {}, []
+    for _ in range(2):
+        loss, grads, _, _ = OT.decoder_loss_and_grads(params, feats, caps, LENGTHS, DIMS["L"])
+        ref_losses.append(loss.item())
+        OT.clamp_(grads, 0.1)
+        OT.adam_step_(params, grads, state, lr=1e-3)
+    for a, b in zip(got["losses"], ref_losses):
+        assert abs(a - b) < 1e-5          # loss rides the last bucket: sum over ranks of sumCE_r / N_global
+    for k in params:
+        assert torch.allclose(got["params"][k], params[k], rtol=0, atol=2e-6), k
+    assert got["calls"][:3] == [0, 1, 2]   # buckets become ready in gradient-completion order
+
+
+def test_single_process_wrapper_is_identity():
+    feats, caps = make_batch()
+    eng = OracleEngine(fresh_params())
+    dp = sat.DataParallelStep(eng)
+    assert dp.world == 1
+    tokens = sum(l - 1 for l in LENGTHS)
+    loss = float(dp.step((feats, caps, LENGTHS), tokens))
+    ref, _, _, _ = OT.decoder_loss_and_grads(fresh_params(), feats, caps, LENGTHS, DIMS["L"])
+    assert abs(loss - ref.item()) < 1e-6

@@ -1,0 +1,308 @@
+"""GPU (MI355X) kernel-level parity: every libsat_hip.so entry point called through the C ABI (ctypes) and
+compared with CPU fp32/fp64 arithmetic on the same seeded inputs.  Tolerances are written next to each check."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+sat = importlib.import_module("show-and-tell_amd")
+L = sat._lib
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    return L.load()
+
+
+def cu(t):
+    return t.cuda()
+
+
+def st():
+    return L.stream()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("amode,bmode", [(0, 0), (0, 1), (2, 1), (2, 0)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 100), (64, 2048, 256), (1216, 512, 64), (33, 20, 8),
+                                   (300, 1000, 516)])
+def test_gemm_f32(lib, amode, bmode, M, N, K):
+    if amode == 2 and M % 4:
+        M = (M + 3) // 4 * 4
+    if bmode == 1 and N % 4:
+        N = (N + 3) // 4 * 4
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    bias2 = torch.randn(N, generator=g)
+    ref = (A.double() @ B.double().t() + bias.double() + bias2.double())
+    Ad = cu(A if amode == 0 else A.t().contiguous())
+    Bd = cu(B if bmode == 0 else B.t().contiguous())
+    lda = K if amode == 0 else M
+    ldb = K if bmode == 0 else N
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    L.check(lib.sat_gemm_f32(amode, bmode, L.ptr(Ad), lda, L.ptr(Bd), ldb, L.ptr(Cd), N, L.ptr(cu(bias)), L.ptr(cu(bias2)),
+                             M, N, K, st()))
+    sync()
+    out = Cd.cpu().double()
+    # exact-f32 MFMA: error ~ 1e-7 * sum|a*b|
+    tol = 3e-6 * (A.abs().double() @ B.abs().double().t()).max().item()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < tol
+
+
+def _conv_op(dtype, x_nhwc, w_ohwi, stride, pad, stats=True):
+    N, H, W, Cin = x_nhwc.shape
+    Cout, KH, KW, _ = w_ohwi.shape
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    td = torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
+    xd = cu(x_nhwc.to(td).contiguous())
+    wd = cu(w_ohwi.to(td).reshape(Cout, -1).contiguous())
+    out = torch.full((N * Ho * Wo, Cout), float("nan"), device="cuda", dtype=td)
+    tiles = L.load().sat_conv_tiles_m(N * Ho * Wo)
+    part = torch.full((tiles, 2, Cout), float("nan"), device="cuda") if stats else None
+    o = L.SatOp()
+    o.kind, o.dtype = L.OP_CONV, dtype
+    o.in0, o.w, o.out = xd.data_ptr(), wd.data_ptr(), out.data_ptr()
+    o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, Ho, Wo, Cout
+    o.KH, o.KW, o.stride, o.pad = KH, KW, stride, pad
+    o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
+    if stats:
+        o.stat_partial, o.tiles_m = part.data_ptr(), tiles
+    return o, (xd, wd, out, part), (N, Ho, Wo, Cout)
+
+
+@pytest.mark.parametrize("dtype", [L.SAT_F32, L.SAT_BF16])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [
+    (2, 8, 8, 64, 64, 1, 1, 0), (2, 9, 7, 64, 128, 3, 1, 1), (3, 10, 10, 128, 64, 3, 2, 1), (2, 8, 8, 256, 72, 1, 2, 0),
+    (2, 12, 12, 8, 16, 3, 1, 1), (1, 6, 6, 16, 8, 1, 1, 0), (2, 7, 7, 24, 40, 3, 2, 1), (4, 14, 14, 256, 256, 3, 1, 1)])
+def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
+    g = torch.Generator().manual_seed(N * H + Cin + Cout + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    if dtype == L.SAT_BF16:          # compare on bf16-rounded operands: what the kernel sees
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+    o, keep, (n, ho, wo, co) = _conv_op(dtype, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), stride, pad)
+    L.check(lib.sat_run_ops(C.pointer(o), 1, st()))
+    sync()
+    out = keep[2].float().cpu().double()
+    assert torch.isfinite(out).all()
+    tol = 2e-5 if dtype == L.SAT_F32 else 2e-2       # bf16 output rounding: 2^-8 relative on |y| <~ 4
+    assert (out - ref).abs().max().item() < tol
+    part = keep[3].cpu().double()
+    np.testing.assert_allclose(part[:, 0].sum(0).numpy(), ref.sum(0).numpy(), rtol=0, atol=1e-3 * ref.shape[0] ** 0.5 + 1e-4)
+    np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [L.SAT_F32, L.SAT_BF16])
+def test_stem_conv_via_padded_nhwc4(lib, dtype):
+    """image prep + 7x7/2 conv on the padded NHWC4 image == conv2d(images, w, stride 2, pad 3)"""
+    N, H, W, width = 2, 32, 40, 16
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(width, 3, 7, 7, generator=g) / 12.0
+    if dtype == L.SAT_BF16:
+        img_r, w = img.bfloat16().float(), w.bfloat16().float()
+    else:
+        img_r = img
+    ref = F.conv2d(img_r.double(), w.double(), None, 2, 3).permute(0, 2, 3, 1).reshape(-1, width)
+    td = torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
+    Hp, Wp = H + 6, (W + 8 + 1) // 2 * 2
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    pad_img = torch.zeros(N, Hp, Wp, 4, device="cuda", dtype=td)
+    imgd = cu(img)
+    p = L.SatOp()
+    p.kind, p.dtype = L.OP_IMAGE_PREP, dtype
+    p.in0, p.out = imgd.data_ptr(), pad_img.data_ptr()
+    p.N, p.Hin, p.Win, p.Hout, p.Wout, p.pad = N, H, W, Hp, Wp, 3
+    wst = torch.zeros(width, 7, 8, 4)
+    wst[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    wd = cu(wst.reshape(width, 224).to(td))
+    out = torch.full((N * Ho * Wo, width), float("nan"), device="cuda", dtype=td)
+    c = L.SatOp()
+    c.kind, c.dtype = L.OP_CONV, dtype
+    c.in0, c.w, c.out = pad_img.data_ptr(), wd.data_ptr(), out.data_ptr()
+    c.N, c.Hin, c.Win, c.Cin, c.Hout, c.Wout, c.Cout = N, Hp, Wp, 32, Ho, Wo, width
+    c.KH, c.KW, c.stride, c.pad = 7, 1, 2, 0
+    c.sN, c.sH, c.sW = Hp * Wp * 4, Wp * 4, 4
+    ops = (L.SatOp * 2)(p, c)
+    L.check(lib.sat_run_ops(ops, 2, st()))
+    sync()
+    got = out.float().cpu().double()
+    assert (got - ref).abs().max().item() < (2e-5 if dtype == L.SAT_F32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [L.SAT_F32, L.SAT_BF16])
+def test_bn_finalize_apply_pool(lib, dtype):
+    td = torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
+    N, H, W, Cc = 3, 10, 10, 32
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(N, H, W, Cc, generator=g) * 2 + 0.5).to(td)
+    idt = torch.randn(N, H, W, Cc, generator=g).to(td)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    xf = x.float().reshape(-1, Cc)
+    M = xf.shape[0]
+    tiles = 3
+    part = torch.zeros(tiles, 2, Cc)
+    for t in range(tiles):
+        rows = xf[t::tiles]
+        part[t, 0], part[t, 1] = rows.sum(0), (rows ** 2).sum(0)
+    rm, rv = cu(torch.zeros(Cc)), cu(torch.ones(Cc))
+    sc, sh = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    pd, gd, bd = cu(part), cu(gamma), cu(beta)
+    f = L.SatOp()
+    f.kind, f.dtype = L.OP_BN_FINALIZE, dtype
+    f.stat_partial, f.gamma, f.beta = pd.data_ptr(), gd.data_ptr(), bd.data_ptr()
+    f.running_mean, f.running_var, f.scale_out, f.shift_out = rm.data_ptr(), rv.data_ptr(), sc.data_ptr(), sh.data_ptr()
+    f.Cout, f.count, f.tiles_m, f.training, f.momentum, f.eps = Cc, M, tiles, 1, 0.1, 1e-5
+    xd, idd = cu(x), cu(idt)
+    y1 = torch.empty_like(xd)
+    a = L.SatOp()
+    a.kind, a.dtype = L.OP_BN_RELU, dtype
+    a.in0, a.out, a.scale0, a.shift0 = xd.data_ptr(), y1.data_ptr(), sc.data_ptr(), sh.data_ptr()
+    a.N, a.Hout, a.Wout, a.Cout = N, H, W, Cc
+    y2 = torch.empty_like(xd)
+    b = L.SatOp()
+    b.kind, b.dtype = L.OP_BN_ADD_RELU, dtype
+    b.in0, b.in1, b.out, b.scale0, b.shift0 = xd.data_ptr(), idd.data_ptr(), y2.data_ptr(), sc.data_ptr(), sh.data_ptr()
+    b.N, b.Hout, b.Wout, b.Cout = N, H, W, Cc
+    y3 = torch.empty_like(xd)
+    b2 = L.SatOp()
+    b2.kind, b2.dtype = L.OP_BN_ADD_RELU, dtype
+    b2.in0, b2.in1, b2.out = xd.data_ptr(), idd.data_ptr(), y3.data_ptr()
+    b2.scale0, b2.shift0, b2.scale1, b2.shift1 = sc.data_ptr(), sh.data_ptr(), sc.data_ptr(), sh.data_ptr()
+    b2.N, b2.Hout, b2.Wout, b2.Cout = N, H, W, Cc
+    Hq, Wq = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y4 = torch.empty(N, Hq, Wq, Cc, device="cuda", dtype=td)
+    m = L.SatOp()
+    m.kind, m.dtype = L.OP_BN_RELU_MAXPOOL, dtype
+    m.in0, m.out, m.scale0, m.shift0 = xd.data_ptr(), y4.data_ptr(), sc.data_ptr(), sh.data_ptr()
+    m.N, m.Hin, m.Win, m.Cout, m.Hout, m.Wout = N, H, W, Cc, Hq, Wq
+    y5 = torch.empty(N, Cc, device="cuda")
+    p = L.SatOp()
+    p.kind, p.dtype = L.OP_AVGPOOL, dtype
+    p.in0, p.out = xd.data_ptr(), y5.data_ptr()
+    p.N, p.Hin, p.Win, p.Cout = N, H, W, Cc
+    ops = (L.SatOp * 6)(f, a, b, b2, m, p)
+    L.check(lib.sat_run_ops(ops, 6, st()))
+    sync()
+    mean, var = xf.double().mean(0), xf.double().var(0, unbiased=False)
+    scale = gamma.double() / torch.sqrt(var + 1e-5)
+    shift = beta.double() - mean * scale
+    np.testing.assert_allclose(sc.cpu().numpy(), scale.numpy(), rtol=2e-5)
+    np.testing.assert_allclose(sh.cpu().numpy(), shift.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * var * M / (M - 1)).numpy(), rtol=1e-5)
+    tol = 1e-5 if dtype == L.SAT_F32 else 4e-2
+    xb = x.double() * scale + shift
+    ib = idt.double()
+    assert (y1.float().cpu().double() - xb.clamp(min=0)).abs().max() < tol
+    assert (y2.float().cpu().double() - (xb + ib).clamp(min=0)).abs().max() < tol
+    assert (y3.float().cpu().double() - (xb + ib * scale + shift).clamp(min=0)).abs().max() < 2 * tol
+    mp = F.max_pool2d(xb.clamp(min=0).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert (y4.float().cpu().double() - mp).abs().max() < tol
+    assert (y5.cpu().double() - x.double().mean((1, 2))).abs().max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_clamp_adam_matches_torch(lib):
+    g = torch.Generator().manual_seed(3)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    npad = (n + 3) // 4 * 4
+    p, m, v = cu(torch.cat([p0, torch.zeros(npad - n)])), torch.zeros(npad, device="cuda"), torch.zeros(npad, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * 0.3
+        ref_p.grad = gr.clone().clamp_(-0.1, 0.1)
+        opt.step()
+        gd = cu(torch.cat([gr, torch.zeros(npad - n)]))
+        L.check(lib.sat_clamp_adam_step(L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0.1, step, st()))
+        sync()
+        np.testing.assert_allclose(gd.cpu()[:n].numpy(), ref_p.grad.numpy(), rtol=0, atol=0)     # clamp is exact
+        np.testing.assert_allclose(p.cpu()[:n].numpy(), ref_p.detach().numpy(), rtol=0, atol=2e-7)
+
+
+def test_ce_rows_and_colsum(lib):
+    g = torch.Generator().manual_seed(11)
+    N, V = 37, 1003
+    logits = torch.randn(N, V, generator=g) * 3
+    logits[5, 17] = 40.0          # force a dominant column (large max, exp underflow elsewhere)
+    tgt = torch.randint(0, V, (N,), generator=g)
+    ld = cu(logits.clone())
+    rl, lo = torch.empty(N, device="cuda"), torch.empty(1, device="cuda")
+    inv = 1.0 / 50.0
+    L.check(lib.sat_ce_rows(L.ptr(ld), L.ptr(cu(tgt)), N, V, inv, 1, L.ptr(rl), L.ptr(lo), st()))
+    sync()
+    lg = logits.double().requires_grad_(True)
+    ref = F.cross_entropy(lg, tgt, reduction="sum") * inv
+    ref.backward()
+    assert abs(lo.item() - ref.item()) < 1e-5 * abs(ref.item())
+    np.testing.assert_allclose(ld.cpu().numpy(), lg.grad.numpy(), rtol=0, atol=2e-8 + 1e-6 * inv)
+    cs = torch.empty(V, device="cuda")
+    L.check(lib.sat_colsum_f32(L.ptr(ld), V, N, V, L.ptr(cs), st()))
+    sync()
+    np.testing.assert_allclose(cs.cpu().numpy(), lg.grad.sum(0).numpy(), rtol=0, atol=1e-7)
+
+
+def test_vocab_argmax_first_max(lib):
+    g = torch.Generator().manual_seed(13)
+    B, H, V = 5, 64, 1003
+    h, w, b = torch.randn(B, H, generator=g), torch.randn(V, H, generator=g) * 0.1, torch.randn(V, generator=g) * 0.01
+    w[900] = w[30]
+    b[900] = b[30]               # exact tie between columns 30 and 900 -> first index must win
+    h[2] = w[30] * 50
+    ref = (h @ w.t() + b).max(1)[1]
+    ids = torch.full((B, 20), -1, dtype=torch.int64, device="cuda")
+    wsb = lib.sat_vocab_argmax_ws_bytes(B, V)
+    ws = torch.empty(wsb // 4, device="cuda")
+    col = ids[:, 3]
+    L.check(lib.sat_vocab_argmax(L.ptr(cu(h)), L.ptr(cu(w)), L.ptr(cu(b)), B, H, V, col.data_ptr(), 20, L.ptr(ws), wsb, st()))
+    sync()
+    assert ids[2, 3].item() == 30
+    assert torch.equal(ids[:, 3].cpu(), ref)
+    assert (ids[:, 0] == -1).all()
+
+
+def test_fc_bn1d_fwd_bwd(lib):
+    from oracle import encoder as OE
+    g = torch.Generator().manual_seed(17)
+    B, Fd, E = 12, 256, 32
+    params, buffers = OE.init_encoder_params(E, dict(layers=(1, 1, 1, 1), width=8), generator=g, randomize_bn=True)
+    pooled = torch.rand(B, Fd, generator=g)
+    dy = torch.randn(B, E, generator=g)
+    bufs = {k: v.clone() for k, v in buffers.items()}
+    y, tape = OE.head_forward(params, bufs, pooled)
+    gr = OE.head_backward(params, tape, dy)
+    rm, rv = cu(buffers["bn.running_mean"]), cu(buffers["bn.running_var"])
+    feats, xhat, rstd = torch.empty(B, E, device="cuda"), torch.empty(B, E, device="cuda"), torch.empty(E, device="cuda")
+    wsb = lib.sat_fc_bn1d_ws_bytes(B, Fd, E)
+    ws = torch.empty(max(wsb // 4, B * E), device="cuda")
+    pd, wd, bd = cu(pooled), cu(params["resnet.fc.weight"]), cu(params["resnet.fc.bias"])
+    gd, bed = cu(params["bn.weight"]), cu(params["bn.bias"])
+    L.check(lib.sat_fc_bn1d_fwd(L.ptr(pd), L.ptr(wd), L.ptr(bd), L.ptr(gd), L.ptr(bed), L.ptr(rm), L.ptr(rv), 0.01, 1e-5, 1,
+                                B, Fd, E, L.ptr(feats), L.ptr(xhat), L.ptr(rstd), L.ptr(ws), ws.numel() * 4, st()))
+    dw, db, dg, dbe = torch.empty(E, Fd, device="cuda"), torch.empty(E, device="cuda"), torch.empty(E, device="cuda"), torch.empty(E, device="cuda")
+    L.check(lib.sat_fc_bn1d_bwd(L.ptr(cu(dy)), L.ptr(pd), L.ptr(xhat), L.ptr(rstd), L.ptr(gd), B, Fd, E, L.ptr(dw), L.ptr(db),
+                                L.ptr(dg), L.ptr(dbe), L.ptr(ws), ws.numel() * 4, st()))
+    sync()
+    np.testing.assert_allclose(feats.cpu().numpy(), y.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), bufs["bn.running_mean"].numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rv.cpu().numpy(), bufs["bn.running_var"].numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dg.cpu().numpy(), gr["bn.weight"].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dbe.cpu().numpy(), gr["bn.bias"].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dw.cpu().numpy(), gr["resnet.fc.weight"].numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), gr["resnet.fc.bias"].numpy(), rtol=0, atol=2e-5)

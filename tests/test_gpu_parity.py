@@ -1,0 +1,276 @@
+"""GPU (MI355X) parity of the HIP path against (a) the golden vectors produced by the reference's own
+`models.DecoderRNN` + train.py arithmetic and (b) the CPU oracle, on identical seeded inputs, plus
+size-independent properties at BASELINE.json's cfg-2 size.  Everything goes through libsat_hip.so."""
+import importlib
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sat = importlib.import_module("show-and-tell_amd")
+from oracle import decoder as OD  # noqa: E402
+from oracle import encoder as OE  # noqa: E402
+from oracle import train_step as OT  # noqa: E402
+
+TINY = dict(layers=(1, 1, 1, 1), width=8)
+SMALL = dict(layers=(2, 1, 2, 1), width=16)
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: z[k] for k in z.files}
+
+
+def golden_setup(g):
+    E, H, V, Lh, B, T = [int(x) for x in g["dims"]]
+    params = OD.init_decoder_params(E, H, V, Lh, generator=torch.Generator().manual_seed(int(g["seed"])))
+    dec = sat.DecoderRNN(E, H, V, Lh)
+    dec.load_state_dict(params)
+    return dec.cuda(), params, (E, H, V, Lh, B, T)
+
+
+@pytest.mark.parametrize("name", ["G1_dec_fwd_bwd_small.npz", "G2_dec_varlen_small.npz", "G5_dec_L2.npz"])
+def test_decoder_autograd_path_matches_reference_goldens(golden_dir, name):
+    """drop-in path: DecoderRNN.forward -> torch CE -> loss.backward() exactly as train.py:134-144 drives it"""
+    g = load(golden_dir, name)
+    dec, params, (E, H, V, Lh, B, T) = golden_setup(g)
+    feats = torch.from_numpy(g["features"]).cuda().requires_grad_(True)
+    caps = torch.from_numpy(g["captions"]).cuda()
+    lengths = [int(x) for x in g["lengths"]]
+    targets, l1 = sat.pack_targets(caps, lengths)                      # train.py:134-135
+    assert np.array_equal(targets.cpu().numpy(), g["targets"])
+    dec.zero_grad()
+    out = dec(feats, caps[:, :-1], l1)                                 # train.py:139
+    assert out.shape == (sum(l1), V)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["logits"], rtol=0, atol=1e-5)
+    loss = torch.nn.CrossEntropyLoss()(out, targets)                   # train.py:143
+    assert abs(loss.item() - float(g["loss"])) < 1e-4                  # north_star: CE within 1e-4 fp32
+    loss.backward()                                                    # train.py:144
+    np.testing.assert_allclose(feats.grad.cpu().numpy(), g["d_features"], rtol=1e-3, atol=1e-7)
+    for k, p in dec.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad." + k], rtol=1e-3, atol=1e-7, err_msg=k)
+
+
+def _decoder_only_model(g):
+    E, H, V, Lh, B, T = [int(x) for x in g["dims"]]
+    model = sat.ShowAndTell(E, H, V, Lh, arch=TINY, compute_dtype="f32")
+    params = OD.init_decoder_params(E, H, V, Lh, generator=torch.Generator().manual_seed(int(g["seed"])))
+    model.decoder.load_state_dict(params)
+    return model.cuda().train()
+
+
+def test_fused_trainstep_three_adam_steps_match_reference(golden_dir):
+    """fused path: HIP CE + backward + clamp + Adam, decoder-only (cached features), vs torch.optim.Adam goldens"""
+    g = load(golden_dir, "G1_dec_fwd_bwd_small.npz")
+    model = _decoder_only_model(g)
+    ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+    feats = torch.from_numpy(g["features"]).cuda()
+    caps = torch.from_numpy(g["captions"]).cuda()
+    lengths = [int(x) for x in g["lengths"]]
+    for it in range(3):
+        loss = ts.step(feats, caps, lengths)
+        assert abs(loss.item() - float(g["losses"][it])) < 1e-4
+        if it == 0:
+            np.testing.assert_allclose(ts.last_d_features.cpu().numpy(), g["d_features"], rtol=1e-3, atol=1e-7)
+        if it + 1 in (1, 3):
+            for k, p in model.decoder.named_parameters():
+                np.testing.assert_allclose(p.detach().cpu().numpy(), g["param_after%d.%s" % (it + 1, k)], rtol=0,
+                                           atol=2e-6, err_msg="%s after %d" % (k, it + 1))
+
+
+@pytest.mark.parametrize("name", ["G2_dec_varlen_small.npz", "G5_dec_L2.npz"])
+def test_fused_trainstep_grads_varlen_and_two_layers(golden_dir, name):
+    g = load(golden_dir, name)
+    model = _decoder_only_model(g)
+    ts = sat.TrainStep(model)
+    feats, caps = torch.from_numpy(g["features"]).cuda(), torch.from_numpy(g["captions"]).cuda()
+    lengths = [int(x) for x in g["lengths"]]
+    n_tok = sum(l - 1 for l in lengths)
+    loss = ts.forward_backward((feats, caps, lengths), 1.0 / n_tok)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    for k, p in model.decoder.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad." + k], rtol=1e-3, atol=1e-7, err_msg=k)
+
+
+def test_cfg1_summary_and_argmax(golden_dir):
+    g = load(golden_dir, "G3_dec_cfg1_summary.npz")
+    dec, params, (E, H, V, Lh, B, T) = golden_setup(g)
+    feats, caps = torch.from_numpy(g["features"]).cuda(), torch.from_numpy(g["captions"]).cuda()
+    lengths = [int(x) for x in g["lengths"]]
+    targets, l1 = sat.pack_targets(caps, lengths)
+    out = dec(feats, caps[:, :-1], l1)
+    loss = torch.nn.functional.cross_entropy(out, targets)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    assert np.array_equal(out.argmax(1).cpu().numpy(), g["argmax"])          # bit-exact token ids
+    np.testing.assert_allclose(out[:, :64].detach().cpu().numpy(), g["logits_head"], rtol=0, atol=1e-5)
+    loss.backward()
+    for k, p in dec.named_parameters():
+        n = float(p.grad.double().norm().item())
+        assert abs(n - float(g["gradnorm." + k])) <= 1e-4 * float(g["gradnorm." + k]) + 1e-9, k
+
+
+@pytest.mark.parametrize("name", ["G1_dec_fwd_bwd_small.npz", "G3_dec_cfg1_summary.npz", "G5_dec_L2.npz"])
+def test_greedy_decode_ids_bit_exact(golden_dir, name):
+    g = load(golden_dir, name)
+    dec, params, (E, H, V, Lh, B, T) = golden_setup(g)
+    ids = dec.eval().sample(torch.from_numpy(g["features"]).cuda(), None)
+    assert ids.shape == (B, 20) and ids.dtype == torch.int64
+    assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])
+
+
+# ------------------------------------------------------------------------------------------------------
+def _encoder_pair(arch, E, seed, dtype):
+    gen = torch.Generator().manual_seed(seed)
+    params, buffers = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
+    enc = sat.EncoderCNN(E, arch=arch, compute_dtype=dtype)
+    sd = dict(params)
+    sd.update(buffers)
+    enc.load_state_dict(sd)
+    return enc.cuda(), params, buffers
+
+
+@pytest.mark.parametrize("arch,hw", [(TINY, 64), (SMALL, 96)])
+def test_encoder_f32_matches_oracle_train_and_eval(arch, hw):
+    E, B = 32, 6
+    enc, params, buffers = _encoder_pair(arch, E, 21, "f32")
+    x = torch.randn(B, 3, hw, hw, generator=torch.Generator().manual_seed(22))
+    bufs = {k: v.clone() for k, v in buffers.items()}
+    pooled_ref, _ = OE.resnet_forward(params, bufs, x, arch, training=True)
+    ref, _ = OE.head_forward(params, bufs, pooled_ref, training=True)
+    enc.train()
+    pooled = enc.pooled_features(x.cuda()).clone()
+    np.testing.assert_allclose(pooled.cpu().numpy(), pooled_ref.numpy(), rtol=2e-3, atol=2e-4)
+    # running statistics were updated exactly once, in place
+    sd = enc.state_dict()
+    for k in ("resnet.bn1.running_mean", "resnet.layer1.0.bn3.running_var", "resnet.layer4.0.downsample.1.running_mean"):
+        np.testing.assert_allclose(sd[k].cpu().numpy(), bufs[k].numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+    assert int(sd["resnet.layer2.0.bn2.num_batches_tracked"]) == 1
+    # full forward (second training pass) then eval pass with the running statistics
+    bufs2 = {k: v.clone() for k, v in bufs.items()}
+    ref2 = OE.encoder_forward(params, bufs2, x, arch, training=True)
+    out2 = enc(x.cuda())
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), ref2.numpy(), rtol=0, atol=5e-3)
+    ref_eval = OE.encoder_forward(params, bufs2, x, arch, training=False)
+    out_eval = enc.eval()(x.cuda())
+    np.testing.assert_allclose(out_eval.detach().cpu().numpy(), ref_eval.numpy(), rtol=0, atol=5e-3)
+    assert ref.shape == out2.shape
+
+
+def test_encoder_bf16_close_to_oracle():
+    arch, E, B = SMALL, 32, 8
+    enc, params, buffers = _encoder_pair(arch, E, 23, "bf16")
+    x = torch.randn(B, 3, 96, 96, generator=torch.Generator().manual_seed(24))
+    bufs = {k: v.clone() for k, v in buffers.items()}
+    pooled_ref, _ = OE.resnet_forward(params, bufs, x, arch, training=True)
+    pooled = enc.train().pooled_features(x.cuda())
+    err = (pooled.cpu() - pooled_ref).abs().max().item()
+    scale = pooled_ref.abs().max().item()
+    assert err < 0.05 * scale + 0.02, (err, scale)       # bf16 activations through 6 bottlenecks: ~1e-2 relative
+    cos = torch.nn.functional.cosine_similarity(pooled.cpu().flatten(), pooled_ref.flatten(), dim=0).item()
+    assert cos > 0.999
+
+
+def test_full_train_step_matches_oracle():
+    """whole train.py:126-146 iteration (encoder f32 + decoder + CE + backward + clamp + Adam) vs the CPU oracle"""
+    arch, E, H, V, Lh, B, T = TINY, 32, 64, 300, 1, 6, 12
+    gen = torch.Generator().manual_seed(31)
+    enc_params, enc_buffers = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
+    dec_params = OD.init_decoder_params(E, H, V, Lh, generator=gen)
+    model = sat.ShowAndTell(E, H, V, Lh, arch=arch, compute_dtype="f32")
+    sd = dict(enc_params)
+    sd.update(enc_buffers)
+    model.encoder.load_state_dict(sd)
+    model.decoder.load_state_dict(dec_params)
+    model.cuda().train()
+    images = torch.randn(B, 3, 64, 64, generator=gen)
+    lengths = [12, 12, 10, 9, 7, 4]
+    caps = torch.zeros(B, T, dtype=torch.long)
+    for b, l in enumerate(lengths):
+        caps[b, 0] = 1
+        caps[b, 1:l - 1] = torch.randint(4, V, (l - 2,), generator=gen)
+        caps[b, l - 1] = 2
+    ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+    state = {}
+    for it in range(2):
+        ref_loss, ref_grads = OT.full_step(enc_params, enc_buffers, dec_params, images, caps, lengths, state, arch=arch,
+                                           num_layers=Lh)
+        loss = ts.step(images.cuda(), caps.cuda(), lengths)
+        assert abs(loss.item() - ref_loss.item()) < 1e-4, it
+    name_map = {"encoder.resnet.fc.weight": enc_params["resnet.fc.weight"], "encoder.bn.weight": enc_params["bn.weight"],
+                "encoder.bn.bias": enc_params["bn.bias"], "encoder.resnet.fc.bias": enc_params["resnet.fc.bias"]}
+    for k, ref in name_map.items():
+        got = dict(model.named_parameters())[k].detach().cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5, err_msg=k)
+    for k, ref in dec_params.items():
+        got = dict(model.decoder.named_parameters())[k].detach().cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE cfg-2 size (B=64, 224x224, E=256, H=512, V=10000): size-independent properties
+def _cfg2(seed=123, B=64):
+    torch.manual_seed(seed)
+    model = sat.ShowAndTell(256, 512, 10000, 1, compute_dtype="bf16").cuda().train()
+    images = torch.randn(B, 3, 224, 224, device="cuda")
+    caps = torch.randint(4, 10000, (B, 20), device="cuda")
+    caps[:, 0], caps[:, 19] = 1, 2
+    return model, images, caps, [20] * B
+
+
+def test_cfg2_full_size_properties():
+    model, images, caps, lengths = _cfg2()
+    ts = sat.TrainStep(model)
+    w0 = model.decoder.linear.weight.detach().clone()
+    l0 = ts.forward_backward((images, caps, lengths), 1.0 / (64 * 19))
+    g_a = ts.flat.grads.clone()
+    l1 = ts.forward_backward((images, caps, lengths), 1.0 / (64 * 19))
+    # (1) determinism: identical inputs -> bit-identical loss and gradients (fixed-order reductions, no atomics)
+    assert l0.item() == l1.item()
+    assert torch.equal(g_a[:ts.flat.n], ts.flat.grads[:ts.flat.n])
+    # (2) at random init the mean CE is ln(V) to within the logit scale
+    assert abs(l0.item() - math.log(10000)) < 0.1
+    # (3) softmax-minus-onehot rows sum to zero => the vocab bias gradient sums to ~0
+    assert abs(ts.flat.grad("decoder.linear.bias").sum().item()) < 1e-4
+    # (4) linearity of the backward in the loss scale
+    ts.forward_backward((images, caps, lengths), 2.0 / (64 * 19))
+    torch.testing.assert_close(ts.flat.grad("decoder.lstm.weight_hh_l0"), 2 * g_a[slice(*_slice(ts, "decoder.lstm.weight_hh_l0"))].view(2048, 512),
+                               rtol=1e-4, atol=1e-9)
+    # (5) the elementwise clamp bounds every Adam update by lr (|m/sqrt(v)| <= 1 on the first step)
+    ts.forward_backward((images, caps, lengths), 1.0 / (64 * 19))
+    ts.optimizer_step()
+    assert (model.decoder.linear.weight.detach() - w0).abs().max().item() <= 1e-3 * 1.001
+    # (6) loss goes down on a fixed batch
+    losses = [ts.step(images, caps, lengths).item() for _ in range(5)]
+    assert losses[-1] < l0.item() - 0.05, losses
+
+
+def _slice(ts, name):
+    o, n, _ = ts.flat.slices[name]
+    return o, o + n
+
+
+def test_cfg2_greedy_and_dropin_forward():
+    model, images, caps, lengths = _cfg2(B=8)
+    out = model(images, caps[:, :-1], [19] * 8)
+    assert out.shape == (8 * 19, 10000) and torch.isfinite(out).all()
+    ids = model.eval().sample(images, None)
+    assert ids.shape == (8, 20) and ids.dtype == torch.int64
+    assert int(ids.min()) >= 0 and int(ids.max()) < 10000
+
+
+@pytest.mark.timeout(900)
+def test_resnet152_f32_matches_oracle_cfg1():
+    """BASELINE cfg-1 shape: batch 4, 224x224, the real [3,8,36,3] stack, f32 MFMA vs the CPU oracle"""
+    arch, E, B = OE.RESNET152, 256, 4
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    enc, params, buffers = _encoder_pair(arch, E, 41, "f32")
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(42))
+    bufs = {k: v.clone() for k, v in buffers.items()}
+    pooled_ref, _ = OE.resnet_forward(params, bufs, x, arch, training=True)
+    pooled = enc.train().pooled_features(x.cuda())
+    err = (pooled.cpu() - pooled_ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, pooled_ref.abs().max().item()), err
