@@ -84,6 +84,8 @@ typedef struct sat_op {
     int64_t sN, sH, sW;       /* element strides of in0 for SAT_OP_CONV (lets the stem read a padded NHWC4 image) */
     int64_t count;            /* BN_FINALIZE: elements per channel (N*Hout*Wout) */
     float momentum, eps;
+    int32_t variant;          /* SAT_OP_CONV: 0 = built-in heuristic, >0 = kernel variant chosen by sat_conv_autotune */
+    int32_t reserved;
 } sat_op;
 
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
@@ -91,6 +93,10 @@ int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
 int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, const sat_op* bnrelu, sat_stream_t stream);
 /* rows of SAT_OP_CONV partials the conv kernel writes for M output pixels */
 int sat_conv_tiles_m(int64_t M);
+/* Build-time tuner (NOT for the hot path: it times launches with HIP events and synchronises): for every bf16
+ * SAT_OP_CONV in ops[] run each kernel variant `reps` times on the op's own buffers and record the fastest in
+ * ops[i].variant.  Results are cached per conv geometry inside the library. */
+int sat_conv_autotune(sat_op* ops /*[host]*/, int n_ops, int reps, sat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder head: resnet.fc (Linear 2048->E) + BatchNorm1d(E, momentum=0.01)  (models.py:16-17,27-28)

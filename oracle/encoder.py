@@ -122,6 +122,48 @@ def resnet_forward(params, buffers, images, arch=RESNET152, training=True, taps=
     return pooled, x
 
 
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def resnet_forward_bf16_storage(params, images, arch=RESNET152):
+    """Train-mode conv stack with every STORED tensor rounded to bfloat16 at the points where the HIP bf16 path
+    stores one (image, weights, raw conv outputs, activations, block outputs); arithmetic stays f32: products of
+    bf16 operands accumulated in f32, batch statistics taken from the un-rounded f32 conv output, affine+ReLU in
+    f32.  This is the oracle for `compute_dtype='bf16'`: what remains between the two is summation order only.
+    Returns pooled [B, feature_dim] (f32).  Running statistics are not touched."""
+    def conv(x, name, stride, pad):
+        return F.conv2d(x, _bf(params["resnet." + name + ".weight"]), None, stride, pad)
+
+    def affine(c_raw, bn):
+        mean = c_raw.mean((0, 2, 3))
+        var = c_raw.var((0, 2, 3), unbiased=False)
+        scale = params["resnet." + bn + ".weight"] / torch.sqrt(var + BN_EPS)
+        shift = params["resnet." + bn + ".bias"] - mean * scale
+        return _bf(c_raw) * scale[None, :, None, None] + shift[None, :, None, None]
+
+    x = _bf(images)
+    x = F.max_pool2d(F.relu(affine(conv(x, "conv1", 2, 3), "bn1")), 3, 2, 1)
+    x = _bf(x)
+    w = arch["width"]
+    inplanes = w
+    for li, nblocks in enumerate(arch["layers"]):
+        planes = w * (2 ** li)
+        for b in range(nblocks):
+            stride = 2 if (li > 0 and b == 0) else 1
+            p = "layer%d.%d." % (li + 1, b)
+            a1 = _bf(F.relu(affine(conv(x, p + "conv1", 1, 0), p + "bn1")))
+            a2 = _bf(F.relu(affine(conv(a1, p + "conv2", stride, 1), p + "bn2")))
+            out = affine(conv(a2, p + "conv3", 1, 0), p + "bn3")
+            if b == 0 and (stride != 1 or inplanes != planes * 4):
+                idt = affine(conv(x, p + "downsample.0", stride, 0), p + "downsample.1")
+            else:
+                idt = x
+            x = _bf(F.relu(out + idt))
+            inplanes = planes * 4
+    return x.mean((2, 3))
+
+
 def head_forward(params, buffers, pooled, training=True):
     """resnet.fc then BatchNorm1d(momentum=0.01): models.py:16-17,27-28.  Returns (features, tape)."""
     z = pooled @ params["resnet.fc.weight"].t() + params["resnet.fc.bias"]

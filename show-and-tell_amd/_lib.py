@@ -29,6 +29,7 @@ class SatOp(C.Structure):
         ("training", C.c_int32), ("tiles_m", C.c_int32),
         ("sN", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64), ("count", C.c_int64),
         ("momentum", C.c_float), ("eps", C.c_float),
+        ("variant", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -40,6 +41,7 @@ SIGNATURES = {
     "sat_run_ops": (_i, [C.POINTER(SatOp), _i, _vp]),
     "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
     "sat_conv_tiles_m": (_i, [_i64]),
+    "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp]),
     "sat_fc_bn1d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_fc_bn1d_ws_bytes": (_i64, [_i, _i, _i]),
     "sat_fc_bn1d_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

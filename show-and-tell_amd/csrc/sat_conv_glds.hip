@@ -1,0 +1,410 @@
+// bf16 implicit-GEMM convolution, deep-prefetch version: the dominant kernel of the Show-and-Tell step
+// (`self.resnet(images)`, models.py:27).
+//
+//   out[m, co] = sum_{kh,kw,ci} in[n, ho*s+kh-p, wo*s+kw-p, ci] * w[co, kh, kw, ci]      m = (n, ho, wo), NHWC
+//
+// ResNet bottleneck layers at batch 64 sit at the HBM/MFMA ridge (1x1 conv, C_in*C_out/(C_in+C_out) ~ 200
+// FLOP/B) and a 128-wide tile consumes a K-step in ~0.1 us, so the kernel lives or dies by bytes in flight:
+//   * operands go global -> LDS directly (global_load_lds_dwordx4, 16 B/lane, no VGPR staging), into a ring of
+//     S stages; S-1 K-steps (24-32 KB each) are in flight per workgroup behind a counted s_waitcnt vmcnt(N)
+//     and ONE raw s_barrier per K-step;
+//   * LDS rows are 128 B (one K-step) unpadded -- an LDS-DMA write is lane-linear -- and bank conflicts are
+//     removed by an XOR swizzle of the 16-byte chunk index, chunk ^ ((row>>1)&7), applied to the per-lane
+//     SOURCE address and to the fragment read (ds_read_b128 stays conflict free);
+//   * zero padding / tile tails: the lane's source pointer is redirected to a 16-byte zero word; per-row tap
+//     validity is a bit mask computed once, so the K loop's address work is ~10 VALU per LDS-DMA piece;
+//   * 8 waves per workgroup (two per SIMD): one wave's address/LDS-read phase hides under its partner's MFMAs;
+//   * epilogue: f32 accumulators -> per-tile BatchNorm column sums (fixed order) and a bf16 tile staged through
+//     LDS so global stores are full 16-byte-per-lane rows;
+//   * blockIdx -> tile map is XCD-aware (tiles sharing an activation panel share an L2).
+#include "sat_internal.h"
+
+namespace {
+
+__device__ u32x4 g_zero16;   // zero-initialised device global: the source of every padded / out-of-range chunk
+
+struct ConvArgs {
+    const bf16_t* A;
+    const bf16_t* B;
+    bf16_t* C;
+    float* stat_partial;
+    int M, N, K;
+    long ldb, ldc;
+    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
+    long sN, sH, sW;
+    int tiles_n;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16 || N == 18 || N == 24,
+                  "add the vmcnt literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+}
+
+// BN: tile width (128/64); S: ring stages; NW: waves (4/8); UNIFORM: Cin % 64 == 0 (a K-step never straddles a tap)
+template <int BN, int S, int NW, bool UNIFORM>
+__global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
+    constexpr int BM = 128, BK = 64, NT = NW * 64;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    // wave grid: NW=4: 2x2;  NW=8: 2(M)x4(N) for BN=128, 4(M)x2(N) for BN=64
+    constexpr int WGM = (NW == 4) ? 2 : (BN == 128 ? 2 : 4);
+    constexpr int WGN = NW / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int NAI = BM / 8 / NW, NBI = BN / 8 / NW;   // LDS-DMA pieces (8 rows x 128 B) per wave per stage
+    constexpr int LPW = NAI + NBI;
+    constexpr int D = S - 1;                               // K-steps kept in flight
+    constexpr int CROW = BN * 2 + 16;                      // bf16 C-tile row stride in LDS (epilogue)
+    static_assert(BM * CROW + 4 * WGM * BN * 4 <= S * STAGE, "epilogue tile + stat scratch must fit the ring");
+    static_assert(TM >= 1 && TN >= 1 && NAI >= 1 && NBI >= 1, "bad tile/wave split");
+    __shared__ __attribute__((aligned(16))) char smem[S * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tile_m = swz / p.tiles_n, tile_n = swz - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const bf16_t* zero = (const bf16_t*)&g_zero16;
+
+    // ---- K-invariant per-lane state: lane covers row (l>>3) of each 8-row LDS-DMA piece, LDS chunk slot l&7;
+    //      it fetches logical chunk (l&7) ^ ((row>>1)&7) so that the LDS image is XOR-swizzled ----
+    const bf16_t* a_ptr[NAI];       // pixel (n, ho*s-p, wo*s-p), channel = this lane's chunk
+    unsigned a_mask[NAI];           // UNIFORM: bit t = tap t in bounds for this row
+    int a_hi0[NAI], a_wi0[NAI], a_c[NAI];
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+        const int row = wave * (NAI * 8) + i * 8 + (lane >> 3);
+        a_c[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        const int grow = m0 + row;
+        a_mask[i] = 0u;
+        if (grow < p.M) {
+            const int hw = p.Hout * p.Wout;
+            const int n = grow / hw;
+            const int rem = grow - n * hw;
+            const int ho = rem / p.Wout;
+            const int wo = rem - ho * p.Wout;
+            a_hi0[i] = ho * p.stride - p.pad;
+            a_wi0[i] = wo * p.stride - p.pad;
+            a_ptr[i] = p.A + ((long)n * p.sN + (long)a_hi0[i] * p.sH + (long)a_wi0[i] * p.sW + a_c[i]);
+            if constexpr (UNIFORM) {
+                for (int kh = 0; kh < p.KH; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw) {
+                        const bool in = ((unsigned)(a_hi0[i] + kh) < (unsigned)p.Hin) && ((unsigned)(a_wi0[i] + kw) < (unsigned)p.Win);
+                        a_mask[i] |= (in ? 1u : 0u) << (kh * p.KW + kw);
+                    }
+            }
+        } else {
+            a_hi0[i] = -(1 << 28); a_wi0[i] = -(1 << 28); a_ptr[i] = zero;
+        }
+    }
+    const bf16_t* b_ptr[NBI];
+    int b_c[NBI];
+    bool b_ok[NBI];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int row = wave * (NBI * 8) + i * 8 + (lane >> 3);
+        b_c[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        const int gn = n0 + row;
+        b_ok[i] = gn < p.N;
+        b_ptr[i] = b_ok[i] ? p.B + ((long)gn * p.ldb + b_c[i]) : zero;
+    }
+    const int nk = (p.K + BK - 1) / BK;
+
+    // scalar walk of the K axis for the UNIFORM path (no division in the loop)
+    int is_kt = 0, is_tap = 0, is_cb = 0, is_kh = 0, is_kw = 0;
+
+    auto issue = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + A_BYTES;
+        const int kt = is_kt;
+        const bool live = kt < nk;                       // beyond the K range: zero-source dummies keep counts uniform
+        if constexpr (UNIFORM) {
+            const long tapoff = (long)is_kh * p.sH + (long)is_kw * p.sW + is_cb;
+#pragma unroll
+            for (int i = 0; i < NAI; ++i) {
+                const bool ok = live && ((a_mask[i] >> is_tap) & 1u);
+                const bf16_t* src = ok ? a_ptr[i] + tapoff : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wave * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) {
+                const bf16_t* src = (live && b_ok[i]) ? b_ptr[i] + (long)kt * BK : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (wave * (NBI * 8) + i * 8) * 128), 16, 0, 0);
+            }
+            is_cb += BK;
+            if (is_cb >= p.Cin) {
+                is_cb = 0; ++is_tap; ++is_kw;
+                if (is_kw == p.KW) { is_kw = 0; ++is_kh; }
+            }
+        } else {
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int i = 0; i < NAI; ++i) {
+                const int kk = k0 + a_c[i];
+                const int tap = kk / p.Cin;
+                const int c = kk - tap * p.Cin;
+                const int kh = tap / p.KW;
+                const int kw = tap - kh * p.KW;
+                const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+                const bool ok = (kk < p.K) && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
+                // a_ptr already carries this lane's chunk offset a_c: add the tap offset and (c - a_c)
+                const bf16_t* src = ok ? a_ptr[i] + ((long)kh * p.sH + (long)kw * p.sW + (c - a_c[i])) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wave * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) {
+                const bool ok = b_ok[i] && (k0 + b_c[i] < p.K);
+                const bf16_t* src = ok ? b_ptr[i] + k0 : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (wave * (NBI * 8) + i * 8) * 128), 16, 0, 0);
+            }
+        }
+        ++is_kt;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // fragment read offsets, K-invariant: row*128 + ((chunk ^ ((row>>1)&7)) * 16), chunk = 2*ks + h
+    int a_off[TM][4], b_off[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * WM + i * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a_off[i][ks] = row * 128 + (((2 * ks + h) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * WN + j * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b_off[j][ks] = A_BYTES + row * 128 + (((2 * ks + h) ^ ((row >> 1) & 7)) << 4);
+    }
+
+#pragma unroll
+    for (int s = 0; s < D; ++s) issue(s);
+
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of K-step kt have landed once all but the (D-1) younger K-steps are done ...
+        wait_vmcnt<LPW * (D - 1)>();
+        // ... and everybody's have once every wave is past that wait; the same barrier retires all reads of
+        // K-step kt-1, whose ring slot the next issue overwrites.
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");            // no LDS read may be hoisted above the barrier
+        int nbuf = buf + D;
+        if (nbuf >= S) nbuf -= S;
+        issue(nbuf);
+        const char* st = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const bf16x8*)(st + a_off[i][ks]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const bf16x8*)(st + b_off[j][ks]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        buf = (buf + 1 == S) ? 0 : buf + 1;
+    }
+    // drain the dummy prefetches and let every wave finish its last reads before the ring is reused
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    // ---- epilogue 1: BatchNorm partial column sums from the f32 accumulators ----
+    float* red = (float*)(smem + BM * CROW);     // [WGM][2][BN] floats, placed after the C tile
+    if (p.stat_partial) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[i][j][e];
+                    s += v;
+                    q += v * v;
+                }
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (h == 0) {
+                red[(wm * 2 + 0) * BN + wn * WN + j * 32 + r] = s;
+                red[(wm * 2 + 1) * BN + wn * WN + j * 32 + r] = q;
+            }
+        }
+    }
+    // ---- epilogue 2: bf16 C tile through LDS (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int col = wn * WN + j * 32 + r;
+                *(bf16_t*)(smem + row * CROW + col * 2) = (bf16_t)acc[i][j][e];
+            }
+    __syncthreads();
+    if (p.stat_partial) {
+        for (int c = tid; c < BN; c += NT) {
+            const int col = n0 + c;
+            if (col < p.N) {
+                float s = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int g = 0; g < WGM; ++g) {          // fixed order over the M-waves
+                    s += red[(g * 2 + 0) * BN + c];
+                    q += red[(g * 2 + 1) * BN + c];
+                }
+                p.stat_partial[((long)tile_m * 2 + 0) * p.N + col] = s;
+                p.stat_partial[((long)tile_m * 2 + 1) * p.N + col] = q;
+            }
+        }
+    }
+    constexpr int CPR = BN / 8;                  // 16-byte chunks per C row
+#pragma unroll
+    for (int it = 0; it < BM * CPR / NT; ++it) {
+        const int qid = tid + it * NT;
+        const int row = qid / CPR, cc = qid - row * CPR;
+        const int grow = m0 + row, gcol = n0 + cc * 8;
+        if (grow < p.M && gcol < p.N)             // N % 8 == 0: a chunk is all in or all out
+            *(u32x4*)(p.C + (long)grow * p.ldc + gcol) = *(const u32x4*)(smem + row * CROW + cc * 16);
+    }
+}
+
+template <int BN, int S, int NW>
+int launch_glds(ConvArgs& a, hipStream_t s) {
+    const int tm = sat_cdiv(a.M, 128), tn = sat_cdiv(a.N, BN);
+    a.tiles_n = tn;
+    const bool uniform = (a.Cin % 64 == 0) && (a.KH * a.KW <= 32);
+    if (uniform) hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
+    else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+// kernel variants: (tile width, ring stages, waves).  LDS = S * (16 + BN/8) KB decides workgroups per CU.
+struct Variant { int bn, s, nw; };
+constexpr Variant kVariants[] = {
+    {128, 4, 8}, {128, 3, 8}, {128, 2, 8}, {64, 4, 8}, {64, 3, 8}, {64, 2, 8},
+    {128, 4, 4}, {128, 2, 4}, {64, 3, 4}, {64, 2, 4},
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+int launch_variant(int v, ConvArgs& a, hipStream_t s) {
+    switch (v) {
+        case 0: return launch_glds<128, 4, 8>(a, s);
+        case 1: return launch_glds<128, 3, 8>(a, s);
+        case 2: return launch_glds<128, 2, 8>(a, s);
+        case 3: return launch_glds<64, 4, 8>(a, s);
+        case 4: return launch_glds<64, 3, 8>(a, s);
+        case 5: return launch_glds<64, 2, 8>(a, s);
+        case 6: return launch_glds<128, 4, 4>(a, s);
+        case 7: return launch_glds<128, 2, 4>(a, s);
+        case 8: return launch_glds<64, 3, 4>(a, s);
+        case 9: return launch_glds<64, 2, 4>(a, s);
+        default: return SAT_ERR_ARG;
+    }
+}
+
+ConvArgs make_args(const sat_op* op) {
+    ConvArgs a = {};
+    a.A = (const bf16_t*)op->in0; a.B = (const bf16_t*)op->w; a.C = (bf16_t*)op->out;
+    a.stat_partial = op->stat_partial;
+    a.M = op->N * op->Hout * op->Wout; a.N = op->Cout; a.K = op->KH * op->KW * op->Cin;
+    a.ldb = a.K; a.ldc = op->Cout;
+    a.Hin = op->Hin; a.Win = op->Win; a.Cin = op->Cin; a.Hout = op->Hout; a.Wout = op->Wout;
+    a.KH = op->KH; a.KW = op->KW; a.stride = op->stride; a.pad = op->pad;
+    a.sN = op->sN; a.sH = op->sH; a.sW = op->sW;
+    return a;
+}
+
+int heuristic_variant(const ConvArgs& a) {
+    // 128x128 with a deep ring when it still leaves >= 2 tiles per CU and K is long enough to use the ring;
+    // otherwise 128x64 with a shallower ring (more workgroups per CU to overlap prologue/epilogue phases)
+    const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
+    const int nk = sat_cdiv(a.K, 64);
+    if (a.N > 64 && t128 >= 512) return nk <= 4 ? 2 : 0;
+    return nk <= 4 ? 5 : 4;
+}
+
+}  // namespace
+
+// bf16 SAT_OP_CONV; arguments already validated by sat_conv_launch
+int sat_conv_glds_launch(const sat_op* op, hipStream_t s) {
+    if (op->Cout % 8) return SAT_ERR_UNSUPPORTED;
+    ConvArgs a = make_args(op);
+    const int v = (op->variant > 0 && op->variant <= kNumVariants) ? op->variant - 1 : heuristic_variant(a);
+    return launch_variant(v, a, s);
+}
+
+#include <map>
+#include <tuple>
+#include <stdio.h>
+
+extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t stream) {
+    if (!ops || n_ops < 0 || reps < 1) return SAT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int> Key;
+    static std::map<Key, int> cache;
+    const bool verbose = getenv("SAT_TUNE_VERBOSE") != nullptr;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SAT_ERR_UNSUPPORTED;
+    int rc = SAT_OK;
+    for (int i = 0; i < n_ops && rc == SAT_OK; ++i) {
+        sat_op* op = ops + i;
+        if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) continue;
+        const Key key(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
+                      op->stat_partial ? 1 : 0);
+        auto it = cache.find(key);
+        if (it != cache.end()) { op->variant = it->second; continue; }
+        ConvArgs a = make_args(op);
+        float best = 1e30f;
+        int best_v = heuristic_variant(a);
+        for (int v = 0; v < kNumVariants; ++v) {
+            if (kVariants[v].bn == 128 && a.N <= 64) continue;
+            float tmin = 1e30f;
+            for (int round = 0; round < 2 && rc == SAT_OK; ++round) {       // round 0 = warm-up
+                if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+                for (int r = 0; r < reps && rc == SAT_OK; ++r) rc = launch_variant(v, a, s);
+                if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (round == 1) tmin = ms / reps;
+            }
+            if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d v%d(%d,%d,%d) %.2f us\n", a.M, a.N, a.K, v, kVariants[v].bn,
+                                 kVariants[v].s, kVariants[v].nw, tmin * 1e3f);
+            if (tmin < best) { best = tmin; best_v = v; }
+        }
+        if (verbose) fprintf(stderr, "tune M=%d N=%d K=%d -> v%d %.2f us (%.0f TFLOP/s)\n", a.M, a.N, a.K, best_v, best * 1e3f,
+                             2.0 * a.M * a.N * a.K / (best * 1e-3) / 1e12);
+        cache[key] = best_v + 1;
+        op->variant = best_v + 1;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+}

@@ -65,18 +65,29 @@ __global__ void image_prep_kernel(const float* __restrict__ in, T* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------------
 // batch-norm finalize: per-tile partial (sum, sumsq) -> scale/shift; running-stat update (momentum).
-// block = 32 channels x 8 partial groups; f64 accumulation, fixed order.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int tiles_m, int C,
-                                                          double count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* running_mean,
-                                                          float* running_var, float momentum, float eps,
-                                                          int training, float* scale, float* shift) {
-    __shared__ double ss[8][32], sq[8][32];
+// block = 32 channels x 32 partial groups (1024 threads: the kernel is pure load latency, so go wide);
+// f64 accumulation, fixed order.
+constexpr int FIN_G = 32;
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int tiles_m, int C,
+                                                           double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* running_mean,
+                                                           float* running_var, float momentum, float eps,
+                                                           int training, float* scale, float* shift) {
+    __shared__ double ss[FIN_G][32], sq[FIN_G][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     if (training && c < C) {
-        for (int t = rg; t < tiles_m; t += 8) {
+        int t = rg;
+        for (; t + 3 * FIN_G < tiles_m; t += 4 * FIN_G) {      // 8 independent loads in flight per thread
+            const float a0 = partial[((long)t * 2 + 0) * C + c], b0 = partial[((long)t * 2 + 1) * C + c];
+            const float a1 = partial[((long)(t + FIN_G) * 2 + 0) * C + c], b1 = partial[((long)(t + FIN_G) * 2 + 1) * C + c];
+            const float a2 = partial[((long)(t + 2 * FIN_G) * 2 + 0) * C + c], b2 = partial[((long)(t + 2 * FIN_G) * 2 + 1) * C + c];
+            const float a3 = partial[((long)(t + 3 * FIN_G) * 2 + 0) * C + c], b3 = partial[((long)(t + 3 * FIN_G) * 2 + 1) * C + c];
+            s += (double)a0; s += (double)a1; s += (double)a2; s += (double)a3;
+            q += (double)b0; q += (double)b1; q += (double)b2; q += (double)b3;
+        }
+        for (; t < tiles_m; t += FIN_G) {
             s += (double)partial[((long)t * 2 + 0) * C + c];
             q += (double)partial[((long)t * 2 + 1) * C + c];
         }
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         if (training) {
             double S = 0.0, Q = 0.0;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) { S += ss[g][cl]; Q += sq[g][cl]; }
+            for (int g = 0; g < FIN_G; ++g) { S += ss[g][cl]; Q += sq[g][cl]; }
             mean = S / count;
             var = Q / count - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -108,13 +119,56 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-// out = relu(in0*s0 + t0)  /  out = relu(in0*s0 + t0 + (in1*s1 + t1 | in1)); NHWC, C % chunk == 0
+// out = relu(in0*s0 + t0)  /  out = relu(in0*s0 + t0 + (in1*s1 + t1 | in1)); NHWC, C % chunk == 0.
+// When the total thread count is a multiple of the chunks per pixel, a thread's channel chunk never changes
+// along its grid-stride walk: scale/shift then live in registers and the loop is pure 16-byte streaming.
 template <typename T, bool ADD>
 __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ in1, T* __restrict__ out,
                               const float* __restrict__ s0, const float* __restrict__ t0,
                               const float* __restrict__ s1, const float* __restrict__ t1, long nchunks, int C) {
     constexpr int V = Vec<T>::N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cch = C / V;
+    if (stride % cch == 0) {
+        const int c0 = (int)(i0 % cch) * V;
+        float sc0[V], sh0[V], sc1[V], sh1[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            sc0[k] = s0[c0 + k]; sh0[k] = t0[c0 + k];
+            sc1[k] = (ADD && s1) ? s1[c0 + k] : 1.0f;
+            sh1[k] = (ADD && s1) ? t1[c0 + k] : 0.0f;
+        }
+        constexpr int U = 4;                       // 4 (8 with ADD) independent 16-byte loads in flight per lane
+        for (long i = i0; i < nchunks; i += stride * U) {
+            float x[U][V], z[U][V];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long iu = i + u * stride;
+                if (iu < nchunks) {
+                    load_chunk<T>(in0 + iu * V, x[u]);
+                    if constexpr (ADD) load_chunk<T>(in1 + iu * V, z[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long iu = i + u * stride;
+                if (iu < nchunks) {
+                    float y[V];
+                    if constexpr (ADD) {
+#pragma unroll
+                        for (int k = 0; k < V; ++k) y[k] = fmaxf(x[u][k] * sc0[k] + sh0[k] + (z[u][k] * sc1[k] + sh1[k]), 0.0f);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < V; ++k) y[k] = fmaxf(x[u][k] * sc0[k] + sh0[k], 0.0f);
+                    }
+                    store_chunk<T>(out + iu * V, y);
+                }
+            }
+        }
+        return;
+    }
+    for (long i = i0; i < nchunks; i += stride) {
         const int c0 = (int)((i * V) % C);
         float x[V], y[V];
         load_chunk<T>(in0 + i * V, x);
@@ -543,7 +597,7 @@ int sat_bn_finalize_launch(const sat_op* op, hipStream_t s) {
     if (!op->gamma || !op->beta || !op->scale_out || !op->shift_out) return SAT_ERR_ARG;
     if (op->training && !op->stat_partial) return SAT_ERR_ARG;
     if (!op->training && (!op->running_mean || !op->running_var)) return SAT_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sat_cdiv(op->Cout, 32)), dim3(256), 0, s, op->stat_partial, op->tiles_m,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sat_cdiv(op->Cout, 32)), dim3(1024), 0, s, op->stat_partial, op->tiles_m,
                        op->Cout, (double)op->count, op->gamma, op->beta, op->running_mean, op->running_var,
                        op->momentum, op->eps, op->training, op->scale_out, op->shift_out);
     SAT_LAUNCH_CHECK();

@@ -36,43 +36,61 @@ struct SkinnyArgs {
     float* pmax; int* pidx;                   // [M][gridDim.x]
 };
 
+constexpr int NWV = 8;   // waves per workgroup: K is split 8 ways (x gridDim.z), partial tiles reduced through LDS
+
+template <bool WKM>
+__device__ __forceinline__ void load_operands(const float* __restrict__ A, long lda, const float* __restrict__ W, long ldw,
+                                              int K, int M, int row_chunk0, long wrow, bool wrow_ok, int kb, int lane,
+                                              f32x4& b, f32x4 (&a)[4]) {
+    const int n16 = lane & 15, kg = lane >> 4;
+    const int k = kb * 16 + kg * 4;
+    const bool kok = k < K;   // K % 4 == 0
+    b = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (kok && wrow_ok) {
+        if constexpr (!WKM) {
+            b = *(const f32x4*)(W + wrow * ldw + k);
+        } else {
+            b[0] = W[(long)(k + 0) * ldw + wrow];
+            b[1] = W[(long)(k + 1) * ldw + wrow];
+            b[2] = W[(long)(k + 2) * ldw + wrow];
+            b[3] = W[(long)(k + 3) * ldw + wrow];
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = row_chunk0 + mt * 16 + n16;
+        a[mt] = (kok && row < M) ? *(const f32x4*)(A + (long)row * lda + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// software-pipelined: the operands of K-block kb+step are in flight while the MFMAs of K-block kb issue
 template <bool WKM>
 __device__ __forceinline__ void accumulate_pair(const float* __restrict__ A, long lda, const float* __restrict__ W,
                                                 long ldw, int K, int M, int row_chunk0, long wrow, bool wrow_ok,
                                                 int kb0, int kbstep, int lane, f32x4 (&acc)[4]) {
-    const int n16 = lane & 15, kg = lane >> 4;
     const int nkb = (K + 15) >> 4;
+    if (kb0 >= nkb) return;
+    f32x4 b, a[4], bn, an[4];
+    load_operands<WKM>(A, lda, W, ldw, K, M, row_chunk0, wrow, wrow_ok, kb0, lane, b, a);
     for (int kb = kb0; kb < nkb; kb += kbstep) {
-        const int k = kb * 16 + kg * 4;
-        const bool kok = k < K;   // K % 4 == 0
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (kok && wrow_ok) {
-            if constexpr (!WKM) {
-                b = *(const f32x4*)(W + wrow * ldw + k);
-            } else {
-                b[0] = W[(long)(k + 0) * ldw + wrow];
-                b[1] = W[(long)(k + 1) * ldw + wrow];
-                b[2] = W[(long)(k + 2) * ldw + wrow];
-                b[3] = W[(long)(k + 3) * ldw + wrow];
-            }
-        }
-        f32x4 a[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int row = row_chunk0 + mt * 16 + n16;
-            a[mt] = (kok && row < M) ? *(const f32x4*)(A + (long)row * lda + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        const bool more = kb + kbstep < nkb;
+        if (more) load_operands<WKM>(A, lda, W, ldw, K, M, row_chunk0, wrow, wrow_ok, kb + kbstep, lane, bn, an);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][e], b[e], acc[mt], 0, 0, 0);
+        if (more) {
+            b = bn;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a[mt] = an[mt];
+        }
     }
 }
 
 template <int EPI, bool WKM>
-__global__ __launch_bounds__(256) void skinny_kernel(const SkinnyArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4][64][16];
+__global__ __launch_bounds__(NWV * 64) void skinny_kernel(const SkinnyArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[NWV][64][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cg = blockIdx.x, rc0 = blockIdx.y * 64, z = blockIdx.z;
     const int n16 = lane & 15;
@@ -91,8 +109,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyArgs p) {
     f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    accumulate_pair<WKM>(p.A, p.lda, p.W, p.ldw, p.K, p.M, rc0, wrow, wrow_ok, z * 4 + wave, 4 * p.nz, lane, acc);
-    if (p.A2) accumulate_pair<false>(p.A2, p.lda2, p.W2, p.ldw2, p.K2, p.M, rc0, wrow, wrow_ok, z * 4 + wave, 4 * p.nz, lane, acc);
+    accumulate_pair<WKM>(p.A, p.lda, p.W, p.ldw, p.K, p.M, rc0, wrow, wrow_ok, z * NWV + wave, NWV * p.nz, lane, acc);
+    if (p.A2) accumulate_pair<false>(p.A2, p.lda2, p.W2, p.ldw2, p.K2, p.M, rc0, wrow, wrow_ok, z * NWV + wave, NWV * p.nz, lane, acc);
 
     // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
@@ -100,13 +118,14 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[wave][mt * 16 + (lane >> 4) * 4 + e][n16] = acc[mt][e];
     __syncthreads();
+    if (tid >= 256) return;                  // the epilogue is 64 rows x 4 column quads = 256 lanes
 
-    const int row = tid >> 2, q = tid & 3;   // 64 rows x 4 column quads
+    const int row = tid >> 2, q = tid & 3;
     const int grow = rc0 + row;
     if constexpr (EPI == EPI_STORE) {
         f32x4 v = *(const f32x4*)&red[0][row][q * 4];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NWV; ++w) {
             const f32x4 t = *(const f32x4*)&red[w][row][q * 4];
             v += t;
         }
@@ -131,7 +150,9 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyArgs p) {
             float g4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float s = red[0][row][g * 4 + q] + red[1][row][g * 4 + q] + red[2][row][g * 4 + q] + red[3][row][g * 4 + q];
+                float s = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) s += red[w][row][g * 4 + q];
                 const long wr = (long)g * H + j;
                 if (p.xg) s += p.xg[(long)grow * p.ldxg + wr];
                 if (p.bias) s += p.bias[wr];
@@ -158,7 +179,9 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyArgs p) {
         for (int e = 0; e < 4; ++e) {
             const int col = cg * 16 + q * 4 + e;
             if (col < p.N) {
-                float s = red[0][row][q * 4 + e] + red[1][row][q * 4 + e] + red[2][row][q * 4 + e] + red[3][row][q * 4 + e];
+                float s = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) s += red[w][row][q * 4 + e];
                 if (p.bias) s += p.bias[col];
                 if (s > best) { best = s; bidx = col; }
             }
@@ -211,8 +234,8 @@ int sat_skinny_store(const float* A, long lda, const float* W, long ldw, int wkm
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.K = K; a.M = M; a.N = N; a.nz = nz;
     a.out = out; a.ldo = ldo; a.slab_stride = slab_stride; a.bias = bias;
     dim3 grid(sat_cdiv(N, 16), sat_cdiv(M, 64), nz);
-    if (wkm) hipLaunchKernelGGL((skinny_kernel<EPI_STORE, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<EPI_STORE, false>), grid, dim3(256), 0, s, a);
+    if (wkm) hipLaunchKernelGGL((skinny_kernel<EPI_STORE, true>), grid, dim3(NWV * 64), 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<EPI_STORE, false>), grid, dim3(NWV * 64), 0, s, a);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
@@ -229,7 +252,7 @@ int sat_skinny_lstm(const float* h_prev, const float* w_hh, const float* x, cons
     a.bias = bias; a.bias2 = bias2; a.xg = xg; a.ldxg = ldxg;
     a.c_state = c_state; a.ga = ga; a.ldga = ldga; a.cs = cs; a.h_out = h_out; a.h_out2 = h_out2; a.m2 = m2;
     dim3 grid(sat_cdiv(H, 4), sat_cdiv(M, 64), 1);
-    hipLaunchKernelGGL((skinny_kernel<EPI_LSTM, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_kernel<EPI_LSTM, false>), grid, dim3(NWV * 64), 0, s, a);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
@@ -247,7 +270,7 @@ extern "C" int sat_vocab_argmax(const float* h, const float* w, const float* b, 
     a.A = h; a.lda = H; a.W = w; a.ldw = H; a.K = H; a.M = B; a.N = V; a.nz = 1; a.bias = b;
     a.pmax = workspace; a.pidx = (int*)(workspace + (long)B * ncg);
     dim3 grid(ncg, sat_cdiv(B, 64), 1);
-    hipLaunchKernelGGL((skinny_kernel<EPI_ARGMAX, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_kernel<EPI_ARGMAX, false>), grid, dim3(NWV * 64), 0, s, a);
     SAT_LAUNCH_CHECK();
     hipLaunchKernelGGL(argmax_reduce_kernel, dim3(B), dim3(256), 0, s, a.pmax, a.pidx, ncg, ids, ids_stride);
     SAT_LAUNCH_CHECK();

@@ -16,6 +16,7 @@ Batch statistics come out of the conv epilogue as per-tile column sums (fixed-or
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -278,6 +279,12 @@ class ConvStackProgram:
         self.final_map = (y, N, geo[-1][2], geo[-1][3], stack.feature_dim)
         self.ops = (L.SatOp * len(ops))(*ops)
         self.n_ops = len(ops)
+        # build-time kernel selection per conv geometry (bf16): time every variant on this program's own buffers
+        if dtype == L.SAT_BF16 and os.environ.get("SAT_AUTOTUNE", "1") != "0" and torch.device(device).type == "cuda":
+            for t in (self.c0, self.c1, self.a1, self.c2, self.a2, self.c3, self.cd, *self.ybuf):
+                t.normal_()
+            L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 3, L.stream()), "sat_conv_autotune")
+            torch.cuda.synchronize()
 
     def run(self, images):
         """images f32 [N,3,H,W] NCHW on the device -> pooled f32 [N, feature_dim] (owned by the program)."""

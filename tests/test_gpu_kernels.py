@@ -107,6 +107,41 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("variant", list(range(1, 11)))
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(3, 15, 13, 64, 192, 3, 1, 1), (2, 9, 9, 24, 72, 3, 2, 1),
+                                                         (5, 8, 8, 320, 64, 1, 1, 0)])
+def test_conv_bf16_every_kernel_variant(lib, variant, N, H, W, Cin, Cout, k, stride, pad):
+    """every (tile, ring depth, waves) variant the autotuner may pick computes the same convolution + statistics"""
+    g = torch.Generator().manual_seed(variant * 31 + Cin)
+    x = (torch.randn(N, Cin, H, W, generator=g)).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+    o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), stride, pad)
+    o.variant = variant
+    L.check(lib.sat_run_ops(C.pointer(o), 1, st()))
+    sync()
+    out = keep[2].float().cpu().double()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < 2e-2
+    part = keep[3].cpu().double()
+    np.testing.assert_allclose(part[:, 0].sum(0).numpy(), ref.sum(0).numpy(), rtol=0, atol=1e-3 * ref.shape[0] ** 0.5 + 1e-4)
+    np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
+
+
+def test_conv_autotune_sets_a_variant_and_keeps_results(lib):
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(4, 128, 14, 14, generator=g).bfloat16().float()
+    w = (torch.randn(256, 128, 3, 3, generator=g) / 34.0).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, 256)
+    o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1)
+    ops = (L.SatOp * 1)(o)
+    L.check(lib.sat_conv_autotune(ops, 1, 2, st()))
+    assert 1 <= ops[0].variant <= 10
+    L.check(lib.sat_run_ops(ops, 1, st()))
+    sync()
+    assert (keep[2].float().cpu().double() - ref).abs().max().item() < 2e-2
+
+
 @pytest.mark.parametrize("dtype", [L.SAT_F32, L.SAT_BF16])
 def test_stem_conv_via_padded_nhwc4(lib, dtype):
     """image prep + 7x7/2 conv on the padded NHWC4 image == conv2d(images, w, stride 2, pad 3)"""
@@ -309,4 +344,6 @@ def test_fc_bn1d_fwd_bwd(lib):
     np.testing.assert_allclose(dg.cpu().numpy(), gr["bn.weight"].numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(dbe.cpu().numpy(), gr["bn.bias"].numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(dw.cpu().numpy(), gr["resnet.fc.weight"].numpy(), rtol=1e-3, atol=2e-5)
-    np.testing.assert_allclose(db.cpu().numpy(), gr["resnet.fc.bias"].numpy(), rtol=0, atol=2e-5)
+    # d(fc.bias) = sum_b dz is mathematically ZERO under train-mode BatchNorm: both sides hold rounding noise of size
+    # ~1e-7 * sum_b |dz| (|dz| is O(10) here), so only its smallness can be compared
+    assert db.cpu().abs().max().item() < 5e-4 and gr["resnet.fc.bias"].abs().max().item() < 5e-4

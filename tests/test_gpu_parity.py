@@ -168,11 +168,18 @@ def test_encoder_bf16_close_to_oracle():
     bufs = {k: v.clone() for k, v in buffers.items()}
     pooled_ref, _ = OE.resnet_forward(params, bufs, x, arch, training=True)
     pooled = enc.train().pooled_features(x.cuda())
-    err = (pooled.cpu() - pooled_ref).abs().max().item()
-    scale = pooled_ref.abs().max().item()
-    assert err < 0.05 * scale + 0.02, (err, scale)       # bf16 activations through 6 bottlenecks: ~1e-2 relative
+    # (a) against the f32 oracle: bf16 storage (2^-8 relative rounding) through 6 bottlenecks whose BatchNorms
+    #     renormalise with the statistics of 72..4608 samples: a few percent, direction preserved
+    diff = (pooled.cpu() - pooled_ref)
+    assert (diff.norm() / pooled_ref.norm()).item() < 0.08
     cos = torch.nn.functional.cosine_similarity(pooled.cpu().flatten(), pooled_ref.flatten(), dim=0).item()
-    assert cos > 0.999
+    assert cos > 0.997
+    # (b) against the oracle with bf16 STORAGE emulated at the same points (f32 arithmetic): only summation
+    #     order is left, plus the occasional 1-ulp bf16 flip it causes downstream
+    ref_bf = OE.resnet_forward_bf16_storage(params, x, arch)
+    d2 = (pooled.cpu() - ref_bf)
+    assert (d2.norm() / ref_bf.norm()).item() < 0.01, (d2.norm() / ref_bf.norm()).item()
+    assert d2.abs().max().item() < 0.03 * ref_bf.abs().max().item() + 0.01
 
 
 def test_full_train_step_matches_oracle():
