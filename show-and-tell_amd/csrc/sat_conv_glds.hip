@@ -33,6 +33,7 @@ struct ConvArgs {
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
     long sN, sH, sW;
     int tiles_n;
+    int linear;     // 1x1 / stride 1 / no padding on a dense NHWC tensor: output row m reads input pixel m
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -94,7 +95,11 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         a_c[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
         const int grow = m0 + row;
         a_mask[i] = 0u;
-        if (grow < p.M) {
+        if (grow < p.M && p.linear) {
+            a_hi0[i] = 0; a_wi0[i] = 0;
+            a_ptr[i] = p.A + ((long)grow * p.sW + a_c[i]);
+            a_mask[i] = 1u;
+        } else if (grow < p.M) {
             const int hw = p.Hout * p.Wout;
             const int n = grow / hw;
             const int rem = grow - n * hw;
@@ -339,6 +344,8 @@ ConvArgs make_args(const sat_op* op) {
     a.Hin = op->Hin; a.Win = op->Win; a.Cin = op->Cin; a.Hout = op->Hout; a.Wout = op->Wout;
     a.KH = op->KH; a.KW = op->KW; a.stride = op->stride; a.pad = op->pad;
     a.sN = op->sN; a.sH = op->sH; a.sW = op->sW;
+    a.linear = (op->KH == 1 && op->KW == 1 && op->stride == 1 && op->pad == 0 && op->Hout == op->Hin &&
+                op->Wout == op->Win && op->sH == (long)op->Win * op->sW && op->sN == (long)op->Hin * op->sH) ? 1 : 0;
     return a;
 }
 

@@ -6,13 +6,16 @@
 //   trainer : fused elementwise clamp + Adam over one flat buffer (train.py:88-91,146)
 #include "sat_common.h"
 #include "../../include/sat_hip.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int EW_BLOCK = 256;
 inline int ew_grid(long n_items) {
+    static long cap = 0;
+    if (cap == 0) { const char* e = getenv("SAT_EW_GRID_CAP"); cap = e ? atol(e) : 2048; if (cap < 1) cap = 2048; }
     long b = (n_items + EW_BLOCK - 1) / EW_BLOCK;
-    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));   // cap and grid-stride the rest
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));   // cap and grid-stride the rest
 }
 
 template <typename T> struct Vec;   // 16-byte vector of T
@@ -130,16 +133,19 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
     const long stride = (long)gridDim.x * blockDim.x;
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int cch = C / V;
-    if (stride % cch == 0) {
-        const int c0 = (int)(i0 % cch) * V;
+    // 32-bit index math in the prologue (a 64-bit modulo costs more than the whole streaming loop of a small tensor)
+    if (((unsigned)stride % (unsigned)cch) == 0) {
+        const int c0 = (int)((unsigned)i0 % (unsigned)cch) * V;
         float sc0[V], sh0[V], sc1[V], sh1[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            sc0[k] = s0[c0 + k]; sh0[k] = t0[c0 + k];
-            sc1[k] = (ADD && s1) ? s1[c0 + k] : 1.0f;
-            sh1[k] = (ADD && s1) ? t1[c0 + k] : 0.0f;
+        for (int k = 0; k < V; k += 4) {
+            const f32x4 a = *(const f32x4*)(s0 + c0 + k), b = *(const f32x4*)(t0 + c0 + k);
+            f32x4 c = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};
+            if (ADD && s1) { c = *(const f32x4*)(s1 + c0 + k); d = *(const f32x4*)(t1 + c0 + k); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc0[k + e] = a[e]; sh0[k + e] = b[e]; sc1[k + e] = c[e]; sh1[k + e] = d[e]; }
         }
-        constexpr int U = 4;                       // 4 (8 with ADD) independent 16-byte loads in flight per lane
+        constexpr int U = ADD ? 2 : 4;             // 4 independent 16-byte loads in flight per lane
         for (long i = i0; i < nchunks; i += stride * U) {
             float x[U][V], z[U][V];
 #pragma unroll
