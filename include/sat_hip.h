@@ -157,7 +157,14 @@ int sat_vocab_ce_fwd(const float* Hs, const float* w, const float* b, const int6
                      float* logits, float* row_loss, float* loss_out, sat_stream_t stream);
 /* backward of the projection given dlogits: dW[V,H], db[V], dHs[N,H] */
 int sat_vocab_ce_bwd(const float* dlogits /*[N,V]*/, const float* Hs, const float* w, int N, int H, int V,
-                     float* dw, float* db, float* dHs, sat_stream_t stream);
+                     float* dw, float* db, float* dHs, float* workspace, int64_t ws_bytes, sat_stream_t stream);
+int64_t sat_vocab_ce_bwd_ws_bytes(int N, int H, int V);
+/* split-K variant of sat_gemm_f32: K-steps dealt to ksplit slices, slice z writes C + z*slab_stride (bias in slice 0);
+ * sat_sum_slabs_f32 adds the slices in fixed order. */
+int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t lda, const float* B, int64_t ldb,
+                        float* C, int64_t ldc, const float* bias, const float* bias2, int M, int N, int K,
+                        int ksplit, int64_t slab_stride, sat_stream_t stream);
+int sat_sum_slabs_f32(const float* in, int nslab, int64_t slab_stride, int64_t n, float* out, sat_stream_t stream);
 /* greedy argmax of one decode step (models.py:61-63): ids[b*ids_stride] = first argmax_v (h[b] . w[v] + b[v]) */
 int sat_vocab_argmax(const float* h /*[B,H]*/, const float* w, const float* b, int B, int H, int V,
                      int64_t* ids, int64_t ids_stride, float* workspace, int64_t ws_bytes, sat_stream_t stream);

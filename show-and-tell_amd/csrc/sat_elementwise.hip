@@ -316,10 +316,39 @@ __global__ __launch_bounds__(256) void embed_concat_bwd_kernel(const float* __re
     int dup = 0;
     for (int i = threadIdx.x; i < row; i += blockDim.x) dup |= (tok[i] == v);
     if (__syncthreads_or(dup)) return;
+    // later occurrences of the same token: parallel scan, gathered as a bitmap so the sum order is by row index
+    __shared__ unsigned match_bits[1280];                  // 40960 rows
+    const int nwords = (Nrows + 31) >> 5;
+    const bool fits = nwords <= 1280;
+    int any = 0;
+    if (fits) {
+        for (int w = threadIdx.x; w < nwords; w += blockDim.x) {
+            unsigned bits = 0u;
+            const int base = w << 5;
+            for (int b = 0; b < 32; ++b) {
+                const int i = base + b;
+                if (i > row && i < Nrows && tok[i] == v) bits |= 1u << b;
+            }
+            match_bits[w] = bits;
+            any |= (bits != 0u);
+        }
+    }
+    any = __syncthreads_or(any);
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        float acc = 0.0f;
-        for (int i = row; i < Nrows; ++i)
-            if (tok[i] == v) acc += dX[(long)i * E + e];
+        float acc = dX[(long)row * E + e];
+        if (!fits) {
+            for (int i = row + 1; i < Nrows; ++i)
+                if (tok[i] == v) acc += dX[(long)i * E + e];
+        } else if (any) {
+            for (int w = row >> 5; w < nwords; ++w) {
+                unsigned bits = match_bits[w];
+                while (bits) {
+                    const int b = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    acc += dX[(long)((w << 5) + b) * E + e];
+                }
+            }
+        }
         d_embed[(long)v * E + e] = acc;
     }
 }
@@ -381,8 +410,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s = 0.0f;
-    if (c < cols)
-        for (int r = rg; r < rows; r += 8) s += x[(long)r * ld + c];
+    if (c < cols) {
+        int r = rg;
+        for (; r + 24 < rows; r += 32) {          // 4 independent loads in flight; the add order stays fixed
+            const float a0 = x[(long)r * ld + c], a1 = x[(long)(r + 8) * ld + c];
+            const float a2 = x[(long)(r + 16) * ld + c], a3 = x[(long)(r + 24) * ld + c];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; r < rows; r += 8) s += x[(long)r * ld + c];
+    }
     sh[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && c < cols) {
@@ -791,6 +827,25 @@ extern "C" int sat_pack_targets(const int64_t* captions, int64_t cap_stride, con
     if (!captions || !prefix || !targets || T < 1 || N < 1) return SAT_ERR_ARG;
     hipLaunchKernelGGL(pack_targets_kernel, dim3(sat_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, captions,
                        (long)cap_stride, prefix, T, N, targets);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+// out[i] = sum_z in[z*slab_stride + i] (fixed order): combines split-K partial slabs
+namespace {
+__global__ void sum_slabs_kernel(const float* __restrict__ in, int nslab, long slab_stride, long n4, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 acc = ((const f32x4*)in)[i];
+        for (int z = 1; z < nslab; ++z) acc += ((const f32x4*)(in + (long)z * slab_stride))[i];
+        ((f32x4*)out)[i] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int sat_sum_slabs_f32(const float* in, int nslab, int64_t slab_stride, int64_t n, float* out, sat_stream_t stream) {
+    if (!in || !out || nslab < 1 || n < 1 || (n & 3) || (slab_stride & 3)) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(ew_grid(n / 4)), dim3(EW_BLOCK), 0, (hipStream_t)stream, in, nslab,
+                       (long)slab_stride, (long)(n / 4), out);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }

@@ -35,6 +35,8 @@ struct GemmArgs {
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
     long sN, sH, sW;
     int tiles_n;
+    int ksplit;          // gridDim.y: K-steps are dealt to ksplit slices, slice z writes C + z*slab_stride
+    long slab_stride;
 };
 
 template <typename T> struct Frag;
@@ -195,9 +197,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kz = blockIdx.y;
+    const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+    const int kt0 = kz * per;
+    const int nk = (kt0 + per < nk_all) ? kt0 + per : nk_all;
+    if (kt0 < nk) load_tiles(kt0);
+    for (int kt = kt0; kt < nk; ++kt) {
         store_tiles();
         __syncthreads();
         if (kt + 1 < nk) load_tiles(kt + 1);   // global loads in flight under the MFMAs below
@@ -257,12 +263,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
-    T* __restrict__ Cg = (T*)p.C;
+    T* __restrict__ Cg = (T*)p.C + (long)kz * p.slab_stride;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WN + j * 32 + r;
         float badd = 0.0f;
-        if (col < p.N) {
+        if (col < p.N && kz == 0) {
             if (p.bias) badd += p.bias[col];
             if (p.bias2) badd += p.bias2[col];
         }
@@ -312,7 +318,8 @@ template <typename T, int BM, int BN, int AMODE, int BMODE>
 int launch(GemmArgs& a, hipStream_t s) {
     const int tm = sat_cdiv(a.M, BM), tn = sat_cdiv(a.N, BN);
     a.tiles_n = tn;
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AMODE, BMODE>), dim3(tm * tn), dim3(256), 0, s, a);
+    if (a.ksplit < 1) a.ksplit = 1;
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AMODE, BMODE>), dim3(tm * tn, a.ksplit), dim3(256), 0, s, a);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
@@ -320,8 +327,9 @@ int launch(GemmArgs& a, hipStream_t s) {
 template <int AMODE, int BMODE>
 int launch_f32_auto(GemmArgs& a, hipStream_t s) {
     // fill the 256 CUs: fall to smaller tiles when the big ones leave most of the chip idle
-    const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
-    const long t12864 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 64);
+    const int ks = a.ksplit < 1 ? 1 : a.ksplit;
+    const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128) * ks;
+    const long t12864 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 64) * ks;
     if (t128 >= 384) return launch<float, 128, 128, AMODE, BMODE>(a, s);
     if (t12864 >= 384) return launch<float, 128, 64, AMODE, BMODE>(a, s);
     return launch<float, 64, 64, AMODE, BMODE>(a, s);
@@ -331,9 +339,20 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
+extern "C" int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                   float* C, int64_t ldc, const float* bias, const float* bias2, int M, int N, int K,
+                                   int ksplit, int64_t slab_stride, sat_stream_t stream);
+
 extern "C" int sat_gemm_f32(int amode, int bmode, const float* A, int64_t lda, const float* B, int64_t ldb,
                             float* C, int64_t ldc, const float* bias, const float* bias2,
                             int M, int N, int K, sat_stream_t stream) {
+    return sat_gemm_f32_splitk(amode, bmode, A, lda, B, ldb, C, ldc, bias, bias2, M, N, K, 1, 0, stream);
+}
+
+extern "C" int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                   float* C, int64_t ldc, const float* bias, const float* bias2, int M, int N, int K,
+                                   int ksplit, int64_t slab_stride, sat_stream_t stream) {
+    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && slab_stride < (int64_t)M * ldc)) return SAT_ERR_ARG;
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return SAT_ERR_ARG;
     if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3)) return SAT_ERR_ARG;
     if ((amode == 0 || bmode == 0) && (K & 3)) return SAT_ERR_ARG;   // 16-byte chunks run along K
@@ -342,6 +361,7 @@ extern "C" int sat_gemm_f32(int amode, int bmode, const float* A, int64_t lda, c
     GemmArgs a = {};
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.bias2 = bias2; a.stat_partial = nullptr;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.ksplit = ksplit; a.slab_stride = slab_stride;
     hipStream_t s = (hipStream_t)stream;
     if (amode == 0 && bmode == 0) return launch_f32_auto<AM_ROW, BMODE_NT>(a, s);
     if (amode == 0 && bmode == 1) return launch_f32_auto<AM_ROW, BMODE_KM>(a, s);

@@ -187,12 +187,37 @@ extern "C" int sat_vocab_ce_fwd(const float* Hs, const float* w, const float* b,
     return sat_ce_rows(logits, targets, N, V, inv_denom, write_grad, row_loss, loss_out, stream);
 }
 
+static int vocab_bwd_split(int N, int H, int V) {
+    // dHs[N,H] = dlogits[N,V] * W[V,H]: K = V is long and M*N small -> deal K over enough slices to fill the chip
+    const long tiles = (long)sat_cdiv(N, 64) * sat_cdiv(H, 64);
+    int ks = (int)(512 / (tiles > 0 ? tiles : 1));
+    const int nk = sat_cdiv(V, 32);
+    if (ks > nk / 8) ks = nk / 8;
+    return ks < 1 ? 1 : (ks > 16 ? 16 : ks);
+}
+
+extern "C" int64_t sat_vocab_ce_bwd_ws_bytes(int N, int H, int V) {
+    const int ks = vocab_bwd_split(N, H, V);
+    return ks > 1 ? (int64_t)ks * N * H * sizeof(float) : 0;
+}
+
+extern "C" int sat_sum_slabs_f32(const float* in, int nslab, int64_t slab_stride, int64_t n, float* out, sat_stream_t stream);
+extern "C" int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                   float* C, int64_t ldc, const float* bias, const float* bias2, int M, int N, int K,
+                                   int ksplit, int64_t slab_stride, sat_stream_t stream);
+
 extern "C" int sat_vocab_ce_bwd(const float* dlogits, const float* Hs, const float* w, int N, int H, int V,
-                                float* dw, float* db, float* dHs, sat_stream_t stream) {
+                                float* dw, float* db, float* dHs, float* workspace, int64_t ws_bytes,
+                                sat_stream_t stream) {
     if (!dlogits || !Hs || !w || !dw || !db || !dHs) return SAT_ERR_ARG;
     if ((V & 3) || (H & 3)) return SAT_ERR_UNSUPPORTED;
+    const int ks = vocab_bwd_split(N, H, V);
+    if (ks > 1 && (!workspace || ws_bytes < sat_vocab_ce_bwd_ws_bytes(N, H, V))) return SAT_ERR_WORKSPACE;
     // dW[V,H] = dlogits^T * Hs ;  db = colsum(dlogits) ;  dHs[N,H] = dlogits * W
     SAT_TRY(sat_gemm_f32(2, 1, dlogits, V, Hs, H, dw, H, nullptr, nullptr, V, H, N, stream));
     SAT_TRY(sat_colsum_f32(dlogits, V, N, V, db, stream));
-    return sat_gemm_f32(0, 1, dlogits, V, w, H, dHs, H, nullptr, nullptr, N, H, V, stream);
+    if (ks == 1) return sat_gemm_f32(0, 1, dlogits, V, w, H, dHs, H, nullptr, nullptr, N, H, V, stream);
+    SAT_TRY(sat_gemm_f32_splitk(0, 1, dlogits, V, w, H, workspace, H, nullptr, nullptr, N, H, V, ks, (int64_t)N * H, stream));
+    if (((long)N * H) & 3) return SAT_ERR_UNSUPPORTED;
+    return sat_sum_slabs_f32(workspace, ks, (int64_t)N * H, (int64_t)N * H, dHs, stream);
 }

@@ -106,6 +106,19 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const SkinnyArgs p) {
         wrow_ok = wrow < p.N;
     }
 
+    // EPI_LSTM: the epilogue's own operands (x-gates, c_{t-1}) are fetched now, under the K loop
+    float pre_xg[4] = {0.f, 0.f, 0.f, 0.f}, pre_c = 0.f;
+    if constexpr (EPI == EPI_LSTM) {
+        const int prow = rc0 + (tid >> 2), pj = cg * 4 + (tid & 3);
+        if (tid < 256 && prow < p.M && pj < p.N) {
+            pre_c = p.c_state[(long)prow * p.N + pj];
+            if (p.xg) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre_xg[g] = p.xg[(long)prow * p.ldxg + (long)g * p.N + pj];
+            }
+        }
+    }
+
     f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -154,13 +167,13 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const SkinnyArgs p) {
 #pragma unroll
                 for (int w = 0; w < NWV; ++w) s += red[w][row][g * 4 + q];
                 const long wr = (long)g * H + j;
-                if (p.xg) s += p.xg[(long)grow * p.ldxg + wr];
+                s += pre_xg[g];
                 if (p.bias) s += p.bias[wr];
                 if (p.bias2) s += p.bias2[wr];
                 g4[g] = s;
             }
             const float gi = sat_sigmoid(g4[0]), gf = sat_sigmoid(g4[1]), gg = sat_tanh(g4[2]), go = sat_sigmoid(g4[3]);
-            const float c_prev = p.c_state[(long)grow * H + j];
+            const float c_prev = pre_c;
             const float c_new = gf * c_prev + gi * gg;
             const float h_new = go * sat_tanh(c_new);
             p.c_state[(long)grow * H + j] = c_new;

@@ -211,8 +211,10 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
     V, Hl = lin_w.shape
     Xtop = tapes["X"][-1]
     dH = torch.empty(N, Hl, device=dev)
+    vwsb = lib.sat_vocab_ce_bwd_ws_bytes(N, Hl, V)
+    vws = torch.empty(max(vwsb // 4, 4), device=dev)
     L.check(lib.sat_vocab_ce_bwd(L.ptr(dlogits), L.ptr(Xtop), L.ptr(lin_w), N, Hl, V, L.ptr(grads_out["lin_w"]),
-                                 L.ptr(grads_out["lin_b"]), L.ptr(dH), st), "sat_vocab_ce_bwd")
+                                 L.ptr(grads_out["lin_b"]), L.ptr(dH), L.ptr(vws), vwsb, st), "sat_vocab_ce_bwd")
     if on_stage is not None:
         on_stage(0)
     for l in reversed(range(len(lstm_layers))):
