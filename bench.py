@@ -144,7 +144,7 @@ def main():
                        "global_batch": world * CFG["batch"], "parallelism": "dp%d" % world,
                        "precision": "conv stack bf16 MFMA / f32 accumulate; head, LSTM, vocab, CE, Adam f32 (exact-f32 MFMA)",
                        "final_loss": round(final_loss, 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16,128,{128|64},conv,nt> (implicit-GEMM conv, %d launches/step)" % n_conv,
+            "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel<BN,S,NW,UNIFORM> (bf16 implicit-GEMM conv, %d launches/step, variants autotuned per geometry)" % n_conv,
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step_in_kernel": round(conv_ms, 3)},
