@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 1
+#define SAT_ABI_VERSION 2
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -86,6 +86,11 @@ typedef struct sat_op {
     float momentum, eps;
     int32_t variant;          /* SAT_OP_CONV: 0 = built-in heuristic, >0 = kernel variant chosen by sat_conv_autotune */
     int32_t reserved;
+    /* SAT_OP_CONV, bf16, training: fused BatchNorm finalize.  stat_acc = int64 [4][2][Cout] fixed-point column sums
+     * (zero before first use; the kernel clears them), stat_ticket = int32 workgroup counter (zero).  The conv then
+     * also needs gamma/beta/(running_*)/scale_out/shift_out/count/momentum/eps and no SAT_OP_BN_FINALIZE follows. */
+    void* stat_acc;
+    int32_t* stat_ticket;
 } sat_op;
 
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);

@@ -30,6 +30,7 @@ class SatOp(C.Structure):
         ("sN", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64), ("count", C.c_int64),
         ("momentum", C.c_float), ("eps", C.c_float),
         ("variant", C.c_int32), ("reserved", C.c_int32),
+        ("stat_acc", _vp), ("stat_ticket", _vp),
     ]
 
 
@@ -85,7 +86,7 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.sat_version() != 1:
+        if lib.sat_version() != 2:
             raise RuntimeError("libsat_hip.so ABI version mismatch")
         _lib = lib
     return _lib

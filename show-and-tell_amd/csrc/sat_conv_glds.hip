@@ -34,7 +34,21 @@ struct ConvArgs {
     long sN, sH, sW;
     int tiles_n;
     int linear;     // 1x1 / stride 1 / no padding on a dense NHWC tensor: output row m reads input pixel m
+    // fused BatchNorm finalize (training): fixed-point column sums accumulated with 64-bit integer atomics
+    // (integer addition is associative => bitwise reproducible whatever the arrival order), the LAST workgroup
+    // of the launch (ticket) turns them into scale/shift, updates the running statistics and clears them.
+    long long* acc;          // [4 buckets][2][N]
+    int* ticket;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;     // may be NULL (no running update)
+    float* running_var;
+    float* scale_out;
+    float* shift_out;
+    double count;
+    float momentum, eps;
 };
+constexpr double kStatScale = 4194304.0;   // 2^22 fixed point
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
 
     // ---- epilogue 1: BatchNorm partial column sums from the f32 accumulators ----
     float* red = (float*)(smem + BM * CROW);     // [WGM][2][BN] floats, placed after the C tile
-    if (p.stat_partial) {
+    if (p.stat_partial || p.acc) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s = 0.0f, q = 0.0f;
@@ -289,6 +303,22 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             }
         }
     }
+    if (p.acc) {
+        for (int c = tid; c < BN; c += NT) {
+            const int col = n0 + c;
+            if (col < p.N) {
+                float s = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int g = 0; g < WGM; ++g) {
+                    s += red[(g * 2 + 0) * BN + c];
+                    q += red[(g * 2 + 1) * BN + c];
+                }
+                long long* a0 = p.acc + ((long)(tile_m & 3) * 2) * p.N + col;
+                atomicAdd((unsigned long long*)a0, (unsigned long long)__double2ll_rn((double)s * kStatScale));
+                atomicAdd((unsigned long long*)(a0 + p.N), (unsigned long long)__double2ll_rn((double)q * kStatScale));
+            }
+        }
+    }
     constexpr int CPR = BN / 8;                  // 16-byte chunks per C row
 #pragma unroll
     for (int it = 0; it < BM * CPR / NT; ++it) {
@@ -297,6 +327,40 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         const int grow = m0 + row, gcol = n0 + cc * 8;
         if (grow < p.M && gcol < p.N)             // N % 8 == 0: a chunk is all in or all out
             *(u32x4*)(p.C + (long)grow * p.ldc + gcol) = *(const u32x4*)(smem + row * CROW + cc * 16);
+    }
+    if (p.acc) {
+        // every wave: its atomics (and stores) are performed before the workgroup takes its ticket
+        wait_vmcnt<0>();
+        __syncthreads();
+        int* flag = (int*)(smem + BM * CROW + 4 * WGM * BN * 4 - 16);      // inside the stat scratch, past `red`
+        if (tid == 0) {
+            const int t = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = (t == (int)gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*flag) {
+            for (int c = tid; c < p.N; c += NT) {
+                long long sumS = 0, sumQ = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {                // read-and-clear at the memory side (coherent across XCDs)
+                    sumS += (long long)atomicExch((unsigned long long*)(p.acc + ((long)b * 2 + 0) * p.N + c), 0ull);
+                    sumQ += (long long)atomicExch((unsigned long long*)(p.acc + ((long)b * 2 + 1) * p.N + c), 0ull);
+                }
+                const double mean = (double)sumS / kStatScale / p.count;
+                double var = (double)sumQ / kStatScale / p.count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                if (p.running_mean) {
+                    const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+                    p.running_mean[c] = (float)((1.0 - p.momentum) * p.running_mean[c] + p.momentum * mean);
+                    p.running_var[c] = (float)((1.0 - p.momentum) * p.running_var[c] + p.momentum * unbiased);
+                }
+                const float invstd = 1.0f / sqrtf((float)var + p.eps);
+                const float sc = p.gamma[c] * invstd;
+                p.scale_out[c] = sc;
+                p.shift_out[c] = p.beta[c] - (float)mean * sc;
+            }
+            if (tid == 0) atomicExch(p.ticket, 0);
+        }
     }
 }
 
@@ -339,6 +403,10 @@ ConvArgs make_args(const sat_op* op) {
     ConvArgs a = {};
     a.A = (const bf16_t*)op->in0; a.B = (const bf16_t*)op->w; a.C = (bf16_t*)op->out;
     a.stat_partial = op->stat_partial;
+    a.acc = (long long*)op->stat_acc; a.ticket = op->stat_ticket;
+    a.gamma = op->gamma; a.beta = op->beta; a.running_mean = op->running_mean; a.running_var = op->running_var;
+    a.scale_out = op->scale_out; a.shift_out = op->shift_out;
+    a.count = (double)op->count; a.momentum = op->momentum; a.eps = op->eps;
     a.M = op->N * op->Hout * op->Wout; a.N = op->Cout; a.K = op->KH * op->KW * op->Cin;
     a.ldb = a.K; a.ldc = op->Cout;
     a.Hin = op->Hin; a.Win = op->Win; a.Cin = op->Cin; a.Hout = op->Hout; a.Wout = op->Wout;
@@ -363,6 +431,8 @@ int heuristic_variant(const ConvArgs& a) {
 // bf16 SAT_OP_CONV; arguments already validated by sat_conv_launch
 int sat_conv_glds_launch(const sat_op* op, hipStream_t s) {
     if (op->Cout % 8) return SAT_ERR_UNSUPPORTED;
+    if (op->stat_acc && (!op->stat_ticket || !op->gamma || !op->beta || !op->scale_out || !op->shift_out || op->count < 1))
+        return SAT_ERR_ARG;
     ConvArgs a = make_args(op);
     const int v = (op->variant > 0 && op->variant <= kNumVariants) ? op->variant - 1 : heuristic_variant(a);
     return launch_variant(v, a, s);
@@ -385,10 +455,11 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
         sat_op* op = ops + i;
         if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) continue;
         const Key key(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
-                      op->stat_partial ? 1 : 0);
+                      (op->stat_partial || op->stat_acc) ? 1 : 0);
         auto it = cache.find(key);
         if (it != cache.end()) { op->variant = it->second; continue; }
         ConvArgs a = make_args(op);
+        a.acc = nullptr;             // tuning launches must not touch the statistics / running buffers
         float best = 1e30f;
         int best_v = heuristic_variant(a);
         for (int v = 0; v < kNumVariants; ++v) {

@@ -201,8 +201,28 @@ class ConvStackProgram:
                 o.tiles_m = L.load().sat_conv_tiles_m(n * hout * wout)
             return o
 
+        fused_fin = training and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSED_BN_FINALIZE", "0") == "1"
+        if fused_fin:
+            # fixed-point column sums [bn][4 buckets][2][C] + one ticket per BN: the conv kernel's last workgroup
+            # finalizes (no SAT_OP_BN_FINALIZE launch)
+            self.stat_acc = alloc((nbn, 4, 2, cmax), torch.int64, zero=True)
+            self.stat_ticket = alloc((nbn,), torch.int32, zero=True)
+
         def fin_op(bn, c, count, tiles_m):
             s, t = new_scale_shift(c)
+            if fused_fin:
+                i = bn_idx[0] - 1
+                cv = ops[-1]                       # the conv that produces this BN's input
+                assert cv.kind == L.OP_CONV and cv.Cout == c
+                cv.stat_partial = None
+                cv.stat_acc = self.stat_acc[i].data_ptr()
+                cv.stat_ticket = self.stat_ticket[i:i + 1].data_ptr()
+                cv.gamma, cv.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                cv.running_mean, cv.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                cv.scale_out, cv.shift_out = s.data_ptr(), t.data_ptr()
+                cv.count, cv.momentum, cv.eps = count, BN_MOMENTUM, BN_EPS
+                self.bn_list.append(bn)
+                return None, s, t
             o = L.SatOp()
             o.kind, o.dtype = L.OP_BN_FINALIZE, dtype
             o.stat_partial = self.partial.data_ptr() if training else None
@@ -233,6 +253,10 @@ class ConvStackProgram:
             return conv_op(x, wt, out, n, hin, win, cin, hout, wout, conv.cout, conv.k, conv.k, conv.stride, conv.pad,
                            hin * win * cin, win * cin, cin)
 
+        def add(o):
+            if o is not None:
+                ops.append(o)
+
         # ---- program ----
         o = L.SatOp()
         o.kind, o.dtype = L.OP_IMAGE_PREP, dtype
@@ -242,7 +266,7 @@ class ConvStackProgram:
         self._prep_index = 0
         ops.append(conv_op(self.img_pad, wst, self.c0, N, Hp, Wp, 32, Ho, Wo, width, 7, 1, 2, 0, Hp * Wp * 4, Wp * 4, 4))
         f, s, t = fin_op(stack.bn1, width, N * Ho * Wo, L.load().sat_conv_tiles_m(N * Ho * Wo))
-        ops.append(f)
+        add(f)
         y, ynext = self.ybuf
         mp = L.SatOp()
         mp.kind, mp.dtype = L.OP_BN_RELU_MAXPOOL, dtype
@@ -254,19 +278,19 @@ class ConvStackProgram:
             tm2 = L.load().sat_conv_tiles_m(N * h2 * w2)
             ops.append(std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_))
             f, s1, t1 = fin_op(blk.bn1, planes, N * h * w_, tm1)
-            ops.append(f)
+            add(f)
             ops.append(act_op(L.OP_BN_RELU, self.c1, s1, t1, self.a1, N, h, w_, planes))
             ops.append(std_conv(blk.conv2, self.a1, self.c2, N, h, w_, h2, w2))
             f, s2, t2 = fin_op(blk.bn2, planes, N * h2 * w2, tm2)
-            ops.append(f)
+            add(f)
             ops.append(act_op(L.OP_BN_RELU, self.c2, s2, t2, self.a2, N, h2, w2, planes))
             ops.append(std_conv(blk.conv3, self.a2, self.c3, N, h2, w2, h2, w2))
             f, s3, t3 = fin_op(blk.bn3, planes * 4, N * h2 * w2, tm2)
-            ops.append(f)
+            add(f)
             if blk.downsample is not None:
                 ops.append(std_conv(blk.downsample[0], y, self.cd, N, h, w_, h2, w2))
                 f, sd, td_ = fin_op(blk.downsample[1], planes * 4, N * h2 * w2, tm2)
-                ops.append(f)
+                add(f)
                 ops.append(act_op(L.OP_BN_ADD_RELU, self.c3, s3, t3, ynext, N, h2, w2, planes * 4, self.cd, sd, td_))
             else:
                 ops.append(act_op(L.OP_BN_ADD_RELU, self.c3, s3, t3, ynext, N, h2, w2, planes * 4, y))

@@ -347,3 +347,41 @@ def test_fc_bn1d_fwd_bwd(lib):
     # d(fc.bias) = sum_b dz is mathematically ZERO under train-mode BatchNorm: both sides hold rounding noise of size
     # ~1e-7 * sum_b |dz| (|dz| is O(10) here), so only its smallness can be compared
     assert db.cpu().abs().max().item() < 5e-4 and gr["resnet.fc.bias"].abs().max().item() < 5e-4
+
+
+@pytest.mark.parametrize("variant", [0, 2, 5, 9])
+def test_conv_bf16_fused_bn_finalize(lib, variant):
+    """bf16 conv with the fused BatchNorm finalize (fixed-point integer atomics + last-workgroup ticket): scale/shift,
+    running statistics, self-clearing accumulators, bitwise reproducibility across launches"""
+    N, H, W, Cin, Cout, k, stride, pad = 6, 20, 20, 64, 192, 3, 1, 1
+    g = torch.Generator().manual_seed(91)
+    x = (torch.randn(N, Cin, H, W, generator=g) + 0.3).bfloat16().float()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16().float()
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+    M = ref.shape[0]
+    o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), stride, pad, stats=False)
+    acc = torch.zeros(4, 2, Cout, dtype=torch.int64, device="cuda")
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gd, bd = cu(gamma), cu(beta)
+    rm, rv = cu(torch.zeros(Cout)), cu(torch.ones(Cout))
+    sc, sh = torch.full((Cout,), float("nan"), device="cuda"), torch.full((Cout,), float("nan"), device="cuda")
+    o.variant = variant
+    o.stat_acc, o.stat_ticket = acc.data_ptr(), ticket.data_ptr()
+    o.gamma, o.beta, o.running_mean, o.running_var = gd.data_ptr(), bd.data_ptr(), rm.data_ptr(), rv.data_ptr()
+    o.scale_out, o.shift_out, o.count, o.momentum, o.eps = sc.data_ptr(), sh.data_ptr(), M, 0.1, 1e-5
+    L.check(lib.sat_run_ops(C.pointer(o), 1, st()))
+    sync()
+    mean, var = ref.mean(0), ref.var(0, unbiased=False)
+    scale = gamma.double() / torch.sqrt(var + 1e-5)
+    np.testing.assert_allclose(sc.cpu().numpy(), scale.numpy(), rtol=2e-4)
+    np.testing.assert_allclose(sh.cpu().numpy(), (beta.double() - mean * scale).numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * var * M / (M - 1)).numpy(), rtol=1e-3)
+    assert int(acc.abs().sum()) == 0 and int(ticket[0]) == 0           # cleared for the next step by the last workgroup
+    sc1, sh1 = sc.clone(), sh.clone()
+    for _ in range(3):                                                 # arrival order varies, the integer sums do not
+        L.check(lib.sat_run_ops(C.pointer(o), 1, st()))
+    sync()
+    assert torch.equal(sc, sc1) and torch.equal(sh, sh1)
+    assert (keep[2].float().cpu().double() - ref).abs().max().item() < 2e-2
