@@ -152,7 +152,12 @@ def main():
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step_in_kernel": round(conv_ms, 3)},
         }
-        if not args.no_cpu_baseline:
+        traffic_file = os.path.join(ROOT, "profiles", "r01_c_conv_pmc_traffic.json")
+        if os.path.exists(traffic_file):      # HBM bytes per conv launch from the separate rocprofv3 --pmc passes (run_gpu_pmc.sh)
+            with open(traffic_file) as f:
+                out["roofline"]["traffic"] = round(json.load(f)["hbm_bytes_per_launch_corrected"])
+                out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c_conv_pmc_traffic.json)"
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(123)
         print(json.dumps(out), flush=True)
     if world > 1:

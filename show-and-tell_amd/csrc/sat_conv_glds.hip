@@ -145,6 +145,13 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         b_ptr[i] = b_ok[i] ? p.B + ((long)gn * p.ldb + b_c[i]) : zero;
     }
     const int nk = (p.K + BK - 1) / BK;
+    // linear (1x1) walk: per-lane pointers advance by one K-step; invalid rows stay on the zero word
+    int a_step[NAI], b_step[NBI];
+    const bf16_t* b_walk[NBI];
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) a_step[i] = (m0 + wave * (NAI * 8) + i * 8 + (lane >> 3) < p.M) ? BK : 0;
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) { b_walk[i] = b_ptr[i]; b_step[i] = b_ok[i] ? BK : 0; }
 
     // scalar walk of the K axis for the UNIFORM path (no division in the loop)
     int is_kt = 0, is_tap = 0, is_cb = 0, is_kh = 0, is_kw = 0;
@@ -155,6 +162,32 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         const int kt = is_kt;
         const bool live = kt < nk;                       // beyond the K range: zero-source dummies keep counts uniform
         if constexpr (UNIFORM) {
+            if (!live) {                                   // uniform: the ring's trailing dummy stages
+#pragma unroll
+                for (int i = 0; i < NAI; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sA + (wave * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NBI; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sB + (wave * (NBI * 8) + i * 8) * 128), 16, 0, 0);
+                ++is_kt;
+                return;
+            }
+            if (p.linear) {
+                // 1x1 / stride 1 / no padding: no taps, no bounds -- the per-lane pointers just walk K.
+                // (rows past M and columns past N hold the zero word with a zero stride.)
+#pragma unroll
+                for (int i = 0; i < NAI; ++i) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[i], (lptr_t)(sA + (wave * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+                    a_ptr[i] += a_step[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NBI; ++i) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)b_walk[i], (lptr_t)(sB + (wave * (NBI * 8) + i * 8) * 128), 16, 0, 0);
+                    b_walk[i] += b_step[i];
+                }
+                ++is_kt;
+                return;
+            }
             const long tapoff = (long)is_kh * p.sH + (long)is_kw * p.sW + is_cb;
 #pragma unroll
             for (int i = 0; i < NAI; ++i) {
@@ -223,6 +256,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
 #pragma unroll
     for (int s = 0; s < D; ++s) issue(s);
 
+    // (unrolling this loop over the ring to make stage offsets LDS immediates was measured: slower -- code size)
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's pieces of K-step kt have landed once all but the (D-1) younger K-steps are done ...
@@ -375,6 +409,11 @@ int launch_glds(ConvArgs& a, hipStream_t s) {
     return SAT_OK;
 }
 
+int tune_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 // kernel variants: (tile width, ring stages, waves).  LDS = S * (16 + BN/8) KB decides workgroups per CU.
 struct Variant { int bn, s, nw; };
 constexpr Variant kVariants[] = {
@@ -414,6 +453,8 @@ ConvArgs make_args(const sat_op* op) {
     a.sN = op->sN; a.sH = op->sH; a.sW = op->sW;
     a.linear = (op->KH == 1 && op->KW == 1 && op->stride == 1 && op->pad == 0 && op->Hout == op->Hin &&
                 op->Wout == op->Win && op->sH == (long)op->Win * op->sW && op->sN == (long)op->Hin * op->sH) ? 1 : 0;
+    static const int no_linear = tune_env("SAT_CONV_NO_LINEAR", 0);
+    if (no_linear) a.linear = 0;
     return a;
 }
 
@@ -465,13 +506,13 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
         for (int v = 0; v < kNumVariants; ++v) {
             if (kVariants[v].bn == 128 && a.N <= 64) continue;
             float tmin = 1e30f;
-            for (int round = 0; round < 2 && rc == SAT_OK; ++round) {       // round 0 = warm-up
+            for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
                 if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
                 for (int r = 0; r < reps && rc == SAT_OK; ++r) rc = launch_variant(v, a, s);
                 if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
                 float ms = 0.f;
                 hipEventElapsedTime(&ms, e0, e1);
-                if (round == 1) tmin = ms / reps;
+                if (round >= 1 && ms / reps < tmin) tmin = ms / reps;
             }
             if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d v%d(%d,%d,%d) %.2f us\n", a.M, a.N, a.K, v, kVariants[v].bn,
                                  kVariants[v].s, kVariants[v].nw, tmin * 1e3f);

@@ -307,7 +307,7 @@ class ConvStackProgram:
         if dtype == L.SAT_BF16 and os.environ.get("SAT_AUTOTUNE", "1") != "0" and torch.device(device).type == "cuda":
             for t in (self.c0, self.c1, self.a1, self.c2, self.a2, self.c3, self.cd, *self.ybuf):
                 t.normal_()
-            L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 3, L.stream()), "sat_conv_autotune")
+            L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 5, L.stream()), "sat_conv_autotune")
             torch.cuda.synchronize()
 
     def run(self, images):

@@ -53,3 +53,35 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "add"
     if what == "add":
         bench_add(offsets=(0, 4096 + 256, 32768 + 2048))
+
+
+def bench_conv(shapes=None, reps=20):
+    """layer-3 conv geometries of ResNet-152 at batch 64 (the bulk of the step), autotuned variant"""
+    shapes = shapes or [(64, 14, 14, 1024, 256, 1, 1, 0), (64, 14, 14, 256, 256, 3, 1, 1), (64, 14, 14, 256, 1024, 1, 1, 0)]
+    lib = L.load()
+    for (N, H, W, Cin, Cout, k, stride, pad) in shapes:
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        x = torch.randn(N, H, W, Cin, device="cuda").bfloat16()
+        w = (torch.randn(Cout, k * k * Cin, device="cuda") / (Cin * k * k) ** 0.5).bfloat16()
+        out = torch.empty(N * Ho * Wo, Cout, device="cuda", dtype=torch.bfloat16)
+        tiles = lib.sat_conv_tiles_m(N * Ho * Wo)
+        part = torch.empty(tiles, 2, Cout, device="cuda")
+        o = L.SatOp()
+        o.kind, o.dtype = L.OP_CONV, L.SAT_BF16
+        o.in0, o.w, o.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+        o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, Ho, Wo, Cout
+        o.KH, o.KW, o.stride, o.pad = k, k, stride, pad
+        o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
+        o.stat_partial, o.tiles_m = part.data_ptr(), tiles
+        ops = (L.SatOp * 1)(o)
+        if os.environ.get("SAT_VARIANT"):
+            ops[0].variant = int(os.environ["SAT_VARIANT"])
+        else:
+            L.check(lib.sat_conv_autotune(ops, 1, 5, L.stream()))
+        us = time_ops(ops, 1, reps)
+        fl = 2.0 * N * Ho * Wo * Cout * k * k * Cin
+        print("conv M=%d N=%d K=%d variant %d: %.1f us  %.0f TFLOP/s" % (N * Ho * Wo, Cout, k * k * Cin, ops[0].variant, us, fl / us / 1e6))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "conv":
+    bench_conv()
