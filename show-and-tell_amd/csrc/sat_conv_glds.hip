@@ -47,6 +47,7 @@ struct ConvArgs {
     float* shift_out;
     double count;
     float momentum, eps;
+    int dbg;                 // diagnostics only (SAT_CONV_DBG): 1 = no loads, 2 = no MFMA, 4 = no epilogue
 };
 constexpr double kStatScale = 4194304.0;   // 2^22 fixed point
 
@@ -67,16 +68,21 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
 
-// BN: tile width (128/64); S: ring stages; NW: waves (4/8); UNIFORM: Cin % 64 == 0 (a K-step never straddles a tap)
-template <int BN, int S, int NW, bool UNIFORM>
+// BN: tile width (128/64); S: ring stages; NW: waves (4/8); UNIFORM: Cin % 64 == 0 (a K-step never straddles a tap);
+// SPEC: wave specialisation -- waves 0..NW/2-1 own the accumulators (ds_read + MFMA only), waves NW/2..NW-1 only
+// issue the LDS-DMA (address walk + global_load_lds).  Each SIMD then holds one consumer and one loader, whose
+// instruction streams are complementary (matrix pipe vs memory issue) instead of two lock-stepped copies.
+template <int BN, int S, int NW, bool UNIFORM, bool SPEC = false>
 __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     constexpr int BM = 128, BK = 64, NT = NW * 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    // wave grid: NW=4: 2x2;  NW=8: 2(M)x4(N) for BN=128, 4(M)x2(N) for BN=64
-    constexpr int WGM = (NW == 4) ? 2 : (BN == 128 ? 2 : 4);
-    constexpr int WGN = NW / WGM;
+    constexpr int LW = SPEC ? NW / 2 : NW;                // waves that issue the LDS-DMA
+    constexpr int CW = SPEC ? NW / 2 : NW;                // waves that own accumulators
+    // consumer wave grid: 4 waves: 2x2;  8 waves: 2(M)x4(N) for BN=128, 4(M)x2(N) for BN=64
+    constexpr int WGM = (CW == 4) ? 2 : (BN == 128 ? 2 : 4);
+    constexpr int WGN = CW / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
-    constexpr int NAI = BM / 8 / NW, NBI = BN / 8 / NW;   // LDS-DMA pieces (8 rows x 128 B) per wave per stage
+    constexpr int NAI = BM / 8 / LW, NBI = BN / 8 / LW;   // LDS-DMA pieces (8 rows x 128 B) per loader wave per stage
     constexpr int LPW = NAI + NBI;
     constexpr int D = S - 1;                               // K-steps kept in flight
     constexpr int CROW = BN * 2 + 16;                      // bf16 C-tile row stride in LDS (epilogue)
@@ -87,7 +93,11 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
+    const bool is_loader = SPEC ? (wave >= CW) : true;
+    const bool is_consumer = SPEC ? (wave < CW) : true;
+    const int lw = SPEC ? (is_loader ? wave - CW : 0) : wave;      // loader index
+    const int cw = is_consumer ? wave : 0;                          // consumer index
+    const int wm = cw / WGN, wn = cw % WGN;
     const int r = lane & 31, h = lane >> 5;
 
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     int a_hi0[NAI], a_wi0[NAI], a_c[NAI];
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
-        const int row = wave * (NAI * 8) + i * 8 + (lane >> 3);
+        const int row = lw * (NAI * 8) + i * 8 + (lane >> 3);
         a_c[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
         const int grow = m0 + row;
         a_mask[i] = 0u;
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     bool b_ok[NBI];
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
-        const int row = wave * (NBI * 8) + i * 8 + (lane >> 3);
+        const int row = lw * (NBI * 8) + i * 8 + (lane >> 3);
         b_c[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
         const int gn = n0 + row;
         b_ok[i] = gn < p.N;
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     int a_step[NAI], b_step[NBI];
     const bf16_t* b_walk[NBI];
 #pragma unroll
-    for (int i = 0; i < NAI; ++i) a_step[i] = (m0 + wave * (NAI * 8) + i * 8 + (lane >> 3) < p.M) ? BK : 0;
+    for (int i = 0; i < NAI; ++i) a_step[i] = (m0 + lw * (NAI * 8) + i * 8 + (lane >> 3) < p.M) ? BK : 0;
 #pragma unroll
     for (int i = 0; i < NBI; ++i) { b_walk[i] = b_ptr[i]; b_step[i] = b_ok[i] ? BK : 0; }
 
@@ -157,6 +167,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     int is_kt = 0, is_tap = 0, is_cb = 0, is_kh = 0, is_kw = 0;
 
     auto issue = [&](int buf) {
+        if (p.dbg & 1) { ++is_kt; return; }
         char* sA = smem + buf * STAGE;
         char* sB = sA + A_BYTES;
         const int kt = is_kt;
@@ -165,10 +176,10 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             if (!live) {                                   // uniform: the ring's trailing dummy stages
 #pragma unroll
                 for (int i = 0; i < NAI; ++i)
-                    __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sA + (wave * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sA + (lw * (NAI * 8) + i * 8) * 128), 16, 0, 0);
 #pragma unroll
                 for (int i = 0; i < NBI; ++i)
-                    __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sB + (wave * (NBI * 8) + i * 8) * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sB + (lw * (NBI * 8) + i * 8) * 128), 16, 0, 0);
                 ++is_kt;
                 return;
             }
@@ -177,12 +188,12 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 // (rows past M and columns past N hold the zero word with a zero stride.)
 #pragma unroll
                 for (int i = 0; i < NAI; ++i) {
-                    __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[i], (lptr_t)(sA + (wave * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[i], (lptr_t)(sA + (lw * (NAI * 8) + i * 8) * 128), 16, 0, 0);
                     a_ptr[i] += a_step[i];
                 }
 #pragma unroll
                 for (int i = 0; i < NBI; ++i) {
-                    __builtin_amdgcn_global_load_lds((gptr_t)b_walk[i], (lptr_t)(sB + (wave * (NBI * 8) + i * 8) * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)b_walk[i], (lptr_t)(sB + (lw * (NBI * 8) + i * 8) * 128), 16, 0, 0);
                     b_walk[i] += b_step[i];
                 }
                 ++is_kt;
@@ -193,12 +204,12 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             for (int i = 0; i < NAI; ++i) {
                 const bool ok = live && ((a_mask[i] >> is_tap) & 1u);
                 const bf16_t* src = ok ? a_ptr[i] + tapoff : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wave * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (lw * (NAI * 8) + i * 8) * 128), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < NBI; ++i) {
                 const bf16_t* src = (live && b_ok[i]) ? b_ptr[i] + (long)kt * BK : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (wave * (NBI * 8) + i * 8) * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (lw * (NBI * 8) + i * 8) * 128), 16, 0, 0);
             }
             is_cb += BK;
             if (is_cb >= p.Cin) {
@@ -218,13 +229,13 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 const bool ok = (kk < p.K) && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
                 // a_ptr already carries this lane's chunk offset a_c: add the tap offset and (c - a_c)
                 const bf16_t* src = ok ? a_ptr[i] + ((long)kh * p.sH + (long)kw * p.sW + (c - a_c[i])) : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wave * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (lw * (NAI * 8) + i * 8) * 128), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < NBI; ++i) {
                 const bool ok = b_ok[i] && (k0 + b_c[i] < p.K);
                 const bf16_t* src = ok ? b_ptr[i] + k0 : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (wave * (NBI * 8) + i * 8) * 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (lw * (NBI * 8) + i * 8) * 128), 16, 0, 0);
             }
         }
         ++is_kt;
@@ -253,21 +264,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         for (int ks = 0; ks < 4; ++ks) b_off[j][ks] = A_BYTES + row * 128 + (((2 * ks + h) ^ ((row >> 1) & 7)) << 4);
     }
 
-#pragma unroll
-    for (int s = 0; s < D; ++s) issue(s);
-
-    // (unrolling this loop over the ring to make stage offsets LDS immediates was measured: slower -- code size)
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // this wave's pieces of K-step kt have landed once all but the (D-1) younger K-steps are done ...
-        wait_vmcnt<LPW * (D - 1)>();
-        // ... and everybody's have once every wave is past that wait; the same barrier retires all reads of
-        // K-step kt-1, whose ring slot the next issue overwrites.
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");            // no LDS read may be hoisted above the barrier
-        int nbuf = buf + D;
-        if (nbuf >= S) nbuf -= S;
-        issue(nbuf);
+    auto compute = [&](int buf) {
         const char* st = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -282,15 +279,60 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        buf = (buf + 1 == S) ? 0 : buf + 1;
+    };
+
+    // Ring protocol (one raw s_barrier per K-step, all waves):
+    //   loader : wait until its own pieces of K-step kt have landed (all but the D-1 younger K-steps done) -> barrier
+    //            -> issue K-step kt+D into the slot K-step kt-1 occupied
+    //   consumer: barrier -> read + MFMA K-step kt
+    // Passing barrier kt tells a consumer that every loader's wait covered K-step kt, and tells a loader that every
+    // consumer has finished its reads of K-step kt-1 (reads retire before the MFMAs that precede the barrier).
+    if constexpr (SPEC) {
+        if (is_loader) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) issue(s);
+            int buf = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                wait_vmcnt<LPW * (D - 1)>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                int nbuf = buf + D;
+                if (nbuf >= S) nbuf -= S;
+                issue(nbuf);
+                buf = (buf + 1 == S) ? 0 : buf + 1;
+            }
+        } else {
+            int buf = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");        // no LDS read may be hoisted above the barrier
+                if (!(p.dbg & 2)) compute(buf);
+                buf = (buf + 1 == S) ? 0 : buf + 1;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < D; ++s) issue(s);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt<LPW * (D - 1)>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");            // no LDS read may be hoisted above the barrier
+            int nbuf = buf + D;
+            if (nbuf >= S) nbuf -= S;
+            issue(nbuf);
+            if (!(p.dbg & 2)) compute(buf);
+            buf = (buf + 1 == S) ? 0 : buf + 1;
+        }
     }
     // drain the dummy prefetches and let every wave finish its last reads before the ring is reused
     wait_vmcnt<0>();
     __syncthreads();
+    if (p.dbg & 4) return;                       // diagnostics: no epilogue
 
     // ---- epilogue 1: BatchNorm partial column sums from the f32 accumulators ----
     float* red = (float*)(smem + BM * CROW);     // [WGM][2][BN] floats, placed after the C tile
-    if (p.stat_partial || p.acc) {
+    if ((p.stat_partial || p.acc) && is_consumer) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s = 0.0f, q = 0.0f;
@@ -310,34 +352,10 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             }
         }
     }
-    // ---- epilogue 2: bf16 C tile through LDS (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ----
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int col = wn * WN + j * 32 + r;
-                *(bf16_t*)(smem + row * CROW + col * 2) = (bf16_t)acc[i][j][e];
-            }
-    __syncthreads();
-    if (p.stat_partial) {
-        for (int c = tid; c < BN; c += NT) {
-            const int col = n0 + c;
-            if (col < p.N) {
-                float s = 0.0f, q = 0.0f;
-#pragma unroll
-                for (int g = 0; g < WGM; ++g) {          // fixed order over the M-waves
-                    s += red[(g * 2 + 0) * BN + c];
-                    q += red[(g * 2 + 1) * BN + c];
-                }
-                p.stat_partial[((long)tile_m * 2 + 0) * p.N + col] = s;
-                p.stat_partial[((long)tile_m * 2 + 1) * p.N + col] = q;
-            }
-        }
-    }
     if (p.acc) {
+        // fused finalize, step 1: this tile's column sums join the launch-wide fixed-point accumulators.  Issued
+        // now so the atomics' round trip hides under the C-tile staging below.
+        __syncthreads();
         for (int c = tid; c < BN; c += NT) {
             const int col = n0 + c;
             if (col < p.N) {
@@ -353,6 +371,38 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             }
         }
     }
+    // ---- epilogue 2: bf16 C tile through LDS (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ----
+    if (is_consumer)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int col = wn * WN + j * 32 + r;
+                *(bf16_t*)(smem + row * CROW + col * 2) = (bf16_t)acc[i][j][e];
+            }
+    if (p.acc) wait_vmcnt<0>();               // this wave's atomics are performed (nothing else is outstanding)
+    __syncthreads();                           // C tile visible; every atomic of the workgroup performed
+    int ticket_val = -1;
+    if (p.acc && tid == 0)                     // step 2: take a ticket; its latency hides under the C stores
+        ticket_val = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p.stat_partial) {
+        for (int c = tid; c < BN; c += NT) {
+            const int col = n0 + c;
+            if (col < p.N) {
+                float s = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int g = 0; g < WGM; ++g) {          // fixed order over the M-waves
+                    s += red[(g * 2 + 0) * BN + c];
+                    q += red[(g * 2 + 1) * BN + c];
+                }
+                p.stat_partial[((long)tile_m * 2 + 0) * p.N + col] = s;
+                p.stat_partial[((long)tile_m * 2 + 1) * p.N + col] = q;
+            }
+        }
+    }
     constexpr int CPR = BN / 8;                  // 16-byte chunks per C row
 #pragma unroll
     for (int it = 0; it < BM * CPR / NT; ++it) {
@@ -363,14 +413,9 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             *(u32x4*)(p.C + (long)grow * p.ldc + gcol) = *(const u32x4*)(smem + row * CROW + cc * 16);
     }
     if (p.acc) {
-        // every wave: its atomics (and stores) are performed before the workgroup takes its ticket
-        wait_vmcnt<0>();
-        __syncthreads();
+        // step 3: the workgroup that drew the last ticket finalizes (every other one exits)
         int* flag = (int*)(smem + BM * CROW + 4 * WGM * BN * 4 - 16);      // inside the stat scratch, past `red`
-        if (tid == 0) {
-            const int t = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = (t == (int)gridDim.x - 1) ? 1 : 0;
-        }
+        if (tid == 0) *flag = (ticket_val == (int)gridDim.x - 1) ? 1 : 0;
         __syncthreads();
         if (*flag) {
             for (int c = tid; c < p.N; c += NT) {
@@ -398,13 +443,13 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     }
 }
 
-template <int BN, int S, int NW>
+template <int BN, int S, int NW, bool SPEC = false>
 int launch_glds(ConvArgs& a, hipStream_t s) {
     const int tm = sat_cdiv(a.M, 128), tn = sat_cdiv(a.N, BN);
     a.tiles_n = tn;
     const bool uniform = (a.Cin % 64 == 0) && (a.KH * a.KW <= 32);
-    if (uniform) hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
-    else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
+    if (uniform) hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
+    else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false, SPEC>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
@@ -415,10 +460,11 @@ int tune_env(const char* name, int dflt) {
 }
 
 // kernel variants: (tile width, ring stages, waves).  LDS = S * (16 + BN/8) KB decides workgroups per CU.
-struct Variant { int bn, s, nw; };
+struct Variant { int bn, s, nw, spec; };
 constexpr Variant kVariants[] = {
-    {128, 4, 8}, {128, 3, 8}, {128, 2, 8}, {64, 4, 8}, {64, 3, 8}, {64, 2, 8},
-    {128, 4, 4}, {128, 2, 4}, {64, 3, 4}, {64, 2, 4},
+    {128, 4, 8, 0}, {128, 3, 8, 0}, {128, 2, 8, 0}, {64, 4, 8, 0}, {64, 3, 8, 0}, {64, 2, 8, 0},
+    {128, 4, 4, 0}, {128, 2, 4, 0}, {64, 3, 4, 0}, {64, 2, 4, 0},
+    {128, 4, 8, 1}, {128, 3, 8, 1}, {128, 2, 8, 1}, {64, 4, 8, 1}, {64, 3, 8, 1},     // 4 consumer + 4 loader waves
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -434,6 +480,11 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 7: return launch_glds<128, 2, 4>(a, s);
         case 8: return launch_glds<64, 3, 4>(a, s);
         case 9: return launch_glds<64, 2, 4>(a, s);
+        case 10: return launch_glds<128, 4, 8, true>(a, s);
+        case 11: return launch_glds<128, 3, 8, true>(a, s);
+        case 12: return launch_glds<128, 2, 8, true>(a, s);
+        case 13: return launch_glds<64, 4, 8, true>(a, s);
+        case 14: return launch_glds<64, 3, 8, true>(a, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -453,6 +504,8 @@ ConvArgs make_args(const sat_op* op) {
     a.sN = op->sN; a.sH = op->sH; a.sW = op->sW;
     a.linear = (op->KH == 1 && op->KW == 1 && op->stride == 1 && op->pad == 0 && op->Hout == op->Hin &&
                 op->Wout == op->Win && op->sH == (long)op->Win * op->sW && op->sN == (long)op->Hin * op->sH) ? 1 : 0;
+    static const int dbg = tune_env("SAT_CONV_DBG", 0);
+    a.dbg = dbg;
     static const int no_linear = tune_env("SAT_CONV_NO_LINEAR", 0);
     if (no_linear) a.linear = 0;
     return a;
@@ -514,8 +567,8 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
                 hipEventElapsedTime(&ms, e0, e1);
                 if (round >= 1 && ms / reps < tmin) tmin = ms / reps;
             }
-            if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d v%d(%d,%d,%d) %.2f us\n", a.M, a.N, a.K, v, kVariants[v].bn,
-                                 kVariants[v].s, kVariants[v].nw, tmin * 1e3f);
+            if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d v%d(%d,%d,%d,%s) %.2f us\n", a.M, a.N, a.K, v, kVariants[v].bn,
+                                 kVariants[v].s, kVariants[v].nw, kVariants[v].spec ? "spec" : "-", tmin * 1e3f);
             if (tmin < best) { best = tmin; best_v = v; }
         }
         if (verbose) fprintf(stderr, "tune M=%d N=%d K=%d -> v%d %.2f us (%.0f TFLOP/s)\n", a.M, a.N, a.K, best_v, best * 1e3f,

@@ -16,13 +16,15 @@ L = sat._lib
 
 
 def time_ops(ops, n, reps=20):
+    """us per pass over ops[0:n]; the op list is replicated so ONE C call launches reps passes back to back
+    (a Python/ctypes call per launch would make anything shorter than ~7 us look host-bound)."""
     lib = L.load()
-    L.check(lib.sat_run_ops(ops, n, L.stream()))
+    rep = (L.SatOp * (n * reps))(*[ops[i % n] for i in range(n * reps)])
+    L.check(lib.sat_run_ops(rep, n * reps, L.stream()))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        L.check(lib.sat_run_ops(ops, n, L.stream()))
+    L.check(lib.sat_run_ops(rep, n * reps, L.stream()))
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3      # us
