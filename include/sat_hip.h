@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 2
+#define SAT_ABI_VERSION 3
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -86,14 +86,23 @@ typedef struct sat_op {
     float momentum, eps;
     int32_t variant;          /* SAT_OP_CONV: 0 = built-in heuristic, >0 = kernel variant chosen by sat_conv_autotune */
     int32_t reserved;
-    /* SAT_OP_CONV, bf16, training: fused BatchNorm finalize.  stat_acc = int64 [4][2][Cout] fixed-point column sums
-     * (zero before first use; the kernel clears them), stat_ticket = int32 workgroup counter (zero).  The conv then
-     * also needs gamma/beta/(running_*)/scale_out/shift_out/count/momentum/eps and no SAT_OP_BN_FINALIZE follows. */
+    /* Integer-atomic BatchNorm statistics (bf16, training, few M-tiles): stat_acc = int64 [2 step parities][2][C]
+     * fixed-point (2^22) column sums, zero before first use.  On a SAT_OP_CONV the kernel ADDS this tile's sums into
+     * parity p's half; on the consuming SAT_OP_BN_RELU / SAT_OP_BN_ADD_RELU (same pointer, plus gamma, beta, running_mean, running_var,
+     * count, momentum, eps) every workgroup derives scale/shift from them, workgroup 0 updates the running statistics
+     * and clears parity 1-p's half: no SAT_OP_BN_FINALIZE launch.  p is sat_run_ops_parity's argument and must
+     * alternate between consecutive runs of the program.  The *1 fields describe in1's BatchNorm (BN_ADD_RELU). */
     void* stat_acc;
-    int32_t* stat_ticket;
+    void* stat_acc1;
+    const float* gamma1;
+    const float* beta1;
+    float* running_mean1;
+    float* running_var1;
 } sat_op;
 
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
+/* same, with the step parity (0/1) that selects the half of every stat_acc buffer in use */
+int sat_run_ops_parity(const sat_op* ops /*[host]*/, int n_ops, int parity, sat_stream_t stream);
 /* conv + batch-stat finalize + normalise/ReLU as one call (three ops) -- `conv -> bn -> relu` of a bottleneck */
 int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, const sat_op* bnrelu, sat_stream_t stream);
 /* rows of SAT_OP_CONV partials the conv kernel writes for M output pixels */

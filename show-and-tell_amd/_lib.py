@@ -30,7 +30,8 @@ class SatOp(C.Structure):
         ("sN", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64), ("count", C.c_int64),
         ("momentum", C.c_float), ("eps", C.c_float),
         ("variant", C.c_int32), ("reserved", C.c_int32),
-        ("stat_acc", _vp), ("stat_ticket", _vp),
+        ("stat_acc", _vp), ("stat_acc1", _vp), ("gamma1", _vp), ("beta1", _vp),
+        ("running_mean1", _vp), ("running_var1", _vp),
     ]
 
 
@@ -40,6 +41,7 @@ SIGNATURES = {
     "sat_error_string": (C.c_char_p, [_i]),
     "sat_gemm_f32": (_i, [_i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
     "sat_run_ops": (_i, [C.POINTER(SatOp), _i, _vp]),
+    "sat_run_ops_parity": (_i, [C.POINTER(SatOp), _i, _i, _vp]),
     "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
     "sat_conv_tiles_m": (_i, [_i64]),
     "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp]),
@@ -86,7 +88,7 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.sat_version() != 2:
+        if lib.sat_version() != 3:
             raise RuntimeError("libsat_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -34,22 +34,15 @@ struct ConvArgs {
     long sN, sH, sW;
     int tiles_n;
     int linear;     // 1x1 / stride 1 / no padding on a dense NHWC tensor: output row m reads input pixel m
-    // fused BatchNorm finalize (training): fixed-point column sums accumulated with 64-bit integer atomics
-    // (integer addition is associative => bitwise reproducible whatever the arrival order), the LAST workgroup
-    // of the launch (ticket) turns them into scale/shift, updates the running statistics and clears them.
-    long long* acc;          // [4 buckets][2][N]
-    int* ticket;
-    const float* gamma;
-    const float* beta;
-    float* running_mean;     // may be NULL (no running update)
-    float* running_var;
-    float* scale_out;
-    float* shift_out;
-    double count;
-    float momentum, eps;
+    // training-mode BatchNorm statistics, atomic form: fixed-point column sums (sum, sum of squares) added with 64-bit
+    // INTEGER atomics into acc[2][N].  Integer addition is associative, so the totals are bitwise reproducible
+    // whatever the arrival order; the consumer kernel (bn_act / maxpool) turns them into scale/shift itself, which
+    // removes the separate finalize launch.  Used when there are few M-tiles (<= ~400 adds per word).
+    long long* acc;
     int dbg;                 // diagnostics only (SAT_CONV_DBG): 1 = no loads, 2 = no MFMA, 4 = no epilogue
 };
-constexpr double kStatScale = 4194304.0;   // 2^22 fixed point
+// fixed-point scale of the atomic statistics is SAT_STAT_SCALE (sat_internal.h)
+constexpr double kStatScale = SAT_STAT_SCALE;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -353,8 +346,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         }
     }
     if (p.acc) {
-        // fused finalize, step 1: this tile's column sums join the launch-wide fixed-point accumulators.  Issued
-        // now so the atomics' round trip hides under the C-tile staging below.
+        // this tile's column sums join the launch-wide fixed-point accumulators
         __syncthreads();
         for (int c = tid; c < BN; c += NT) {
             const int col = n0 + c;
@@ -365,9 +357,8 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                     s += red[(g * 2 + 0) * BN + c];
                     q += red[(g * 2 + 1) * BN + c];
                 }
-                long long* a0 = p.acc + ((long)(tile_m & 3) * 2) * p.N + col;
-                atomicAdd((unsigned long long*)a0, (unsigned long long)__double2ll_rn((double)s * kStatScale));
-                atomicAdd((unsigned long long*)(a0 + p.N), (unsigned long long)__double2ll_rn((double)q * kStatScale));
+                atomicAdd((unsigned long long*)(p.acc + col), (unsigned long long)__double2ll_rn((double)s * kStatScale));
+                atomicAdd((unsigned long long*)(p.acc + p.N + col), (unsigned long long)__double2ll_rn((double)q * kStatScale));
             }
         }
     }
@@ -383,11 +374,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 const int col = wn * WN + j * 32 + r;
                 *(bf16_t*)(smem + row * CROW + col * 2) = (bf16_t)acc[i][j][e];
             }
-    if (p.acc) wait_vmcnt<0>();               // this wave's atomics are performed (nothing else is outstanding)
-    __syncthreads();                           // C tile visible; every atomic of the workgroup performed
-    int ticket_val = -1;
-    if (p.acc && tid == 0)                     // step 2: take a ticket; its latency hides under the C stores
-        ticket_val = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     if (p.stat_partial) {
         for (int c = tid; c < BN; c += NT) {
             const int col = n0 + c;
@@ -411,35 +398,6 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         const int grow = m0 + row, gcol = n0 + cc * 8;
         if (grow < p.M && gcol < p.N)             // N % 8 == 0: a chunk is all in or all out
             *(u32x4*)(p.C + (long)grow * p.ldc + gcol) = *(const u32x4*)(smem + row * CROW + cc * 16);
-    }
-    if (p.acc) {
-        // step 3: the workgroup that drew the last ticket finalizes (every other one exits)
-        int* flag = (int*)(smem + BM * CROW + 4 * WGM * BN * 4 - 16);      // inside the stat scratch, past `red`
-        if (tid == 0) *flag = (ticket_val == (int)gridDim.x - 1) ? 1 : 0;
-        __syncthreads();
-        if (*flag) {
-            for (int c = tid; c < p.N; c += NT) {
-                long long sumS = 0, sumQ = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {                // read-and-clear at the memory side (coherent across XCDs)
-                    sumS += (long long)atomicExch((unsigned long long*)(p.acc + ((long)b * 2 + 0) * p.N + c), 0ull);
-                    sumQ += (long long)atomicExch((unsigned long long*)(p.acc + ((long)b * 2 + 1) * p.N + c), 0ull);
-                }
-                const double mean = (double)sumS / kStatScale / p.count;
-                double var = (double)sumQ / kStatScale / p.count - mean * mean;
-                if (var < 0.0) var = 0.0;
-                if (p.running_mean) {
-                    const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
-                    p.running_mean[c] = (float)((1.0 - p.momentum) * p.running_mean[c] + p.momentum * mean);
-                    p.running_var[c] = (float)((1.0 - p.momentum) * p.running_var[c] + p.momentum * unbiased);
-                }
-                const float invstd = 1.0f / sqrtf((float)var + p.eps);
-                const float sc = p.gamma[c] * invstd;
-                p.scale_out[c] = sc;
-                p.shift_out[c] = p.beta[c] - (float)mean * sc;
-            }
-            if (tid == 0) atomicExch(p.ticket, 0);
-        }
     }
 }
 
@@ -493,10 +451,7 @@ ConvArgs make_args(const sat_op* op) {
     ConvArgs a = {};
     a.A = (const bf16_t*)op->in0; a.B = (const bf16_t*)op->w; a.C = (bf16_t*)op->out;
     a.stat_partial = op->stat_partial;
-    a.acc = (long long*)op->stat_acc; a.ticket = op->stat_ticket;
-    a.gamma = op->gamma; a.beta = op->beta; a.running_mean = op->running_mean; a.running_var = op->running_var;
-    a.scale_out = op->scale_out; a.shift_out = op->shift_out;
-    a.count = (double)op->count; a.momentum = op->momentum; a.eps = op->eps;
+    a.acc = (long long*)op->stat_acc;
     a.M = op->N * op->Hout * op->Wout; a.N = op->Cout; a.K = op->KH * op->KW * op->Cin;
     a.ldb = a.K; a.ldc = op->Cout;
     a.Hin = op->Hin; a.Win = op->Win; a.Cin = op->Cin; a.Hout = op->Hout; a.Wout = op->Wout;
@@ -523,11 +478,10 @@ int heuristic_variant(const ConvArgs& a) {
 }  // namespace
 
 // bf16 SAT_OP_CONV; arguments already validated by sat_conv_launch
-int sat_conv_glds_launch(const sat_op* op, hipStream_t s) {
+int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
     if (op->Cout % 8) return SAT_ERR_UNSUPPORTED;
-    if (op->stat_acc && (!op->stat_ticket || !op->gamma || !op->beta || !op->scale_out || !op->shift_out || op->count < 1))
-        return SAT_ERR_ARG;
     ConvArgs a = make_args(op);
+    if (a.acc) a.acc += (long)parity * 2 * a.N;          // [2 parities][2][N]
     const int v = (op->variant > 0 && op->variant <= kNumVariants) ? op->variant - 1 : heuristic_variant(a);
     return launch_variant(v, a, s);
 }

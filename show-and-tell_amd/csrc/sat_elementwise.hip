@@ -4,8 +4,7 @@
 //   decoder : embedding gather / deterministic scatter, row-wise softmax-CE, column sums, LSTM backward
 //             pointwise step, BatchNorm1d forward/backward
 //   trainer : fused elementwise clamp + Adam over one flat buffer (train.py:88-91,146)
-#include "sat_common.h"
-#include "../../include/sat_hip.h"
+#include "sat_internal.h"
 #include <stdlib.h>
 
 namespace {
@@ -122,14 +121,65 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
 }
 
+// Where a BatchNorm's (scale, shift) comes from: either a table the finalize kernel wrote, or -- `acc` set -- the
+// fixed-point integer sums the producing conv accumulated (sat_conv_glds.hip): then every workgroup derives the
+// table itself into LDS (a few KB of loads, f64 arithmetic identical to bn_finalize_kernel), and workgroup 0 also
+// updates the running statistics and clears the OTHER step-parity's accumulators for the next step.
+struct BnSrc {
+    const float* scale;
+    const float* shift;
+    const long long* acc;     // [2][C] (this step's parity)
+    long long* acc_clear;     // [2][C] (other parity) or NULL
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+};
+
+__device__ __forceinline__ void bn_table_from_acc(const BnSrc& b, int C, double count, float momentum, float eps,
+                                                  float* sc, float* sh) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double mean = (double)b.acc[c] / SAT_STAT_SCALE / count;
+        double var = (double)b.acc[C + c] / SAT_STAT_SCALE / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = 1.0f / sqrtf((float)var + eps);
+        const float s = b.gamma[c] * invstd;
+        sc[c] = s;
+        sh[c] = b.beta[c] - (float)mean * s;
+        if (blockIdx.x == 0) {
+            if (b.running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                b.running_mean[c] = (float)((1.0 - momentum) * b.running_mean[c] + momentum * mean);
+                b.running_var[c] = (float)((1.0 - momentum) * b.running_var[c] + momentum * unbiased);
+            }
+            if (b.acc_clear) { b.acc_clear[c] = 0; b.acc_clear[C + c] = 0; }
+        }
+    }
+}
+
 // out = relu(in0*s0 + t0)  /  out = relu(in0*s0 + t0 + (in1*s1 + t1 | in1)); NHWC, C % chunk == 0.
-// When the total thread count is a multiple of the chunks per pixel, a thread's channel chunk never changes
-// along its grid-stride walk: scale/shift then live in registers and the loop is pure 16-byte streaming.
+// The launcher makes the total thread count a multiple of the chunks per pixel, so a thread's channel chunk never
+// changes along its grid-stride walk: scale/shift live in registers and the loop is pure 16-byte streaming.
 template <typename T, bool ADD>
 __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ in1, T* __restrict__ out,
-                              const float* __restrict__ s0, const float* __restrict__ t0,
-                              const float* __restrict__ s1, const float* __restrict__ t1, long nchunks, int C) {
+                              const BnSrc b0, const BnSrc b1, int has_b1, double count, float momentum, float eps,
+                              long nchunks, int C) {
     constexpr int V = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float tab[];      // [4][C] when a table is derived here
+    const float* s0 = b0.scale;
+    const float* t0 = b0.shift;
+    const float* s1 = b1.scale;
+    const float* t1 = b1.shift;
+    bool derived = false;
+    if (b0.acc) {
+        bn_table_from_acc(b0, C, count, momentum, eps, tab, tab + C);
+        s0 = tab; t0 = tab + C; derived = true;
+    }
+    if (ADD && has_b1 && b1.acc) {
+        bn_table_from_acc(b1, C, count, momentum, eps, tab + 2 * C, tab + 3 * C);
+        s1 = tab + 2 * C; t1 = tab + 3 * C; derived = true;
+    }
+    if (derived) __syncthreads();
     const long stride = (long)gridDim.x * blockDim.x;
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int cch = C / V;
@@ -141,7 +191,7 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
         for (int k = 0; k < V; k += 4) {
             const f32x4 a = *(const f32x4*)(s0 + c0 + k), b = *(const f32x4*)(t0 + c0 + k);
             f32x4 c = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};
-            if (ADD && s1) { c = *(const f32x4*)(s1 + c0 + k); d = *(const f32x4*)(t1 + c0 + k); }
+            if (ADD && has_b1) { c = *(const f32x4*)(s1 + c0 + k); d = *(const f32x4*)(t1 + c0 + k); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { sc0[k + e] = a[e]; sh0[k + e] = b[e]; sc1[k + e] = c[e]; sh1[k + e] = d[e]; }
         }
@@ -183,7 +233,7 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
         if constexpr (ADD) {
             float z[V];
             load_chunk<T>(in1 + i * V, z);
-            if (s1) {
+            if (has_b1) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) y[k] += z[k] * s1[c0 + k] + t1[c0 + k];
             } else {
@@ -647,26 +697,64 @@ int sat_bn_finalize_launch(const sat_op* op, hipStream_t s) {
 }
 
 template <typename T>
-static int bn_act_launch_t(const sat_op* op, bool add, hipStream_t s) {
+static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s) {
     constexpr int V = Vec<T>::N;
     const int C = op->Cout;
     if (C % V) return SAT_ERR_ARG;
     const long n = (long)op->N * op->Hout * op->Wout * C;
     const long nch = n / V;
+    BnSrc b0 = {}, b1 = {};
+    b0.scale = op->scale0; b0.shift = op->shift0;
+    b1.scale = op->scale1; b1.shift = op->shift1;
+    int has_b1 = 0;
+    size_t lds = 0;
+    if (op->stat_acc) {              // statistics arrive as integer sums: derive the table in the kernel
+        if (!op->gamma || !op->beta || op->count < 1) return SAT_ERR_ARG;
+        long long* base = (long long*)op->stat_acc;          // [2 parities][2][C]
+        b0.acc = base + (long)parity * 2 * C;
+        b0.acc_clear = base + (long)(1 - parity) * 2 * C;
+        b0.gamma = op->gamma; b0.beta = op->beta; b0.running_mean = op->running_mean; b0.running_var = op->running_var;
+        lds = (size_t)4 * C * sizeof(float);
+    } else if (!op->scale0 || !op->shift0) {
+        return SAT_ERR_ARG;
+    }
+    if (add) {
+        if (op->stat_acc1) {
+            if (!op->gamma1 || !op->beta1 || op->count < 1) return SAT_ERR_ARG;
+            long long* base = (long long*)op->stat_acc1;
+            b1.acc = base + (long)parity * 2 * C;
+            b1.acc_clear = base + (long)(1 - parity) * 2 * C;
+            b1.gamma = op->gamma1; b1.beta = op->beta1; b1.running_mean = op->running_mean1; b1.running_var = op->running_var1;
+            lds = (size_t)4 * C * sizeof(float);
+            has_b1 = 1;
+        } else if (op->scale1) {
+            if (!op->shift1) return SAT_ERR_ARG;
+            has_b1 = 1;
+        }
+    }
+    if (lds > 64 * 1024) return SAT_ERR_UNSUPPORTED;
+    // thread count a multiple of the chunks per pixel (channel chunk invariant per thread)
+    const int cch = C / V;
+    int grid = ew_grid(nch);
+    if (cch > EW_BLOCK && (cch % EW_BLOCK) == 0) {
+        const int g0 = cch / EW_BLOCK;
+        grid = grid / g0 * g0;
+        if (grid < g0) grid = g0;
+    }
+    const double count = (double)op->count;
     if (add)
-        hipLaunchKernelGGL((bn_act_kernel<T, true>), dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, s, (const T*)op->in0,
-                           (const T*)op->in1, (T*)op->out, op->scale0, op->shift0, op->scale1, op->shift1, nch, C);
+        hipLaunchKernelGGL((bn_act_kernel<T, true>), dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (const T*)op->in1,
+                           (T*)op->out, b0, b1, has_b1, count, op->momentum, op->eps, nch, C);
     else
-        hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, s, (const T*)op->in0,
-                           (const T*)nullptr, (T*)op->out, op->scale0, op->shift0, (const float*)nullptr,
-                           (const float*)nullptr, nch, C);
+        hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (const T*)nullptr,
+                           (T*)op->out, b0, b1, 0, count, op->momentum, op->eps, nch, C);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
 
-int sat_bn_act_launch(const sat_op* op, bool add, hipStream_t s) {
-    if (!op->in0 || !op->out || !op->scale0 || !op->shift0 || (add && !op->in1)) return SAT_ERR_ARG;
-    return op->dtype == SAT_BF16 ? bn_act_launch_t<bf16_t>(op, add, s) : bn_act_launch_t<float>(op, add, s);
+int sat_bn_act_launch(const sat_op* op, bool add, int parity, hipStream_t s) {
+    if (!op->in0 || !op->out || (add && !op->in1)) return SAT_ERR_ARG;
+    return op->dtype == SAT_BF16 ? bn_act_launch_t<bf16_t>(op, add, parity, s) : bn_act_launch_t<float>(op, add, parity, s);
 }
 
 int sat_bn_relu_maxpool_launch(const sat_op* op, hipStream_t s) {

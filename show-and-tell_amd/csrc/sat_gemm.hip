@@ -372,7 +372,7 @@ extern "C" int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t
 
 extern "C" int sat_conv_tiles_m(int64_t M) { return sat_cdiv(M, 128); }
 
-int sat_conv_glds_launch(const sat_op* op, hipStream_t s);   // sat_conv_glds.hip
+int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s);   // sat_conv_glds.hip
 
 static bool conv_legacy() {
     static int v = -1;
@@ -381,7 +381,7 @@ static bool conv_legacy() {
 }
 
 // SAT_OP_CONV
-int sat_conv_launch(const sat_op* op, hipStream_t s) {
+int sat_conv_launch(const sat_op* op, int parity, hipStream_t s) {
     if (!op->in0 || !op->w || !op->out) return SAT_ERR_ARG;
     const int esz = op->dtype == SAT_BF16 ? 2 : 4;
     const int ch = 16 / esz;
@@ -399,7 +399,7 @@ int sat_conv_launch(const sat_op* op, hipStream_t s) {
     a.KH = op->KH; a.KW = op->KW; a.stride = op->stride; a.pad = op->pad;
     a.sN = op->sN; a.sH = op->sH; a.sW = op->sW;
     if (op->stat_partial && op->tiles_m != sat_cdiv(a.M, 128)) return SAT_ERR_ARG;
-    if (op->dtype == SAT_BF16 && (op->Cout % 8) == 0 && !conv_legacy()) return sat_conv_glds_launch(op, s);
+    if (op->dtype == SAT_BF16 && (op->Cout % 8) == 0 && !conv_legacy()) return sat_conv_glds_launch(op, parity, s);
     // register-staged kernel (f32 parity mode, odd shapes).  BM is always 128 (it fixes the partial-slab geometry); BN 64 for narrow layers or to fill the chip
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const bool narrow = (a.N <= 64) || (t128 < 512);

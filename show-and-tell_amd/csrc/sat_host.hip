@@ -18,17 +18,21 @@ extern "C" const char* sat_error_string(int code) {
 }
 
 extern "C" int sat_run_ops(const sat_op* ops, int n_ops, sat_stream_t stream) {
-    if (!ops || n_ops < 0) return SAT_ERR_ARG;
+    return sat_run_ops_parity(ops, n_ops, 0, stream);
+}
+
+extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_stream_t stream) {
+    if (!ops || n_ops < 0 || (parity != 0 && parity != 1)) return SAT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < n_ops; ++i) {
         const sat_op* op = ops + i;
         int rc;
         switch (op->kind) {
             case SAT_OP_IMAGE_PREP: rc = sat_image_prep_launch(op, s); break;
-            case SAT_OP_CONV: rc = sat_conv_launch(op, s); break;
+            case SAT_OP_CONV: rc = sat_conv_launch(op, parity, s); break;
             case SAT_OP_BN_FINALIZE: rc = sat_bn_finalize_launch(op, s); break;
-            case SAT_OP_BN_RELU: rc = sat_bn_act_launch(op, false, s); break;
-            case SAT_OP_BN_ADD_RELU: rc = sat_bn_act_launch(op, true, s); break;
+            case SAT_OP_BN_RELU: rc = sat_bn_act_launch(op, false, parity, s); break;
+            case SAT_OP_BN_ADD_RELU: rc = sat_bn_act_launch(op, true, parity, s); break;
             case SAT_OP_BN_RELU_MAXPOOL: rc = sat_bn_relu_maxpool_launch(op, s); break;
             case SAT_OP_AVGPOOL: rc = sat_avgpool_launch(op, s); break;
             default: rc = SAT_ERR_UNSUPPORTED;
@@ -44,9 +48,9 @@ extern "C" int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, 
     if (conv->kind != SAT_OP_CONV || finalize->kind != SAT_OP_BN_FINALIZE || bnrelu->kind != SAT_OP_BN_RELU)
         return SAT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    SAT_TRY(sat_conv_launch(conv, s));
+    SAT_TRY(sat_conv_launch(conv, 0, s));
     SAT_TRY(sat_bn_finalize_launch(finalize, s));
-    return sat_bn_act_launch(bnrelu, false, s);
+    return sat_bn_act_launch(bnrelu, false, 0, s);
 }
 
 // ------------------------------------------------------------------------------------------------------

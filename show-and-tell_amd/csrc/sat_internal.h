@@ -3,10 +3,10 @@
 #include "sat_common.h"
 #include "../../include/sat_hip.h"
 
-int sat_conv_launch(const sat_op* op, hipStream_t s);
+int sat_conv_launch(const sat_op* op, int parity, hipStream_t s);
 int sat_image_prep_launch(const sat_op* op, hipStream_t s);
 int sat_bn_finalize_launch(const sat_op* op, hipStream_t s);
-int sat_bn_act_launch(const sat_op* op, bool add, hipStream_t s);
+int sat_bn_act_launch(const sat_op* op, bool add, int parity, hipStream_t s);
 int sat_bn_relu_maxpool_launch(const sat_op* op, hipStream_t s);
 int sat_avgpool_launch(const sat_op* op, hipStream_t s);
 
@@ -24,6 +24,9 @@ int sat_bn1d_fwd_launch(const float* part, int nz, long slab_stride, const float
                         float* zbuf, float* feats, float* xhat, float* rstd, hipStream_t s);
 int sat_bn1d_bwd_launch(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int E,
                         float* dz, float* dgamma, float* dbeta, float* db_fc, hipStream_t s);
+
+// fixed-point scale (2^22) of the integer-atomic BatchNorm statistics shared by the conv epilogue and its consumers
+#define SAT_STAT_SCALE 4194304.0
 
 #define SAT_TRY(expr)                 \
     do {                              \

@@ -201,26 +201,28 @@ class ConvStackProgram:
                 o.tiles_m = L.load().sat_conv_tiles_m(n * hout * wout)
             return o
 
-        fused_fin = training and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSED_BN_FINALIZE", "0") == "1"
-        if fused_fin:
-            # fixed-point column sums [bn][4 buckets][2][C] + one ticket per BN: the conv kernel's last workgroup
-            # finalizes (no SAT_OP_BN_FINALIZE launch)
-            self.stat_acc = alloc((nbn, 4, 2, cmax), torch.int64, zero=True)
-            self.stat_ticket = alloc((nbn,), torch.int32, zero=True)
+        # BatchNorm statistics, two forms (both bitwise reproducible):
+        #  * per-tile slabs + SAT_OP_BN_FINALIZE (f32 mode, eval mode, layers with many M-tiles);
+        #  * bf16 training, <= ATOMIC_MAX_TILES M-tiles: the conv adds fixed-point sums with integer atomics into
+        #    stat_acc[bn][parity][2][C] and the consuming BN_RELU / BN_ADD_RELU derives scale/shift itself
+        #    (no finalize launch).  The parity alternates per run() so workgroup 0 of the consumer can clear the
+        #    other half for the next step.
+        ATOMIC_MAX_TILES = int(os.environ.get("SAT_ATOMIC_BN_MAX_TILES", "400"))
+        atomic_stats = training and dtype == L.SAT_BF16 and ATOMIC_MAX_TILES > 0
+        self._parity = 0
+        bnref = {}
+        if atomic_stats:
+            self.stat_acc = alloc((nbn, 2, 2, cmax), torch.int64, zero=True)
 
-        def fin_op(bn, c, count, tiles_m):
+        def fin_op(bn, c, count, tiles_m, consumer_can_derive=True):
             s, t = new_scale_shift(c)
-            if fused_fin:
+            if atomic_stats and consumer_can_derive and tiles_m <= ATOMIC_MAX_TILES:
                 i = bn_idx[0] - 1
                 cv = ops[-1]                       # the conv that produces this BN's input
                 assert cv.kind == L.OP_CONV and cv.Cout == c
                 cv.stat_partial = None
                 cv.stat_acc = self.stat_acc[i].data_ptr()
-                cv.stat_ticket = self.stat_ticket[i:i + 1].data_ptr()
-                cv.gamma, cv.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
-                cv.running_mean, cv.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-                cv.scale_out, cv.shift_out = s.data_ptr(), t.data_ptr()
-                cv.count, cv.momentum, cv.eps = count, BN_MOMENTUM, BN_EPS
+                bnref[s.data_ptr()] = (self.stat_acc[i].data_ptr(), bn, count)
                 self.bn_list.append(bn)
                 return None, s, t
             o = L.SatOp()
@@ -238,11 +240,27 @@ class ConvStackProgram:
             o = L.SatOp()
             o.kind, o.dtype = kind, dtype
             o.in0, o.out = x.data_ptr(), out.data_ptr()
-            o.scale0, o.shift0 = s.data_ptr(), t.data_ptr()
+            ref = bnref.get(s.data_ptr())
+            if ref is None:
+                o.scale0, o.shift0 = s.data_ptr(), t.data_ptr()
+            else:                                  # derive (scale, shift) from the conv's integer sums
+                acc, bn, count = ref
+                o.stat_acc = acc
+                o.gamma, o.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                o.running_mean, o.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                o.count, o.momentum, o.eps = count, BN_MOMENTUM, BN_EPS
             if x1 is not None:
                 o.in1 = x1.data_ptr()
                 if s1 is not None:
-                    o.scale1, o.shift1 = s1.data_ptr(), t1.data_ptr()
+                    ref1 = bnref.get(s1.data_ptr())
+                    if ref1 is None:
+                        o.scale1, o.shift1 = s1.data_ptr(), t1.data_ptr()
+                    else:
+                        acc1, bn1_, count1 = ref1
+                        o.stat_acc1 = acc1
+                        o.gamma1, o.beta1 = bn1_.weight.data_ptr(), bn1_.bias.data_ptr()
+                        o.running_mean1, o.running_var1 = bn1_.running_mean.data_ptr(), bn1_.running_var.data_ptr()
+                        o.count, o.momentum, o.eps = count1, BN_MOMENTUM, BN_EPS
             o.N, o.Hout, o.Wout, o.Cout = n, h_, w__, c
             return o
 
@@ -265,7 +283,7 @@ class ConvStackProgram:
         ops.append(o)
         self._prep_index = 0
         ops.append(conv_op(self.img_pad, wst, self.c0, N, Hp, Wp, 32, Ho, Wo, width, 7, 1, 2, 0, Hp * Wp * 4, Wp * 4, 4))
-        f, s, t = fin_op(stack.bn1, width, N * Ho * Wo, L.load().sat_conv_tiles_m(N * Ho * Wo))
+        f, s, t = fin_op(stack.bn1, width, N * Ho * Wo, L.load().sat_conv_tiles_m(N * Ho * Wo), consumer_can_derive=False)
         add(f)
         y, ynext = self.ybuf
         mp = L.SatOp()
@@ -317,7 +335,8 @@ class ConvStackProgram:
             raise ValueError("images must be float32 [%d,3,%d,%d]" % (self.N, self.H, self.W))
         images = images.contiguous()
         self.ops[self._prep_index].in0 = images.data_ptr()
-        L.check(L.load().sat_run_ops(self.ops, self.n_ops, L.stream()), "sat_run_ops")
+        L.check(L.load().sat_run_ops_parity(self.ops, self.n_ops, self._parity, L.stream()), "sat_run_ops")
+        self._parity ^= 1
         if self.training:
             self.stack._nbt_flat += 1
         return self.pooled
