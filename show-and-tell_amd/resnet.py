@@ -207,7 +207,7 @@ class ConvStackProgram:
         #    stat_acc[bn][parity][2][C] and the consuming BN_RELU / BN_ADD_RELU derives scale/shift itself
         #    (no finalize launch).  The parity alternates per run() so workgroup 0 of the consumer can clear the
         #    other half for the next step.
-        ATOMIC_MAX_TILES = int(os.environ.get("SAT_ATOMIC_BN_MAX_TILES", "400"))
+        ATOMIC_MAX_TILES = int(os.environ.get("SAT_ATOMIC_BN_MAX_TILES", "128"))
         atomic_stats = training and dtype == L.SAT_BF16 and ATOMIC_MAX_TILES > 0
         self._parity = 0
         bnref = {}
