@@ -154,7 +154,7 @@ def main():
                          "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step_in_kernel": round(conv_ms, 3)},
         }
         traffic_file = os.path.join(ROOT, "profiles", "r01_c_conv_pmc_traffic.json")
-        if os.path.exists(traffic_file):      # HBM bytes per conv launch from the separate rocprofv3 --pmc passes (run_gpu_pmc.sh)
+        if os.path.exists(traffic_file):      # HBM bytes per conv launch from the separate rocprofv3 --pmc passes (tools/run_gpu_pmc.sh)
             with open(traffic_file) as f:
                 out["roofline"]["traffic"] = round(json.load(f)["hbm_bytes_per_launch_corrected"])
                 out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c_conv_pmc_traffic.json)"

@@ -158,19 +158,21 @@ int sat_lstm_bwd(const float* dHS /*[N,H]*/, const float* X, const float* w_ih, 
                  float* dX /*[N,In] or NULL*/, float* workspace, int64_t ws_bytes, sat_stream_t stream);
 
 /* vocab projection (models.py:53) */
+/* logits rows have stride ldl >= V floats.  For the backward (sat_vocab_ce_bwd) ldl must be a multiple of 4 and the
+ * pad columns [V, ldl) must hold zeros (allocate the buffer zero-filled: no kernel here writes the pad). */
 int sat_vocab_logits_fwd(const float* Hs /*[N,H]*/, const float* w /*[V,H]*/, const float* b /*[V]*/,
-                         int N, int H, int V, float* logits /*[N,V]*/, sat_stream_t stream);
+                         int N, int H, int V, float* logits /*[N,ldl]*/, int64_t ldl, sat_stream_t stream);
 /* row-wise softmax cross entropy (train.py:53,143): row_loss[n] = lse - logit[target]; loss_out[0] =
  * inv_denom * sum(row_loss) (fixed-order reduction).  write_grad: logits are overwritten IN PLACE with
  * d(loss)/d(logits) = (softmax - onehot) * inv_denom. */
-int sat_ce_rows(float* logits /*[N,V]*/, const int64_t* targets /*[N]*/, int N, int V, float inv_denom,
+int sat_ce_rows(float* logits /*[N,ldl]*/, int64_t ldl, const int64_t* targets /*[N]*/, int N, int V, float inv_denom,
                 int write_grad, float* row_loss /*[N]*/, float* loss_out /*[1]*/, sat_stream_t stream);
 /* fused: logits + CE (+ in-place grad) */
 int sat_vocab_ce_fwd(const float* Hs, const float* w, const float* b, const int64_t* targets,
                      int N, int H, int V, float inv_denom, int write_grad,
-                     float* logits, float* row_loss, float* loss_out, sat_stream_t stream);
+                     float* logits, int64_t ldl, float* row_loss, float* loss_out, sat_stream_t stream);
 /* backward of the projection given dlogits: dW[V,H], db[V], dHs[N,H] */
-int sat_vocab_ce_bwd(const float* dlogits /*[N,V]*/, const float* Hs, const float* w, int N, int H, int V,
+int sat_vocab_ce_bwd(const float* dlogits /*[N,ldl]*/, int64_t ldl, const float* Hs, const float* w, int N, int H, int V,
                      float* dw, float* db, float* dHs, float* workspace, int64_t ws_bytes, sat_stream_t stream);
 int64_t sat_vocab_ce_bwd_ws_bytes(int N, int H, int V);
 /* split-K variant of sat_gemm_f32: K-steps dealt to ksplit slices, slice z writes C + z*slab_stride (bias in slice 0);

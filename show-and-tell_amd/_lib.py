@@ -55,10 +55,10 @@ SIGNATURES = {
     "sat_lstm_bwd_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "sat_vocab_logits_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
-    "sat_ce_rows": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
-    "sat_vocab_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
-    "sat_vocab_ce_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sat_vocab_logits_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "sat_ce_rows": (_i, [_vp, _i64, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "sat_vocab_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i64, _vp, _vp, _vp]),
+    "sat_vocab_ce_bwd": (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_vocab_ce_bwd_ws_bytes": (_i64, [_i, _i, _i]),
     "sat_gemm_f32_splitk": (_i, [_i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i64, _vp]),
     "sat_sum_slabs_f32": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),

@@ -416,11 +416,11 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void ce_rows_kernel(float* __restrict__ logits, const int64_t* __restrict__ targets,
+__global__ __launch_bounds__(256) void ce_rows_kernel(float* __restrict__ logits, long ldl, const int64_t* __restrict__ targets,
                                                       int V, float inv_denom, int write_grad, float* __restrict__ row_loss) {
     __shared__ float sh[4];
     const int row = blockIdx.x;
-    float* x = logits + (long)row * V;
+    float* x = logits + (long)row * ldl;
     float m = -INFINITY;
     for (int i = threadIdx.x; i < V; i += 256) m = fmaxf(m, x[i]);
     m = block_reduce(m, true, sh);
@@ -851,11 +851,11 @@ extern "C" int sat_embed_rows(const float* embed, const int64_t* ids, int64_t id
     return SAT_OK;
 }
 
-extern "C" int sat_ce_rows(float* logits, const int64_t* targets, int N, int V, float inv_denom, int write_grad,
-                           float* row_loss, float* loss_out, sat_stream_t stream) {
-    if (!logits || !targets || !row_loss || N < 1 || V < 1) return SAT_ERR_ARG;
+extern "C" int sat_ce_rows(float* logits, int64_t ldl, const int64_t* targets, int N, int V, float inv_denom,
+                           int write_grad, float* row_loss, float* loss_out, sat_stream_t stream) {
+    if (!logits || !targets || !row_loss || N < 1 || V < 1 || ldl < V) return SAT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ce_rows_kernel, dim3(N), dim3(256), 0, s, logits, targets, V, inv_denom, write_grad, row_loss);
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(N), dim3(256), 0, s, logits, (long)ldl, targets, V, inv_denom, write_grad, row_loss);
     SAT_LAUNCH_CHECK();
     if (loss_out) {
         hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, s, row_loss, N, inv_denom, loss_out);

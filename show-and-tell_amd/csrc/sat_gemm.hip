@@ -355,9 +355,13 @@ extern "C" int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t
     if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && slab_stride < (int64_t)M * ldc)) return SAT_ERR_ARG;
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return SAT_ERR_ARG;
     if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3)) return SAT_ERR_ARG;
-    if ((amode == 0 || bmode == 0) && (K & 3)) return SAT_ERR_ARG;   // 16-byte chunks run along K
-    if (amode == 2 && (M & 3)) return SAT_ERR_ARG;                   // ... along M
-    if (bmode == 1 && (N & 3)) return SAT_ERR_ARG;                   // ... along N
+    // 16-byte chunks run along K (k-contiguous operands), M (amode 2) or N (bmode 1).  A ragged last chunk is fine
+    // when the operand's rows are padded (ld >= the extent rounded up to 4) and the pad holds zeros.
+    const bool a_pad = lda >= ((amode == 0 ? (int64_t)K : (int64_t)M) + 3) / 4 * 4;
+    if (bmode == 0 && (K & 3)) return SAT_ERR_ARG;
+    if (amode == 0 && (K & 3) && !a_pad) return SAT_ERR_ARG;
+    if (amode == 2 && (M & 3) && !a_pad) return SAT_ERR_ARG;
+    if (bmode == 1 && (N & 3)) return SAT_ERR_ARG;
     GemmArgs a = {};
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.bias2 = bias2; a.stat_partial = nullptr;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;

@@ -179,16 +179,16 @@ extern "C" int sat_lstm_bwd(const float* dHS, const float* X, const float* w_ih,
 // ------------------------------------------------------------------------------------------------------
 // vocab projection + CE
 extern "C" int sat_vocab_logits_fwd(const float* Hs, const float* w, const float* b, int N, int H, int V,
-                                    float* logits, sat_stream_t stream) {
-    if (!Hs || !w || !b || !logits) return SAT_ERR_ARG;
-    return sat_gemm_f32(0, 0, Hs, H, w, H, logits, V, b, nullptr, N, V, H, stream);
+                                    float* logits, int64_t ldl, sat_stream_t stream) {
+    if (!Hs || !w || !b || !logits || ldl < V) return SAT_ERR_ARG;
+    return sat_gemm_f32(0, 0, Hs, H, w, H, logits, ldl, b, nullptr, N, V, H, stream);
 }
 
 extern "C" int sat_vocab_ce_fwd(const float* Hs, const float* w, const float* b, const int64_t* targets, int N,
-                                int H, int V, float inv_denom, int write_grad, float* logits, float* row_loss,
-                                float* loss_out, sat_stream_t stream) {
-    SAT_TRY(sat_vocab_logits_fwd(Hs, w, b, N, H, V, logits, stream));
-    return sat_ce_rows(logits, targets, N, V, inv_denom, write_grad, row_loss, loss_out, stream);
+                                int H, int V, float inv_denom, int write_grad, float* logits, int64_t ldl,
+                                float* row_loss, float* loss_out, sat_stream_t stream) {
+    SAT_TRY(sat_vocab_logits_fwd(Hs, w, b, N, H, V, logits, ldl, stream));
+    return sat_ce_rows(logits, ldl, targets, N, V, inv_denom, write_grad, row_loss, loss_out, stream);
 }
 
 static int vocab_bwd_split(int N, int H, int V) {
@@ -210,18 +210,19 @@ extern "C" int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t
                                    float* C, int64_t ldc, const float* bias, const float* bias2, int M, int N, int K,
                                    int ksplit, int64_t slab_stride, sat_stream_t stream);
 
-extern "C" int sat_vocab_ce_bwd(const float* dlogits, const float* Hs, const float* w, int N, int H, int V,
+extern "C" int sat_vocab_ce_bwd(const float* dlogits, int64_t ldl, const float* Hs, const float* w, int N, int H, int V,
                                 float* dw, float* db, float* dHs, float* workspace, int64_t ws_bytes,
                                 sat_stream_t stream) {
     if (!dlogits || !Hs || !w || !dw || !db || !dHs) return SAT_ERR_ARG;
-    if ((V & 3) || (H & 3)) return SAT_ERR_UNSUPPORTED;
+    // any V: the dlogits rows are padded to a multiple of 4 floats (ldl), pad columns must hold zeros
+    if ((H & 3) || (ldl & 3) || ldl < ((V + 3) & ~3)) return SAT_ERR_UNSUPPORTED;
     const int ks = vocab_bwd_split(N, H, V);
     if (ks > 1 && (!workspace || ws_bytes < sat_vocab_ce_bwd_ws_bytes(N, H, V))) return SAT_ERR_WORKSPACE;
     // dW[V,H] = dlogits^T * Hs ;  db = colsum(dlogits) ;  dHs[N,H] = dlogits * W
-    SAT_TRY(sat_gemm_f32(2, 1, dlogits, V, Hs, H, dw, H, nullptr, nullptr, V, H, N, stream));
-    SAT_TRY(sat_colsum_f32(dlogits, V, N, V, db, stream));
-    if (ks == 1) return sat_gemm_f32(0, 1, dlogits, V, w, H, dHs, H, nullptr, nullptr, N, H, V, stream);
-    SAT_TRY(sat_gemm_f32_splitk(0, 1, dlogits, V, w, H, workspace, H, nullptr, nullptr, N, H, V, ks, (int64_t)N * H, stream));
+    SAT_TRY(sat_gemm_f32(2, 1, dlogits, ldl, Hs, H, dw, H, nullptr, nullptr, V, H, N, stream));
+    SAT_TRY(sat_colsum_f32(dlogits, ldl, N, V, db, stream));
+    if (ks == 1) return sat_gemm_f32(0, 1, dlogits, ldl, w, H, dHs, H, nullptr, nullptr, N, H, V, stream);
+    SAT_TRY(sat_gemm_f32_splitk(0, 1, dlogits, ldl, w, H, workspace, H, nullptr, nullptr, N, H, V, ks, (int64_t)N * H, stream));
     if (((long)N * H) & 3) return SAT_ERR_UNSUPPORTED;
     return sat_sum_slabs_f32(workspace, ks, (int64_t)N * H, (int64_t)N * H, dHs, stream);
 }

@@ -194,14 +194,14 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
         tapes["X"].append(HS)
         inp = HS
     if logits is None:
-        logits = torch.empty(N, V, device=dev)
-    L.check(lib.sat_vocab_logits_fwd(L.ptr(inp), L.ptr(lin_w), L.ptr(lin_b), N, lin_w.shape[1], V, L.ptr(logits), st),
-            "sat_vocab_logits_fwd")
+        logits = torch.zeros(N, (V + 3) // 4 * 4, device=dev) if V % 4 else torch.empty(N, V, device=dev)
+    L.check(lib.sat_vocab_logits_fwd(L.ptr(inp), L.ptr(lin_w), L.ptr(lin_b), N, lin_w.shape[1], V, L.ptr(logits),
+                                     logits.stride(0), st), "sat_vocab_logits_fwd")
     return logits, tapes
 
 
 def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi, grads_out, on_stage=None):
-    """Backward of decoder_forward_tapes.  grads_out: dict name -> preallocated f32 tensor to fill:
+    """Backward of decoder_forward_tapes.  `dlogits`: f32 [N, ld] with ld = V rounded up to 4 and zero pad columns.  grads_out: dict name -> preallocated f32 tensor to fill:
     'embed', ('w_ih',l), ('w_hh',l), ('b_ih',l), ('b_hh',l), 'lin_w', 'lin_b', 'features'.
     on_stage(i) is called when gradient group i is final (0 vocab projection, 1 LSTM) -- the data-parallel
     wrapper launches that bucket's all-reduce there, under the remaining backward kernels."""
@@ -213,7 +213,7 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
     dH = torch.empty(N, Hl, device=dev)
     vwsb = lib.sat_vocab_ce_bwd_ws_bytes(N, Hl, V)
     vws = torch.empty(max(vwsb // 4, 4), device=dev)
-    L.check(lib.sat_vocab_ce_bwd(L.ptr(dlogits), L.ptr(Xtop), L.ptr(lin_w), N, Hl, V, L.ptr(grads_out["lin_w"]),
+    L.check(lib.sat_vocab_ce_bwd(L.ptr(dlogits), dlogits.stride(0), L.ptr(Xtop), L.ptr(lin_w), N, Hl, V, L.ptr(grads_out["lin_w"]),
                                  L.ptr(grads_out["lin_b"]), L.ptr(dH), L.ptr(vws), vwsb, st), "sat_vocab_ce_bwd")
     if on_stage is not None:
         on_stage(0)
@@ -248,13 +248,20 @@ class _DecoderFn(torch.autograd.Function):
         logits, tapes = decoder_forward_tapes(lib, features, embed_w, layers, lin_w, lin_b, captions, pi)
         ctx.tapes, ctx.pi, ctx.layers = tapes, pi, layers
         ctx.embed_w, ctx.lin_w = embed_w, lin_w
-        return logits
+        V = lin_w.shape[0]
+        return logits if logits.shape[1] == V else logits[:, :V]
 
     @staticmethod
     def backward(ctx, dlogits):
         lib = L.load()
         dev = dlogits.device
-        dlogits = dlogits.contiguous()
+        V = ctx.lin_w.shape[0]
+        if V % 4:                                  # rows padded to 4 floats, zero pad (sat_vocab_ce_bwd's layout)
+            padded = torch.zeros(dlogits.shape[0], (V + 3) // 4 * 4, device=dev)
+            padded[:, :V] = dlogits
+            dlogits = padded
+        else:
+            dlogits = dlogits.contiguous()
         layers = ctx.layers
         g = {"embed": torch.empty_like(ctx.embed_w), "lin_w": torch.empty_like(ctx.lin_w),
              "lin_b": torch.empty(ctx.lin_w.shape[0], device=dev),

@@ -114,7 +114,7 @@ class TrainStep:
             F = enc.resnet.feature_dim
             wsb = lib.sat_fc_bn1d_ws_bytes(B, F, E)
             bufs = self._bufs[key] = dict(
-                targets=torch.empty(N, dtype=torch.int64, device=dev), logits=torch.empty(N, V, device=dev),
+                targets=torch.empty(N, dtype=torch.int64, device=dev), logits=torch.zeros(N, (V + 3) // 4 * 4, device=dev),
                 row_loss=torch.empty(N, device=dev), feats=torch.empty(B, E, device=dev),
                 xhat=torch.empty(B, E, device=dev), rstd=torch.empty(E, device=dev),
                 head_ws=torch.empty(max(wsb // 4, B * E), device=dev), d_feat=torch.empty(B, E, device=dev))
@@ -141,7 +141,7 @@ class TrainStep:
                                               dec.linear.bias, captions[:, :-1], pi, logits=bufs["logits"])
         # ---- loss + d(loss)/d(logits) in place (train.py:143) ----
         loss_slot = flat.grads[flat.loss_slot:flat.loss_slot + 1]
-        L.check(lib.sat_ce_rows(L.ptr(logits), L.ptr(bufs["targets"]), N, V, float(inv_denom), 1,
+        L.check(lib.sat_ce_rows(L.ptr(logits), logits.stride(0), L.ptr(bufs["targets"]), N, V, float(inv_denom), 1,
                                 L.ptr(bufs["row_loss"]), L.ptr(loss_slot), st), "sat_ce_rows")
         # ---- backward (train.py:144): gradients land directly in the flat buffer ----
         g = {"embed": flat.grad("decoder.embed.weight"), "lin_w": flat.grad("decoder.linear.weight"),

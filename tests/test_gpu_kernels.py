@@ -282,7 +282,7 @@ def test_ce_rows_and_colsum(lib):
     rl, lo = torch.empty(N, device="cuda"), torch.empty(1, device="cuda")
     inv = 1.0 / 50.0
     tgd = cu(tgt)
-    L.check(lib.sat_ce_rows(L.ptr(ld), L.ptr(tgd), N, V, inv, 1, L.ptr(rl), L.ptr(lo), st()))
+    L.check(lib.sat_ce_rows(L.ptr(ld), V, L.ptr(tgd), N, V, inv, 1, L.ptr(rl), L.ptr(lo), st()))
     sync()
     lg = logits.double().requires_grad_(True)
     ref = F.cross_entropy(lg, tgt, reduction="sum") * inv

@@ -284,3 +284,50 @@ def test_resnet152_f32_matches_oracle_cfg1():
     pooled = enc.train().pooled_features(x.cuda())
     err = (pooled.cpu() - pooled_ref).abs().max().item()
     assert err < 2e-3 * max(1.0, pooled_ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("B,T,E,H,V,Lh", [(70, 9, 36, 40, 1003, 1), (5, 14, 32, 64, 300, 2), (1, 6, 32, 32, 64, 1),
+                                          (130, 5, 64, 128, 500, 1)])
+def test_decoder_odd_shapes_ragged_vs_oracle(B, T, E, H, V, Lh):
+    """edge cases the reference's collate_fn can produce: batch 1, batches larger than one 64-row chunk of the skinny
+    kernels, steeply ragged lengths (down to the minimum 2), vocab / hidden sizes that are not tile multiples"""
+    gen = torch.Generator().manual_seed(B * 131 + T)
+    params = OD.init_decoder_params(E, H, V, Lh, generator=gen)
+    lengths = sorted([int(x) for x in torch.randint(2, T + 1, (B,), generator=gen)], reverse=True)
+    lengths[0] = T
+    caps = torch.zeros(B, T, dtype=torch.long)
+    for b, l in enumerate(lengths):
+        caps[b, 0] = 1
+        if l > 2:
+            caps[b, 1:l - 1] = torch.randint(4, V, (l - 2,), generator=gen)
+        caps[b, l - 1] = 2
+    feats = torch.randn(B, E, generator=gen)
+    ref_loss, ref_grads, ref_dfeat, ref_logits = OT.decoder_loss_and_grads(params, feats, caps, lengths, Lh)
+    dec = sat.DecoderRNN(E, H, V, Lh)
+    dec.load_state_dict(params)
+    dec.cuda()
+    fd = feats.cuda().requires_grad_(True)
+    cd = caps.cuda()
+    targets, l1 = sat.pack_targets(cd, lengths)
+    out = dec(fd, cd[:, :-1], l1)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_logits.numpy(), rtol=0, atol=2e-5)
+    loss = torch.nn.functional.cross_entropy(out, targets)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    loss.backward()
+    np.testing.assert_allclose(fd.grad.cpu().numpy(), ref_dfeat.numpy(), rtol=2e-3, atol=2e-7)
+    for k, p in dec.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref_grads[k].numpy(), rtol=2e-3, atol=2e-7, err_msg=k)
+    ids = dec.eval().sample(feats.cuda(), None)
+    assert np.array_equal(ids.cpu().numpy(), OD.greedy_sample(params, feats, Lh).numpy())
+
+
+def test_decoder_rejects_bad_inputs():
+    dec = sat.DecoderRNN(32, 64, 100, 1).cuda()
+    f = torch.zeros(3, 32, device="cuda")
+    c = torch.zeros(3, 5, dtype=torch.long, device="cuda")
+    with pytest.raises(ValueError):
+        dec(f, c, [3, 5, 2])            # not sorted (pack_padded_sequence would raise too)
+    with pytest.raises(ValueError):
+        dec(f, c, [6, 6])               # wrong batch size
+    with pytest.raises(ValueError):
+        dec(f, c, [9, 3, 2])            # longer than captions + 1

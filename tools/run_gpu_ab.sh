@@ -1,6 +1,6 @@
 #!/bin/bash
 # helper for gpurun: quick A/B of conv kernel variants through bench.py (no CPU baseline)
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; mkdir -p gpurun_out
 for cfg in "$@"; do
   echo "== $cfg"
   env $cfg timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>gpurun_out/ab.err | python -c "

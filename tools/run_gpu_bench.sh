@@ -1,6 +1,6 @@
 #!/bin/bash
 # helper for gpurun: bench line + rocprofv3 kernel trace of the same command
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 cd $R
 timeout -k 10 600 python bench.py --steps ${STEPS:-20} --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
