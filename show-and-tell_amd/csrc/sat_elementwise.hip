@@ -736,6 +736,11 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
     // thread count a multiple of the chunks per pixel (channel chunk invariant per thread)
     const int cch = C / V;
     int grid = ew_grid(nch);
+    if (lds) {          // every workgroup derives the affine table first: fewer, fatter workgroups amortise that prologue
+        static int cap = 0;
+        if (cap == 0) { const char* e = getenv("SAT_BN_DERIVE_GRID"); cap = e ? atoi(e) : 768; if (cap < 1) cap = 768; }
+        if (grid > cap) grid = cap;
+    }
     if (cch > EW_BLOCK && (cch % EW_BLOCK) == 0) {
         const int g0 = cch / EW_BLOCK;
         grid = grid / g0 * g0;
