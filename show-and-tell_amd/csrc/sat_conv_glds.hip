@@ -39,6 +39,20 @@ struct ConvArgs {
     // whatever the arrival order; the consumer kernel (bn_act / maxpool) turns them into scale/shift itself, which
     // removes the separate finalize launch.  Used when there are few M-tiles (<= ~400 adds per word).
     long long* acc;
+    // Input-side fusion (1x1 convs): the A operand is the RAW output of the previous conv and its BatchNorm + ReLU is
+    // applied to each landed LDS stage in place, so the normalised tensor never exists in HBM.  The (scale, shift)
+    // table comes precomputed (in_scale/in_shift) or is derived here from the previous conv's integer sums (in_acc).
+    const float* in_scale;
+    const float* in_shift;
+    const long long* in_acc;      // [2][Cin], this step's parity
+    long long* in_acc_clear;      // other parity (cleared by workgroup 0) or NULL
+    const float* in_gamma;
+    const float* in_beta;
+    float* in_running_mean;
+    float* in_running_var;
+    double in_count;
+    float in_momentum, in_eps;
+    int in_affine;
     int dbg;                 // diagnostics only (SAT_CONV_DBG): 1 = no loads, 2 = no MFMA, 4 = no epilogue
 };
 // fixed-point scale of the atomic statistics is SAT_STAT_SCALE (sat_internal.h)
@@ -81,7 +95,9 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     constexpr int CROW = BN * 2 + 16;                      // bf16 C-tile row stride in LDS (epilogue)
     static_assert(BM * CROW + 4 * WGM * BN * 4 <= S * STAGE, "epilogue tile + stat scratch must fit the ring");
     static_assert(TM >= 1 && TN >= 1 && NAI >= 1 && NBI >= 1, "bad tile/wave split");
-    __shared__ __attribute__((aligned(16))) char smem[S * STAGE];
+    constexpr int TAB_BYTES = 2 * 512 * 4;                 // input-BN (scale, shift) table: up to 512 input channels
+    __shared__ __attribute__((aligned(16))) char smem[S * STAGE + TAB_BYTES];   // ONE LDS object (ring + table)
+    float* in_tab = (float*)(smem + S * STAGE);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -257,6 +273,60 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         for (int ks = 0; ks < 4; ++ks) b_off[j][ks] = A_BYTES + row * 128 + (((2 * ks + h) ^ ((row >> 1) & 7)) << 4);
     }
 
+    if (p.in_affine) {
+        // (scale, shift) of the input's BatchNorm for all Cin (= K) channels, into LDS
+        for (int c = tid; c < p.Cin; c += NT) {
+            float sc, sh;
+            if (p.in_acc) {
+                const double mean = (double)p.in_acc[c] / kStatScale / p.in_count;
+                double var = (double)p.in_acc[p.Cin + c] / kStatScale / p.in_count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float invstd = 1.0f / sqrtf((float)var + p.in_eps);
+                sc = p.in_gamma[c] * invstd;
+                sh = p.in_beta[c] - (float)mean * sc;
+                if (bid == 0) {
+                    if (p.in_running_mean) {
+                        const double unbiased = p.in_count > 1.0 ? var * p.in_count / (p.in_count - 1.0) : var;
+                        p.in_running_mean[c] = (float)((1.0 - p.in_momentum) * p.in_running_mean[c] + p.in_momentum * mean);
+                        p.in_running_var[c] = (float)((1.0 - p.in_momentum) * p.in_running_var[c] + p.in_momentum * unbiased);
+                    }
+                    if (p.in_acc_clear) { p.in_acc_clear[c] = 0; p.in_acc_clear[p.Cin + c] = 0; }
+                }
+            } else {
+                sc = p.in_scale[c];
+                sh = p.in_shift[c];
+            }
+            in_tab[c] = sc;
+            in_tab[p.Cin + c] = sh;
+        }
+        __syncthreads();          // nothing is in flight yet: a plain barrier (with its LDS wait) is fine here
+    }
+
+    // relu(x*scale + shift) on the A half of a landed stage, in place (rows past M stay zero)
+    auto affine_stage = [&](int buf, int kt) {
+        char* sA = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < BM * 8 / NT; ++j) {
+            const int q = tid + j * NT;
+            const int row = q >> 3, pos = q & 7;
+            if (m0 + row < p.M) {
+                const int c0 = kt * BK + ((pos ^ ((row >> 1) & 7)) << 3);      // channel of this chunk's first element
+                bf16x8 v = *(const bf16x8*)(sA + row * 128 + pos * 16);
+                const f32x4 s0 = *(const f32x4*)(in_tab + c0), s1 = *(const f32x4*)(in_tab + c0 + 4);
+                const f32x4 t0 = *(const f32x4*)(in_tab + p.Cin + c0), t1 = *(const f32x4*)(in_tab + p.Cin + c0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e], 0.0f);
+                    v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e], 0.0f);
+                }
+                *(bf16x8*)(sA + row * 128 + pos * 16) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes are done ...
+        __builtin_amdgcn_s_barrier();                         // ... and everybody's (raw barrier: the ring stays in flight)
+        asm volatile("" ::: "memory");
+    };
+
     auto compute = [&](int buf) {
         const char* st = smem + buf * STAGE;
 #pragma unroll
@@ -314,6 +384,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             int nbuf = buf + D;
             if (nbuf >= S) nbuf -= S;
             issue(nbuf);
+            if (p.in_affine) affine_stage(buf, kt);
             if (!(p.dbg & 2)) compute(buf);
             buf = (buf + 1 == S) ? 0 : buf + 1;
         }
@@ -452,6 +523,15 @@ ConvArgs make_args(const sat_op* op) {
     a.A = (const bf16_t*)op->in0; a.B = (const bf16_t*)op->w; a.C = (bf16_t*)op->out;
     a.stat_partial = op->stat_partial;
     a.acc = (long long*)op->stat_acc;
+    a.in_affine = 0;
+    if (op->scale0 || op->stat_acc1) {          // BatchNorm + ReLU of the INPUT fused into the A staging (1x1 convs)
+        a.in_affine = 1;
+        a.in_scale = op->scale0; a.in_shift = op->shift0;
+        a.in_acc = (const long long*)op->stat_acc1;
+        a.in_gamma = op->gamma1; a.in_beta = op->beta1;
+        a.in_running_mean = op->running_mean1; a.in_running_var = op->running_var1;
+        a.in_count = (double)op->count; a.in_momentum = op->momentum; a.in_eps = op->eps;
+    }
     a.M = op->N * op->Hout * op->Wout; a.N = op->Cout; a.K = op->KH * op->KW * op->Cin;
     a.ldb = a.K; a.ldc = op->Cout;
     a.Hin = op->Hin; a.Win = op->Win; a.Cin = op->Cin; a.Hout = op->Hout; a.Wout = op->Wout;
@@ -482,7 +562,19 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
     if (op->Cout % 8) return SAT_ERR_UNSUPPORTED;
     ConvArgs a = make_args(op);
     if (a.acc) a.acc += (long)parity * 2 * a.N;          // [2 parities][2][N]
-    const int v = (op->variant > 0 && op->variant <= kNumVariants) ? op->variant - 1 : heuristic_variant(a);
+    if (a.in_affine) {
+        if (!a.linear || a.Cin > 512 || (a.Cin % 64)) return SAT_ERR_UNSUPPORTED;
+        if (a.in_acc) {
+            if (!a.in_gamma || !a.in_beta || a.in_count < 1) return SAT_ERR_ARG;
+            long long* base = (long long*)op->stat_acc1;       // [2 parities][2][Cin]
+            a.in_acc = base + (long)parity * 2 * a.Cin;
+            a.in_acc_clear = base + (long)(1 - parity) * 2 * a.Cin;
+        } else if (!a.in_scale || !a.in_shift) {
+            return SAT_ERR_ARG;
+        }
+    }
+    int v = (op->variant > 0 && op->variant <= kNumVariants) ? op->variant - 1 : heuristic_variant(a);
+    if (a.in_affine && kVariants[v].spec) v = heuristic_variant(a);     // the in-LDS transform lives in the unified-wave loop
     return launch_variant(v, a, s);
 }
 
@@ -503,15 +595,27 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
         sat_op* op = ops + i;
         if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) continue;
         const Key key(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
-                      (op->stat_partial || op->stat_acc) ? 1 : 0);
+                      ((op->stat_partial || op->stat_acc) ? 1 : 0) + ((op->scale0 || op->stat_acc1) ? 2 : 0));
         auto it = cache.find(key);
         if (it != cache.end()) { op->variant = it->second; continue; }
         ConvArgs a = make_args(op);
         a.acc = nullptr;             // tuning launches must not touch the statistics / running buffers
+        if (a.in_affine) {           // ... nor derive from / clear the live accumulators: a neutral table stands in
+            static float* neutral = nullptr;
+            if (!neutral) {
+                if (hipMalloc((void**)&neutral, 1024 * sizeof(float)) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+                if (hipMemsetD32((hipDeviceptr_t)neutral, 0x3f800000, 512) != hipSuccess ||          // scale 1.0
+                    hipMemset(neutral + 512, 0, 512 * sizeof(float)) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+            }
+            a.in_acc = nullptr; a.in_acc_clear = nullptr; a.in_running_mean = nullptr;
+            a.in_scale = neutral; a.in_shift = neutral + 512;
+            if (!a.linear || a.Cin > 512 || (a.Cin % 64)) continue;
+        }
         float best = 1e30f;
         int best_v = heuristic_variant(a);
         for (int v = 0; v < kNumVariants; ++v) {
             if (kVariants[v].bn == 128 && a.N <= 64) continue;
+            if (kVariants[v].spec && a.in_affine) continue;
             float tmin = 1e30f;
             for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
                 if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }

@@ -211,6 +211,7 @@ class ConvStackProgram:
         atomic_stats = training and dtype == L.SAT_BF16 and ATOMIC_MAX_TILES > 0
         self._parity = 0
         bnref = {}
+        fuse_in_bn = dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_INPUT_BN", "1") != "0"   # bn2+ReLU inside conv3
         if atomic_stats:
             self.stat_acc = alloc((nbn, 2, 2, cmax), torch.int64, zero=True)
 
@@ -301,8 +302,22 @@ class ConvStackProgram:
             ops.append(std_conv(blk.conv2, self.a1, self.c2, N, h, w_, h2, w2))
             f, s2, t2 = fin_op(blk.bn2, planes, N * h2 * w2, tm2)
             add(f)
-            ops.append(act_op(L.OP_BN_RELU, self.c2, s2, t2, self.a2, N, h2, w2, planes))
-            ops.append(std_conv(blk.conv3, self.a2, self.c3, N, h2, w2, h2, w2))
+            if fuse_in_bn and planes <= 512 and planes % 64 == 0:
+                # conv3 reads the RAW c2 and applies bn2 + ReLU to its A operand in LDS: a2 never exists in HBM
+                cv3 = std_conv(blk.conv3, self.c2, self.c3, N, h2, w2, h2, w2)
+                ref = bnref.get(s2.data_ptr())
+                if ref is None:
+                    cv3.scale0, cv3.shift0 = s2.data_ptr(), t2.data_ptr()
+                else:
+                    acc2, bn2_, count2 = ref
+                    cv3.stat_acc1 = acc2
+                    cv3.gamma1, cv3.beta1 = bn2_.weight.data_ptr(), bn2_.bias.data_ptr()
+                    cv3.running_mean1, cv3.running_var1 = bn2_.running_mean.data_ptr(), bn2_.running_var.data_ptr()
+                    cv3.count, cv3.momentum, cv3.eps = count2, BN_MOMENTUM, BN_EPS
+                ops.append(cv3)
+            else:
+                ops.append(act_op(L.OP_BN_RELU, self.c2, s2, t2, self.a2, N, h2, w2, planes))
+                ops.append(std_conv(blk.conv3, self.a2, self.c3, N, h2, w2, h2, w2))
             f, s3, t3 = fin_op(blk.bn3, planes * 4, N * h2 * w2, tm2)
             add(f)
             if blk.downsample is not None:

@@ -392,3 +392,49 @@ def test_conv_atomic_stats_then_consumer_derives_affine(lib):
     sync()
     assert torch.equal(y1, y_first)
     assert int(acc[0].abs().sum()) == 0 and int(acc[1].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("derive", [False, True])
+@pytest.mark.parametrize("variant", [0, 1, 3, 6, 9])
+def test_conv1x1_with_input_bn_relu_fused(lib, derive, variant):
+    """1x1 bf16 conv whose A operand is relu(bn(x)) applied to the landed LDS stage: table precomputed or derived from
+    the producer's integer sums (which workgroup 0 then clears / folds into the running statistics)"""
+    N, H, W, Cin, Cout = 5, 12, 12, 128, 192
+    g = torch.Generator().manual_seed(97 + variant)
+    x = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
+    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).bfloat16()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    xf = x.float().reshape(-1, Cin).double()
+    M = xf.shape[0]
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
+    shift = (beta.double() - mean * scale.double()).float()
+    a = torch.clamp(x.float().reshape(-1, Cin) * scale + shift, min=0).bfloat16().float().double()    # what the LDS stage holds
+    ref = a @ w.float().double().t()
+    o, keep, _ = _conv_op(L.SAT_BF16, x.float(), w.float().reshape(Cout, 1, 1, Cin), 1, 0)
+    o.variant = variant
+    extra = []
+    if derive:
+        acc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
+        acc[0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
+        acc[0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
+        acc[1] = 777
+        gd, bd, rm, rv = cu(gamma), cu(beta), cu(torch.zeros(Cin)), cu(torch.ones(Cin))
+        o.stat_acc1, o.gamma1, o.beta1 = acc.data_ptr(), gd.data_ptr(), bd.data_ptr()
+        o.running_mean1, o.running_var1 = rm.data_ptr(), rv.data_ptr()
+        o.count, o.momentum, o.eps = M, 0.1, 1e-5
+        extra = [acc, gd, bd, rm, rv]
+    else:
+        sd, td = cu(scale), cu(shift)
+        o.scale0, o.shift0 = sd.data_ptr(), td.data_ptr()
+        extra = [sd, td]
+    L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+    sync()
+    out = keep[2].float().cpu().double()
+    assert (out - ref).abs().max().item() < 3e-2 + 4e-3 * ref.abs().max().item()
+    part = keep[3].cpu().double()
+    np.testing.assert_allclose(part[:, 0].sum(0).numpy(), ref.sum(0).numpy(), rtol=2e-3, atol=0.3)
+    if derive:
+        acc, _, _, rm, rv = extra
+        assert int(acc[1].abs().sum()) == 0
+        np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-4, atol=1e-6)
