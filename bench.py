@@ -44,9 +44,13 @@ def conv_only_time_ms(sat, model, images, reps=3):
     conv_ops = [prog.ops[i] for i in range(prog.n_ops) if prog.ops[i].kind == L.OP_CONV]
     arr = (L.SatOp * len(conv_ops))(*conv_ops)
     scratch = torch.zeros(2 * 2 * 2048, dtype=torch.int64, device=images.device)
+    ones, zeros = torch.ones(2048, device=images.device), torch.zeros(2048, device=images.device)
     for j in range(len(conv_ops)):            # same kernels incl. the BatchNorm-statistics epilogue, but the integer
-        if arr[j].stat_acc:                   # sums go to a scratch buffer, not into the model's live accumulators
+        if arr[j].stat_acc:                   # sums go to a scratch buffer, not into the model's live accumulators,
             arr[j].stat_acc = scratch.data_ptr()
+        if arr[j].stat_acc1:                  # and a fused input BatchNorm uses a neutral table instead of deriving
+            arr[j].stat_acc1 = None           # from (and clearing) the live ones
+            arr[j].scale0, arr[j].shift0 = ones.data_ptr(), zeros.data_ptr()
     lib = L.load()
     prog.run(images)                                   # fills the activation buffers with real data
     L.check(lib.sat_run_ops(arr, len(conv_ops), L.stream()))

@@ -87,3 +87,32 @@ def bench_conv(shapes=None, reps=20):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "conv":
     bench_conv()
+
+
+def bench_conv_inbn(reps=20):
+    """conv3 of layer 3 (M=12544, N=1024, K=256) with and without the fused input BatchNorm+ReLU, every variant"""
+    lib = L.load()
+    N, H, W, Cin, Cout = 64, 14, 14, 256, 1024
+    x = torch.randn(N, H, W, Cin, device="cuda").bfloat16()
+    w = (torch.randn(Cout, Cin, device="cuda") / 16).bfloat16()
+    out = torch.empty(N * H * W, Cout, device="cuda", dtype=torch.bfloat16)
+    tiles = lib.sat_conv_tiles_m(N * H * W)
+    part = torch.empty(tiles, 2, Cout, device="cuda")
+    sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
+    for fused in (0, 1):
+        for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+            o = L.SatOp()
+            o.kind, o.dtype = L.OP_CONV, L.SAT_BF16
+            o.in0, o.w, o.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+            o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, H, W, Cout
+            o.KH, o.KW, o.stride, o.pad = 1, 1, 1, 0
+            o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
+            o.stat_partial, o.tiles_m, o.variant = part.data_ptr(), tiles, v
+            if fused:
+                o.scale0, o.shift0 = sc.data_ptr(), sh.data_ptr()
+            ops = (L.SatOp * 1)(o)
+            print("conv3 fused=%d variant %2d: %.1f us" % (fused, v, time_ops(ops, 1, reps)))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "inbn":
+    bench_conv_inbn()
