@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 3
+#define SAT_ABI_VERSION 4
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -103,6 +103,14 @@ typedef struct sat_op {
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
 /* same, with the step parity (0/1) that selects the half of every stat_acc buffer in use */
 int sat_run_ops_parity(const sat_op* ops /*[host]*/, int n_ops, int parity, sat_stream_t stream);
+/* The same program as ONE hipGraph launch (the reference's `self.resnet(images)` issues ~1500 eager kernels per
+ * forward, models.py:27; here the host enqueues one graph).  sat_graph_create records ops[0..n) for the given step
+ * parity on an internal capture stream (nothing executes) and instantiates it; all pointers and shapes in ops[] are
+ * frozen into the graph.  sat_graph_launch replays it on `stream`; sat_graph_destroy frees it.  No host sync. */
+typedef struct sat_graph sat_graph;
+int sat_graph_create(const sat_op* ops /*[host]*/, int n_ops, int parity, sat_graph** graph_out);
+int sat_graph_launch(sat_graph* graph, sat_stream_t stream);
+int sat_graph_destroy(sat_graph* graph);
 /* conv + batch-stat finalize + normalise/ReLU as one call (three ops) -- `conv -> bn -> relu` of a bottleneck */
 int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, const sat_op* bnrelu, sat_stream_t stream);
 /* rows of SAT_OP_CONV partials the conv kernel writes for M output pixels */

@@ -42,6 +42,9 @@ SIGNATURES = {
     "sat_gemm_f32": (_i, [_i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
     "sat_run_ops": (_i, [C.POINTER(SatOp), _i, _vp]),
     "sat_run_ops_parity": (_i, [C.POINTER(SatOp), _i, _i, _vp]),
+    "sat_graph_create": (_i, [C.POINTER(SatOp), _i, _i, C.POINTER(_vp)]),
+    "sat_graph_launch": (_i, [_vp, _vp]),
+    "sat_graph_destroy": (_i, [_vp]),
     "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
     "sat_conv_tiles_m": (_i, [_i64]),
     "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp]),
@@ -88,7 +91,7 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.sat_version() != 3:
+        if lib.sat_version() != 4:
             raise RuntimeError("libsat_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -42,6 +42,52 @@ extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_
     return SAT_OK;
 }
 
+struct sat_graph {
+    hipGraphExec_t exec;
+};
+
+extern "C" int sat_graph_create(const sat_op* ops, int n_ops, int parity, sat_graph** graph_out) {
+    if (!ops || n_ops <= 0 || !graph_out || (parity != 0 && parity != 1)) return SAT_ERR_ARG;
+    *graph_out = nullptr;
+    hipStream_t cs = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        hipStreamDestroy(cs);
+        return (int)e;
+    }
+    const int rc = sat_run_ops_parity(ops, n_ops, parity, (sat_stream_t)cs);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(cs, &g);           // always end the capture, also after a failed launch
+    hipStreamDestroy(cs);
+    if (rc != SAT_OK || e != hipSuccess || !g) {
+        if (g) hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return rc != SAT_OK ? rc : (e != hipSuccess ? (int)e : SAT_ERR_UNSUPPORTED);
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return (int)e;
+    sat_graph* out = new sat_graph;
+    out->exec = exec;
+    *graph_out = out;
+    return SAT_OK;
+}
+
+extern "C" int sat_graph_launch(sat_graph* graph, sat_stream_t stream) {
+    if (!graph || !graph->exec) return SAT_ERR_ARG;
+    return (int)hipGraphLaunch(graph->exec, (hipStream_t)stream);
+}
+
+extern "C" int sat_graph_destroy(sat_graph* graph) {
+    if (!graph) return SAT_ERR_ARG;
+    hipError_t e = graph->exec ? hipGraphExecDestroy(graph->exec) : hipSuccess;
+    delete graph;
+    return (int)e;
+}
+
 extern "C" int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, const sat_op* bnrelu,
                                     sat_stream_t stream) {
     if (!conv || !finalize || !bnrelu) return SAT_ERR_ARG;

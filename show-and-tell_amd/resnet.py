@@ -336,6 +336,9 @@ class ConvStackProgram:
         self.final_map = (y, N, geo[-1][2], geo[-1][3], stack.feature_dim)
         self.ops = (L.SatOp * len(ops))(*ops)
         self.n_ops = len(ops)
+        # replay as a hipGraph (SAT_GRAPH=0: eager launches).  Per step parity: first run eager, then captured.
+        self._use_graph = os.environ.get("SAT_GRAPH", "1") != "0" and torch.device(device).type == "cuda"
+        self._runs, self._graphs = [0, 0], [None, None]
         # build-time kernel selection per conv geometry (bf16): time every variant on this program's own buffers
         if dtype == L.SAT_BF16 and os.environ.get("SAT_AUTOTUNE", "1") != "0" and torch.device(device).type == "cuda":
             for t in (self.c0, self.c1, self.a1, self.c2, self.a2, self.c3, self.cd, *self.ybuf):
@@ -343,14 +346,35 @@ class ConvStackProgram:
             L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 5, L.stream()), "sat_conv_autotune")
             torch.cuda.synchronize()
 
+    def __del__(self):
+        for g in getattr(self, "_graphs", ()):
+            if g is not None:
+                try:
+                    L.load().sat_graph_destroy(g)
+                except Exception:
+                    pass
+
     def run(self, images):
         """images f32 [N,3,H,W] NCHW on the device -> pooled f32 [N, feature_dim] (owned by the program)."""
         L.require_gpu(images, "images")
         if images.dtype != torch.float32 or tuple(images.shape) != (self.N, 3, self.H, self.W):
             raise ValueError("images must be float32 [%d,3,%d,%d]" % (self.N, self.H, self.W))
         images = images.contiguous()
-        self.ops[self._prep_index].in0 = images.data_ptr()
-        L.check(L.load().sat_run_ops_parity(self.ops, self.n_ops, self._parity, L.stream()), "sat_run_ops")
+        lib, p = L.load(), self._parity
+        self.ops[0].in0 = images.data_ptr()
+        if not self._use_graph or self._runs[p] == 0:
+            L.check(lib.sat_run_ops_parity(self.ops, self.n_ops, p, L.stream()), "sat_run_ops")
+        else:
+            # image prep reads the caller's tensor (a new pointer every batch) -> eager; everything after it only
+            # touches the program's own buffers -> one hipGraph per step parity, captured on this parity's 2nd run
+            if self._graphs[p] is None:
+                tail = (L.SatOp * (self.n_ops - 1))(*list(self.ops)[1:])
+                g = C.c_void_p()
+                L.check(lib.sat_graph_create(tail, self.n_ops - 1, p, C.byref(g)), "sat_graph_create")
+                self._graphs[p] = g
+            L.check(lib.sat_run_ops_parity(self.ops, 1, p, L.stream()), "sat_run_ops")
+            L.check(lib.sat_graph_launch(self._graphs[p], L.stream()), "sat_graph_launch")
+        self._runs[p] += 1
         self._parity ^= 1
         if self.training:
             self.stack._nbt_flat += 1
