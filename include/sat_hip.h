@@ -201,6 +201,24 @@ int sat_embed_rows(const float* embed, const int64_t* ids, int64_t ids_stride, i
                    float* out, sat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Beam decode (the reference has only a stub, model2.py:113-114, next to the greedy loop
+ * models.py:56-67).  Rows are (image b, hypothesis k) = b*K + k, K <= 8.
+ * sat_beam_step: candidates (k, v) score scores_in[b,k] + log_softmax(logits[b*K+k])[v]; the best K of the K*V per
+ *   image (ties: lower k*V+v) give parent[b,r] (k), token[b,r] (v), scores_out[b,r], r best-first.  A hypothesis with
+ *   scores_in = -inf is dead.  last_tokens/end_id (NULL / <0 to disable): a hypothesis whose last token is end_id
+ *   only continues with end_id, at unchanged score.
+ * sat_beam_gather_rows: dst[b*K+k] = src[b*K+parent[b,k]] (LSTM h/c re-ordering), width floats per row, dst != src.
+ * sat_beam_backtrack: parents/tokens [T][B*K] back-pointers -> ids [B*K][T].
+ */
+int sat_beam_step(const float* logits /*[B*K, ldl]*/, int64_t ldl, const float* scores_in /*[B*K]*/,
+                  const int64_t* last_tokens /*[B*K] or NULL*/, int64_t end_id, int B, int K, int V,
+                  int32_t* parent /*[B*K]*/, int64_t* token /*[B*K]*/, float* scores_out /*[B*K]*/, sat_stream_t stream);
+int sat_beam_gather_rows(const float* src, const int32_t* parent, int B, int K, int width, float* dst,
+                         sat_stream_t stream);
+int sat_beam_backtrack(const int32_t* parents, const int64_t* tokens, int T, int B, int K, int64_t* ids,
+                       sat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * clip_gradient (train.py:88-91) + optim.Adam step (train.py:56,146) over one flat buffer.
  * clip <= 0 disables the clamp.  step is the 1-based Adam step count.
  */

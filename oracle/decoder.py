@@ -170,6 +170,56 @@ def greedy_sample(params, features, num_layers=1, steps=20, states=None):
     return torch.stack(ids, 1)
 
 
+def beam_search(params, features, beam_size=5, num_layers=1, steps=20, end_id=None):
+    """Beam decode.  The reference only has a stub (`model2.py:113-114` `sample_beam: pass`), so this is
+    the textbook algorithm laid over `models.py:56-67`'s loop -- PARITY UNPINNED by the reference, except that
+    beam_size=1 with end_id=None must reproduce `greedy_sample` (pinned by the G1/G3/G5 greedy goldens).
+
+    Per image: `beam_size` hypotheses; step 0 feeds the image feature (all hypotheses identical, only hypothesis 0
+    live); every step scores candidate (k, v) as score[k] + log_softmax(logits[k])[v] and keeps the best
+    `beam_size` of the K*V candidates (ties: lower k*V+v first), re-ordering the LSTM state by parent.
+    end_id: a hypothesis whose last token is end_id is finished -- it only extends with end_id at no cost.
+    Returns (ids [B,K,steps] int64 sorted best-first, scores [B,K] f32)."""
+    B, K = features.shape[0], beam_size
+    V = params["linear.weight"].shape[0]
+    rep = lambda t: t.repeat_interleave(K, 0)
+    hs, cs = [], []
+    for l in range(num_layers):
+        H = params["lstm.weight_hh_l%d" % l].shape[1]
+        hs.append(torch.zeros(B * K, H))
+        cs.append(torch.zeros(B * K, H))
+    scores = torch.full((B, K), float("-inf"))
+    scores[:, 0] = 0.0
+    x = rep(features)
+    seqs = torch.zeros(B, K, 0, dtype=torch.int64)
+    last = None
+    for _ in range(steps):
+        inp = x
+        for l in range(num_layers):
+            xg = inp @ params["lstm.weight_ih_l%d" % l].t() + params["lstm.bias_ih_l%d" % l] + params["lstm.bias_hh_l%d" % l]
+            hs[l], cs[l], _ = lstm_cell(xg, hs[l], cs[l], params["lstm.weight_hh_l%d" % l])
+            inp = hs[l]
+        logits = inp @ params["linear.weight"].t() + params["linear.bias"]
+        logp = torch.log_softmax(logits, dim=1).view(B, K, V)
+        cand = scores.unsqueeze(2) + logp
+        if end_id is not None and last is not None:
+            fin = last == end_id                                     # [B,K]
+            frozen = torch.full((B, K, V), float("-inf"))
+            frozen[:, :, end_id] = scores
+            cand = torch.where(fin.unsqueeze(2), frozen, cand)
+        cand = cand.view(B, K * V)
+        order = torch.sort(cand, dim=1, descending=True, stable=True)[1][:, :K]     # stable: lower flat index first
+        scores = torch.gather(cand, 1, order)
+        parent, token = order // V, order % V
+        rows = (torch.arange(B).unsqueeze(1) * K + parent).reshape(-1)
+        hs = [h[rows] for h in hs]
+        cs = [c[rows] for c in cs]
+        seqs = torch.cat([torch.gather(seqs, 1, parent.unsqueeze(2).expand(B, K, seqs.shape[2])), token.unsqueeze(2)], 2)
+        last = token
+        x = params["embed.weight"][token.reshape(-1)]
+    return seqs, scores
+
+
 def init_decoder_params(embed_size, hidden_size, vocab_size, num_layers, generator=None):
     """Reference init (models.py:35-45): embed U(-.1,.1); LSTM torch default U(+-1/sqrt(H)); linear W U(-.1,.1), b=0."""
     g = generator

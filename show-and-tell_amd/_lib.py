@@ -69,6 +69,9 @@ SIGNATURES = {
     "sat_vocab_argmax_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_embed_rows": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "sat_beam_step": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sat_beam_gather_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sat_beam_backtrack": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_clamp_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
     "sat_colsum_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "sat_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),

@@ -1,0 +1,217 @@
+// Beam decode helpers (the reference has a stub only, model2.py:113-114; greedy loop models.py:56-67).
+// One decode step per image = log-softmax of K rows of logits + top-K over the K*V candidates + LSTM state
+// re-ordering by parent; the sequences are recovered at the end by walking the (parent, token) back-pointers.
+// HBM-bound byte/compare work: one workgroup per image streams its K rows of logits twice (max+sum, select).
+#include "sat_internal.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int KMAX = 8;   // beam width limit (thread-local candidate lists live in registers)
+
+// a better than b: higher score, ties -> lower flat candidate index (k*V + v)
+__device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
+
+__device__ __forceinline__ float block_reduce256(float v, bool is_max, float* sh) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logits, long ldl,
+                                                        const float* __restrict__ scores_in,
+                                                        const int64_t* __restrict__ last_tok, long end_id, int K, int V,
+                                                        int* __restrict__ parent, int64_t* __restrict__ token,
+                                                        float* __restrict__ scores_out) {
+    __shared__ float sh[4];
+    __shared__ float s_lse[KMAX], s_base[KMAX];
+    __shared__ int s_frozen[KMAX];
+    __shared__ float s_rv[4];
+    __shared__ int s_ri[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // ---- phase 1: log-sum-exp of every live row ----
+    for (int k = 0; k < K; ++k) {
+        const float base = scores_in[b * K + k];
+        const bool frozen = last_tok != nullptr && end_id >= 0 && last_tok[b * K + k] == end_id;
+        float lse = 0.0f;
+        if (base != -INFINITY && !frozen) {           // uniform across the block
+            const float* x = logits + (long)(b * K + k) * ldl;
+            float m = -INFINITY;
+            for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
+            m = block_reduce256(m, true, sh);
+            float s = 0.0f;
+            for (int i = tid; i < V; i += 256) s += expf(x[i] - m);
+            s = block_reduce256(s, false, sh);
+            lse = m + logf(s);
+        }
+        if (tid == 0) {
+            s_lse[k] = lse;
+            s_base[k] = base;
+            s_frozen[k] = frozen ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: thread-local best KMAX candidates, kept sorted (score desc, index asc) ----
+    float val[KMAX];
+    int idx[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        val[j] = -INFINITY;
+        idx[j] = INT_MAX;
+    }
+    for (int k = 0; k < K; ++k) {
+        const float base = s_base[k];
+        if (base == -INFINITY) continue;
+        const float* x = logits + (long)(b * K + k) * ldl;
+        if (s_frozen[k]) {
+            // a finished hypothesis has one continuation: end_id again, score unchanged
+            if (tid == (int)(end_id % 256) && end_id < V) {
+                float cv = base;
+                int ci = k * V + (int)end_id;
+                bool shifted = false;
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) {
+                    const bool sw = shifted || cv > val[j];
+                    const float tv = val[j];
+                    const int ti = idx[j];
+                    if (sw) {
+                        val[j] = cv;
+                        idx[j] = ci;
+                        cv = tv;
+                        ci = ti;
+                    }
+                    shifted = sw;
+                }
+            }
+            continue;
+        }
+        const float lse = s_lse[k];
+        for (int i = tid; i < V; i += 256) {
+            float cv = base + (x[i] - lse);
+            if (!(cv > val[KMAX - 1])) continue;     // visited in increasing flat index: ties keep the earlier one
+            int ci = k * V + i;
+            bool shifted = false;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                const bool sw = shifted || cv > val[j];
+                const float tv = val[j];
+                const int ti = idx[j];
+                if (sw) {
+                    val[j] = cv;
+                    idx[j] = ci;
+                    cv = tv;
+                    ci = ti;
+                }
+                shifted = sw;
+            }
+        }
+    }
+    // ---- phase 3: K rounds of block arg-best over the threads' list heads; the winner pops its head ----
+    for (int r = 0; r < K; ++r) {
+        float bv = val[0];
+        int bi = idx[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(ov, oi, bv, bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            s_rv[tid >> 6] = bv;
+            s_ri[tid >> 6] = bi;
+        }
+        __syncthreads();
+        bv = s_rv[0];
+        bi = s_ri[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (better(s_rv[w], s_ri[w], bv, bi)) {
+                bv = s_rv[w];
+                bi = s_ri[w];
+            }
+        if (idx[0] == bi && bi != INT_MAX) {          // candidate indices are unique across threads
+#pragma unroll
+            for (int j = 0; j + 1 < KMAX; ++j) {
+                val[j] = val[j + 1];
+                idx[j] = idx[j + 1];
+            }
+            val[KMAX - 1] = -INFINITY;
+            idx[KMAX - 1] = INT_MAX;
+        }
+        if (tid == 0) {
+            const bool ok = bi != INT_MAX;
+            parent[b * K + r] = ok ? bi / V : 0;
+            token[b * K + r] = ok ? bi % V : 0;
+            scores_out[b * K + r] = ok ? bv : -INFINITY;
+        }
+    }
+}
+
+// dst row (b,k) = src row (b, parent[b,k]); W floats per row
+__global__ __launch_bounds__(256) void beam_gather_kernel(const float* __restrict__ src, const int* __restrict__ parent, int K,
+                                                          int W, long total, float* __restrict__ dst) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / W;
+        const int col = (int)(i - row * W);
+        const long b = row / K;
+        dst[i] = src[(b * K + parent[row]) * W + col];
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_backtrack_kernel(const int* __restrict__ parents, const int64_t* __restrict__ tokens,
+                                                             int T, int BK, int K, int64_t* __restrict__ ids) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= BK) return;
+    const int b = row / K;
+    int cur = row - b * K;
+    for (int t = T - 1; t >= 0; --t) {
+        const long at = (long)t * BK + b * K + cur;
+        ids[(long)row * T + t] = tokens[at];
+        cur = parents[at];
+    }
+}
+
+}  // namespace
+
+extern "C" int sat_beam_step(const float* logits, int64_t ldl, const float* scores_in, const int64_t* last_tokens,
+                             int64_t end_id, int B, int K, int V, int32_t* parent, int64_t* token, float* scores_out,
+                             sat_stream_t stream) {
+    if (!logits || !scores_in || !parent || !token || !scores_out) return SAT_ERR_ARG;
+    if (B <= 0 || K <= 0 || V <= 0 || ldl < V) return SAT_ERR_ARG;
+    if (K > KMAX || (long)K * V > INT_MAX - 1) return SAT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, scores_in,
+                       last_tokens, (long)end_id, K, V, parent, token, scores_out);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_beam_gather_rows(const float* src, const int32_t* parent, int B, int K, int width, float* dst,
+                                    sat_stream_t stream) {
+    if (!src || !parent || !dst || src == dst) return SAT_ERR_ARG;
+    if (B <= 0 || K <= 0 || width <= 0) return SAT_ERR_ARG;
+    const long total = (long)B * K * width;
+    int grid = sat_cdiv(total, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(beam_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, parent, K, width, total, dst);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_beam_backtrack(const int32_t* parents, const int64_t* tokens, int T, int B, int K, int64_t* ids,
+                                  sat_stream_t stream) {
+    if (!parents || !tokens || !ids) return SAT_ERR_ARG;
+    if (T <= 0 || B <= 0 || K <= 0) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(beam_backtrack_kernel, dim3(sat_cdiv((long)B * K, 256)), dim3(256), 0, (hipStream_t)stream, parents,
+                       tokens, T, B * K, K, ids);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}

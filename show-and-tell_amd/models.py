@@ -351,6 +351,64 @@ class DecoderRNN(nn.Module):
             x = xe
         return ids
 
+    @torch.no_grad()
+    def sample_beam(self, features, beam_size=5, end_id=None, steps=20, return_all=False):
+        """Beam search over the same 20-step loop (`model2.py:113-114` is a stub in the reference).
+        Returns the best hypothesis per image, i64 [B,steps]; with return_all also (ids [B,K,steps] best-first,
+        scores [B,K] = sum of token log-probabilities).  beam_size=1, end_id=None is exactly `sample`.
+        end_id (eval.py's `<end>`, id 2): a finished hypothesis only repeats end_id at no cost."""
+        lib = L.load()
+        features = _f32c(features, "features")
+        dev = features.device
+        B, K = features.shape[0], int(beam_size)
+        if K < 1 or K > 8:
+            raise ValueError("beam_size must be in 1..8")
+        H, V, E = self.hidden_size, self.vocab_size, self.embed_size
+        st, R = L.stream(), B * K
+        h = [torch.zeros(R, H, device=dev) for _ in range(self.num_layers)]
+        c = [torch.zeros(R, H, device=dev) for _ in range(self.num_layers)]
+        h2 = [torch.empty(R, H, device=dev) for _ in range(self.num_layers)]
+        c2 = [torch.empty(R, H, device=dev) for _ in range(self.num_layers)]
+        ldl = (V + 3) // 4 * 4
+        logits = torch.zeros(R, ldl, device=dev)
+        scores = torch.full((B, K), float("-inf"), device=dev)
+        scores[:, 0] = 0.0                       # step 0: K identical rows per image, only hypothesis 0 is live
+        scores2 = torch.empty(B, K, device=dev)
+        parents = torch.empty(steps, R, dtype=torch.int32, device=dev)
+        tokens = torch.empty(steps, R, dtype=torch.int64, device=dev)
+        x = features.repeat_interleave(K, 0).contiguous()
+        xe = torch.empty(R, E, device=dev)
+        eid = -1 if end_id is None else int(end_id)
+        for i in range(steps):
+            inp = x
+            for l in range(self.num_layers):
+                w_ih, w_hh, b_ih, b_hh = self.lstm.layer(l)
+                L.check(lib.sat_lstm_step(L.ptr(inp), L.ptr(h[l]), L.ptr(c[l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih),
+                                          L.ptr(b_hh), R, w_ih.shape[1], H, L.ptr(h2[l]), st), "sat_lstm_step")
+                h[l], h2[l] = h2[l], h[l]
+                inp = h[l]
+            L.check(lib.sat_vocab_logits_fwd(L.ptr(inp), L.ptr(self.linear.weight), L.ptr(self.linear.bias), R, H, V,
+                                             L.ptr(logits), ldl, st), "sat_vocab_logits_fwd")
+            last = tokens[i - 1].data_ptr() if (i > 0 and eid >= 0) else None
+            L.check(lib.sat_beam_step(L.ptr(logits), ldl, L.ptr(scores), last, eid, B, K, V, parents[i].data_ptr(),
+                                      tokens[i].data_ptr(), L.ptr(scores2), st), "sat_beam_step")
+            scores, scores2 = scores2, scores
+            if K > 1:
+                for l in range(self.num_layers):
+                    L.check(lib.sat_beam_gather_rows(L.ptr(h[l]), parents[i].data_ptr(), B, K, H, L.ptr(h2[l]), st),
+                            "sat_beam_gather_rows")
+                    L.check(lib.sat_beam_gather_rows(L.ptr(c[l]), parents[i].data_ptr(), B, K, H, L.ptr(c2[l]), st),
+                            "sat_beam_gather_rows")
+                    h[l], h2[l], c[l], c2[l] = h2[l], h[l], c2[l], c[l]
+            L.check(lib.sat_embed_rows(L.ptr(self.embed.weight), tokens[i].data_ptr(), 1, R, E, V, L.ptr(xe), st),
+                    "sat_embed_rows")
+            x = xe
+        ids = torch.empty(B, K, steps, dtype=torch.int64, device=dev)
+        L.check(lib.sat_beam_backtrack(L.ptr(parents), L.ptr(tokens), steps, B, K, L.ptr(ids), st), "sat_beam_backtrack")
+        if return_all:
+            return ids, scores
+        return ids[:, 0].contiguous()
+
 
 class ShowAndTell(nn.Module):
     """Encoder + decoder behind the reference trainer's single-module call contract (train.py:37,139;

@@ -172,6 +172,52 @@ class TrainStep:
                                              self.eps, float(self.grad_clip), self.step_count, L.stream()),
                 "sat_clamp_adam_step")
 
+    # -- optimizer checkpoint interchange (the reference's load_optimizer is an empty stub, ------
+    #    train.py:60-64, and only model.state_dict() is saved, train.py:191-193) ---------------------------
+    def _trainable(self):
+        """(name, param) in the order train.py:55 hands them to optim.Adam: model.parameters() with requires_grad"""
+        return [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+
+    def optimizer_state_dict(self):
+        """The flat Adam state in `torch.optim.Adam.state_dict()` layout (loads into a torch Adam built over
+        `filter(requires_grad, model.parameters())` and back)."""
+        f, state, names = self.flat, {}, []
+        for i, (name, p) in enumerate(self._trainable()):
+            o, n, shape = f.slices[name]
+            names.append(name)
+            if self.step_count > 0:
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": f.m[o:o + n].view(shape).clone(),
+                            "exp_avg_sq": f.v[o:o + n].view(shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group], "param_names": names, "grad_clip": self.grad_clip}
+
+    def load_optimizer_state_dict(self, sd):
+        f, trainable = self.flat, self._trainable()
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(trainable):
+            raise ValueError("optimizer state has %d parameters, model has %d trainable"
+                             % (len(group["params"]), len(trainable)))
+        self.lr, self.betas, self.eps = float(group["lr"]), tuple(group["betas"]), float(group["eps"])
+        steps = set()
+        f.m.zero_()
+        f.v.zero_()
+        for i, (name, p) in enumerate(trainable):
+            st = sd["state"].get(group["params"][i])
+            if st is None:
+                continue
+            o, n, shape = f.slices[name]
+            if tuple(st["exp_avg"].shape) != shape:
+                raise ValueError("optimizer state of %s has shape %s, expected %s" % (name, tuple(st["exp_avg"].shape), shape))
+            f.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            f.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter Adam step counts differ (%s): one flat step count is kept" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+
     # -- single-GPU convenience ----------------------------------------------------------------------
     def step(self, images, captions, lengths, lr=None):
         """One whole iteration; returns the mean-CE loss as a 1-element device tensor (no host sync)."""

@@ -122,6 +122,63 @@ def test_greedy_decode_ids_bit_exact(golden_dir, name):
     assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])
 
 
+@pytest.mark.parametrize("name", ["G1_dec_fwd_bwd_small.npz", "G3_dec_cfg1_summary.npz", "G5_dec_L2.npz"])
+def test_beam_width_one_reproduces_golden_greedy_ids(golden_dir, name):
+    """sample_beam has no reference counterpart (model2.py:113-114 is a stub); width 1 must be the pinned greedy ids"""
+    g = load(golden_dir, name)
+    dec, params, (E, H, V, Lh, B, T) = golden_setup(g)
+    ids = dec.eval().sample_beam(torch.from_numpy(g["features"]).cuda(), beam_size=1)
+    assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])
+
+
+@pytest.mark.parametrize("name,K,end_id", [("G1_dec_fwd_bwd_small.npz", 5, None), ("G5_dec_L2.npz", 3, None),
+                                           ("G1_dec_fwd_bwd_small.npz", 4, "auto"), ("G3_dec_cfg1_summary.npz", 5, 2)])
+def test_beam_search_matches_oracle(golden_dir, name, K, end_id):
+    g = load(golden_dir, name)
+    dec, params, (E, H, V, Lh, B, T) = golden_setup(g)
+    feats = torch.from_numpy(g["features"])
+    if end_id == "auto":                   # a token the search really emits, so finished hypotheses occur
+        end_id = int(OD.beam_search(params, feats, K, Lh)[0][0, 0, 2])
+    ref_ids, ref_scores = OD.beam_search(params, feats, K, Lh, end_id=end_id)
+    ids, scores = dec.eval().sample_beam(feats.cuda(), beam_size=K, end_id=end_id, return_all=True)
+    assert ids.shape == (B, K, 20) and ids.dtype == torch.int64
+    assert np.array_equal(ids.cpu().numpy(), ref_ids.numpy())
+    np.testing.assert_allclose(scores.cpu().numpy(), ref_scores.numpy(), rtol=0, atol=1e-4)
+    best = dec.sample_beam(feats.cuda(), beam_size=K, end_id=end_id)
+    assert torch.equal(best, ids[:, 0])
+
+
+def test_beam_step_ties_dead_and_finished_hypotheses():
+    """sat_beam_step on hand-made logits: exact ties resolve to the lower k*V+v, -inf hypotheses never win,
+    a finished hypothesis continues only with end_id at unchanged score"""
+    from importlib import import_module
+    L = import_module("show-and-tell_amd._lib")
+    lib = L.load()
+    B, K, V = 2, 3, 700
+    logits = torch.zeros(B * K, V, device="cuda")                 # uniform rows: log-prob = -log(V) everywhere
+    logits[4, 650] = 3.0                                          # image 1, hypothesis 1: one clear winner
+    scores = torch.tensor([[0.0, 0.0, float("-inf")], [-1.0, -1.0, -0.5]], device="cuda")
+    last = torch.tensor([5, 6, 7, 9, 8, 2], device="cuda")        # image 1 / hypothesis 2 ended (end_id 2)
+    parent = torch.empty(B * K, dtype=torch.int32, device="cuda")
+    token = torch.empty(B * K, dtype=torch.int64, device="cuda")
+    out = torch.empty(B * K, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.sat_beam_step(logits.data_ptr(), V, scores.data_ptr(), last.data_ptr(), 2, B, K, V, parent.data_ptr(),
+                              token.data_ptr(), out.data_ptr(), st))
+    parent, token, out = parent.cpu().view(B, K), token.cpu().view(B, K), out.cpu().view(B, K)
+    # image 0: everything ties at -log(V): flat indices 0, 1, 2 of hypothesis 0
+    assert parent[0].tolist() == [0, 0, 0] and token[0].tolist() == [0, 1, 2]
+    np.testing.assert_allclose(out[0].numpy(), -math.log(V), atol=1e-5)
+    # image 1: finished hypothesis 2 keeps -0.5 with token 2; then hypothesis 1's spike; then the tie at index 0
+    lse1 = math.log(V - 1 + math.exp(3.0))
+    assert parent[1].tolist() == [2, 1, 0] and token[1].tolist() == [2, 650, 0]
+    np.testing.assert_allclose(out[1].numpy(), [-0.5, -1.0 + 3.0 - lse1, -1.0 - math.log(V)], atol=1e-5)
+    # argument errors
+    assert lib.sat_beam_step(logits.data_ptr(), V, scores.data_ptr(), None, -1, B, 9, V, parent.data_ptr(),
+                             token.data_ptr(), out.data_ptr(), st) == 1003
+    assert lib.sat_beam_step(None, V, scores.data_ptr(), None, -1, B, K, V, None, None, None, st) == 1001
+
+
 # ------------------------------------------------------------------------------------------------------
 def _encoder_pair(arch, E, seed, dtype):
     gen = torch.Generator().manual_seed(seed)
@@ -242,6 +299,63 @@ def test_full_train_step_matches_oracle():
     for k, ref in dec_params.items():
         got = dict(model.decoder.named_parameters())[k].detach().cpu()
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5, err_msg=k)
+
+
+def _small_model_and_batch(seed, dtype="bf16"):
+    arch, E, H, V, Lh, B, T = SMALL, 32, 64, 300, 2, 8, 12
+    torch.manual_seed(seed)
+    model = sat.ShowAndTell(E, H, V, Lh, arch=arch, compute_dtype=dtype).cuda().train()
+    gen = torch.Generator().manual_seed(seed + 1)
+    batches = []
+    for _ in range(4):
+        images = torch.randn(B, 3, 96, 96, generator=gen)
+        lengths = sorted(torch.randint(4, T + 1, (B,), generator=gen).tolist(), reverse=True)
+        caps = torch.zeros(B, T, dtype=torch.long)
+        for b, l in enumerate(lengths):
+            caps[b, 0] = 1
+            caps[b, 1:l - 1] = torch.randint(4, V, (l - 2,), generator=gen)
+            caps[b, l - 1] = 2
+        batches.append((images.cuda(), caps.cuda(), lengths))
+    return model, batches, (E, H, V, Lh, arch, dtype)
+
+
+def test_checkpoint_resume_is_bit_exact_and_interchanges_with_torch_adam():
+    """model.state_dict() (train.py:193 saves exactly that) + the Adam state in torch.optim.Adam layout: a run resumed
+    from them continues bit-identically, and the state loads into a torch Adam built as train.py:55-56 builds it"""
+    model, batches, (E, H, V, Lh, arch, dtype) = _small_model_and_batch(51)
+    ts = sat.TrainStep(model, lr=2e-3, grad_clip=0.1)
+    for b in batches[:2]:
+        ts.step(*b)
+    ck_model = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ck_opt = ts.optimizer_state_dict()
+    ck_opt = {"state": {i: {k: v.cpu() for k, v in s.items()} for i, s in ck_opt["state"].items()},
+              "param_groups": ck_opt["param_groups"]}
+    for b in batches[2:]:
+        ts.step(*b)
+    # resume in a fresh model + fresh TrainStep
+    model2 = sat.ShowAndTell(E, H, V, Lh, arch=arch, compute_dtype=dtype)
+    model2.load_state_dict(ck_model)
+    model2.cuda().train()
+    ts2 = sat.TrainStep(model2)
+    ts2.load_optimizer_state_dict(ck_opt)
+    assert ts2.step_count == 2 and ts2.lr == 2e-3
+    for b in batches[2:]:
+        ts2.step(*b)
+    sa, sb = model.state_dict(), model2.state_dict()
+    assert set(sa) == set(sb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(ts.flat.m, ts2.flat.m) and torch.equal(ts.flat.v, ts2.flat.v)
+    # torch.optim.Adam over filter(requires_grad, parameters()) accepts the same dict (train.py:55-56)
+    cpu = [torch.nn.Parameter(p.detach().cpu().clone()) for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(cpu, lr=1e-3)
+    opt.load_state_dict(ck_opt)
+    assert opt.param_groups[0]["lr"] == 2e-3
+    st0 = opt.state[cpu[0]]
+    assert int(st0["step"]) == 2 and st0["exp_avg"].shape == cpu[0].shape
+    # and its own state_dict loads back
+    ts2.load_optimizer_state_dict(opt.state_dict())
+    assert ts2.step_count == 2
 
 
 # ------------------------------------------------------------------------------------------------------

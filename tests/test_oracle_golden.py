@@ -78,6 +78,42 @@ def test_greedy_ids_bit_exact(golden_dir, name):
     assert np.array_equal(ids.numpy(), g["greedy_ids"])
 
 
+@pytest.mark.parametrize("name", ["G1_dec_fwd_bwd_small.npz", "G3_dec_cfg1_summary.npz", "G5_dec_L2.npz"])
+def test_beam_width_one_is_the_golden_greedy_decode(golden_dir, name):
+    """the beam restatement has no reference counterpart (stub), but beam_size=1 must be the pinned greedy ids"""
+    g = load(golden_dir, name)
+    params, (E, H, V, L, B, T) = params_from_seed(g)
+    ids, scores = OD.beam_search(params, torch.from_numpy(g["features"]), 1, L)
+    assert np.array_equal(ids[:, 0].numpy(), g["greedy_ids"])
+    assert torch.isfinite(scores).all()
+
+
+def test_beam_search_properties(golden_dir):
+    g = load(golden_dir, "G5_dec_L2.npz")
+    params, (E, H, V, L, B, T) = params_from_seed(g)
+    feats = torch.from_numpy(g["features"])
+    ids, scores = OD.beam_search(params, feats, 4, L)
+    assert ids.shape == (B, 4, 20) and scores.shape == (B, 4)
+    assert (scores[:, :-1] >= scores[:, 1:]).all()                      # best first
+    assert len({tuple(r.tolist()) for r in ids[0]}) == 4               # hypotheses are distinct
+    # the reported score is the sum of the token log-probabilities of the returned sequence (teacher forcing)
+    b, k = 1, 2
+    caps = torch.cat([ids[b, k, :19]]).unsqueeze(0)
+    logits = OD.decoder_forward(params, feats[b:b + 1], caps, [20], L)
+    lp = torch.log_softmax(logits, 1)
+    total = sum(lp[t, ids[b, k, t]].item() for t in range(20))
+    assert abs(total - scores[b, k].item()) < 1e-4
+    # end_id: once emitted, a hypothesis only repeats it, at unchanged score
+    end = int(ids[0, 0, 3])
+    ids_e, scores_e = OD.beam_search(params, feats, 4, L, end_id=end)
+    for b in range(B):
+        for k in range(4):
+            seq = ids_e[b, k].tolist()
+            if end in seq:
+                assert all(t == end for t in seq[seq.index(end):])
+    assert (scores_e[:, :-1] >= scores_e[:, 1:]).all()
+
+
 def test_lr_schedule():
     # train.py:101-107 with config.py defaults (decay_start 1, every 3, rate 0.8)
     assert OT.lr_for_epoch(1) == 1e-3
