@@ -70,8 +70,7 @@ def cpu_baseline(seed):
     from oracle import decoder as OD
     from oracle import encoder as OE
     from oracle import train_step as OT
-    threads = torch.get_num_threads()
-    B = 8
+    B = 16
     gen = torch.Generator().manual_seed(seed)
     ep, eb = OE.init_encoder_params(CFG["embed"], OE.RESNET152, generator=gen)
     dp = OD.init_decoder_params(CFG["embed"], CFG["hidden"], CFG["vocab"], CFG["layers"], generator=gen)
@@ -80,14 +79,31 @@ def cpu_baseline(seed):
     caps[:, 0], caps[:, -1] = 1, 2
     lengths = [CFG["cap_len"]] * B
     state = {}
-    OT.full_step(ep, eb, dp, images, caps, lengths, state)
+    # The box gives this job a CPU quota well below os.cpu_count() (16 of 256 hardware threads on the 1-GPU boxes):
+    # torch's default thread count oversubscribes it ~10x.  Take the best of a short thread-count probe.
+    default_threads = torch.get_num_threads()
+    best = (0.0, default_threads)
+    for th in sorted({8, 16, 32, default_threads}):
+        if th > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(th)
+        OT.full_step(ep, eb, dp, images, caps, lengths, state)        # warm-up at this thread count
+        t0 = time.perf_counter()
+        OT.full_step(ep, eb, dp, images, caps, lengths, state)
+        rate = B / (time.perf_counter() - t0)
+        if rate > best[0]:
+            best = (rate, th)
+    threads = best[1]
+    torch.set_num_threads(threads)
+    n = 6
     t0 = time.perf_counter()
-    n = 2
     for _ in range(n):
         OT.full_step(ep, eb, dp, images, caps, lengths, state)
     dt = time.perf_counter() - t0
+    torch.set_num_threads(default_threads)
     return {"value": B * n / dt, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "CPU oracle (oracle/train_step.py full_step, torch-CPU fp32), batch %d of the same shapes, 1 warm-up + %d timed steps" % (B, n)}
+            "sample": "CPU oracle (oracle/train_step.py full_step, torch-CPU fp32), batch %d of the same shapes, %d timed "
+                      "steps at the best of {8,16,32,%d} torch threads" % (B, n, default_threads)}
 
 
 def main():

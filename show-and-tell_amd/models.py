@@ -427,6 +427,10 @@ class ShowAndTell(nn.Module):
     def sample(self, images, state=None):
         return self.decoder.sample(self.encoder(images), None)
 
+    @torch.no_grad()
+    def sample_beam(self, images, beam_size=5, end_id=None, return_all=False):
+        return self.decoder.sample_beam(self.encoder(images), beam_size, end_id, return_all=return_all)
+
 
 Encoder = EncoderCNN      # names BASELINE.json uses
 Decoder = DecoderRNN

@@ -414,7 +414,6 @@ def test_cfg2_greedy_and_dropin_forward():
 def test_resnet152_f32_matches_oracle_cfg1():
     """BASELINE cfg-1 shape: batch 4, 224x224, the real [3,8,36,3] stack, f32 MFMA vs the CPU oracle"""
     arch, E, B = OE.RESNET152, 256, 4
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     enc, params, buffers = _encoder_pair(arch, E, 41, "f32")
     x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(42))
     bufs = {k: v.clone() for k, v in buffers.items()}
@@ -425,7 +424,8 @@ def test_resnet152_f32_matches_oracle_cfg1():
 
 
 @pytest.mark.parametrize("B,T,E,H,V,Lh", [(70, 9, 36, 40, 1003, 1), (5, 14, 32, 64, 300, 2), (1, 6, 32, 32, 64, 1),
-                                          (130, 5, 64, 128, 500, 1)])
+                                          (130, 5, 64, 128, 500, 1),
+                                          (16, 20, 512, 1024, 10000, 2)])     # BASELINE configs[3] decoder (cfg4)
 def test_decoder_odd_shapes_ragged_vs_oracle(B, T, E, H, V, Lh):
     """edge cases the reference's collate_fn can produce: batch 1, batches larger than one 64-row chunk of the skinny
     kernels, steeply ragged lengths (down to the minimum 2), vocab / hidden sizes that are not tile multiples"""

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Captions/sec of the decode path at BASELINE configs[4] shape (beam 5; greedy beside it) on ONE GPU, with the CPU
+oracle timed on a bounded sample.  Not the headline metric (bench.py is); numbers go to DESIGN.md / profiles/.
+
+    python tools/bench_decode.py [--batch 64] [--iters 10] [--no-cpu]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sat = importlib.import_module("show-and-tell_amd")
+
+
+def timed(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    torch.manual_seed(123)
+    model = sat.ShowAndTell(256, 512, 10000, 1).cuda().eval()
+    images = torch.randn(a.batch, 3, 224, 224, device="cuda")
+    out = {"batch": a.batch, "data": "synthetic", "unit": "captions/s"}
+    feats = model.encoder(images)
+    t_enc = timed(lambda: model.encoder(images), a.iters)
+    t_greedy = timed(lambda: model.decoder.sample(feats), a.iters)
+    t_beam = timed(lambda: model.decoder.sample_beam(feats, 5, end_id=2), a.iters)
+    out["encoder_eval_ms"] = round(t_enc * 1e3, 3)
+    out["greedy_decode_ms"] = round(t_greedy * 1e3, 3)
+    out["beam5_decode_ms"] = round(t_beam * 1e3, 3)
+    out["greedy_captions_per_s"] = round(a.batch / (t_enc + t_greedy), 1)
+    out["beam5_captions_per_s"] = round(a.batch / (t_enc + t_beam), 1)
+    if not a.no_cpu:
+        sys.path.insert(0, ROOT)
+        from oracle import decoder as OD          # checker / baseline only
+        params = {k: v.detach().cpu() for k, v in model.decoder.state_dict().items()}
+        nb = 8
+        f = feats[:nb].cpu()
+        torch.set_num_threads(os.cpu_count())
+        t0 = time.perf_counter()
+        ref_ids, _ = OD.beam_search(params, f, 5, 1, end_id=2)
+        dt = time.perf_counter() - t0
+        out["cpu_beam5_decoder_only_captions_per_s"] = round(nb / dt, 2)
+        out["cpu_threads"] = os.cpu_count()
+        ids, _ = model.decoder.sample_beam(feats[:nb].contiguous(), 5, end_id=2, return_all=True)
+        out["ids_equal_oracle"] = bool(torch.equal(ids.cpu(), ref_ids))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
