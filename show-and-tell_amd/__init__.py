@@ -8,4 +8,5 @@ from . import _lib  # noqa: F401
 from .models import (CaptionModel, Decoder, DecoderRNN, Encoder, EncoderCNN, ShowAndTell)  # noqa: F401
 from .pack import PackInfo, pack_targets  # noqa: F401
 from .resnet import RESNET152, conv_flops  # noqa: F401
-from .trainer import DataParallelStep, FlatParams, TrainStep, dp_shard, lr_for_epoch  # noqa: F401
+from .trainer import (DataParallelStep, FlatParams, TrainStep, decode_shard, dp_shard, gather_decoded,  # noqa: F401
+                      lr_for_epoch)

@@ -237,6 +237,29 @@ def dp_shard(images, captions, lengths, rank, world):
             sum(int(l) - 1 for l in lengths))
 
 
+def decode_shard(n, rank, world):
+    """Decode (eval.py:93-99 `model.sample`) shards by image with no exchange step: rank r owns the contiguous rows
+    [lo, hi) of an n-image batch (the first n % world ranks take one row more)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_decoded(ids_local, n, process_group=None):
+    """Collect every rank's decoded ids (i64 [rows_r, ...]) into the full [n, ...] tensor on every rank -- only the
+    result collection for the host-side id->word loop (eval.py:99-118), not part of the decode itself."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return ids_local
+    world = dist.get_world_size(process_group)
+    rows = max(decode_shard(n, r, world)[1] - decode_shard(n, r, world)[0] for r in range(world))
+    pad = ids_local.new_zeros((rows,) + tuple(ids_local.shape[1:]))
+    pad[:ids_local.shape[0]] = ids_local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=process_group)
+    return torch.cat([parts[r][:decode_shard(n, r, world)[1] - decode_shard(n, r, world)[0]] for r in range(world)], 0)
+
+
 class DataParallelStep:
     """One process per GPU; replaces `nn.DataParallel` (train.py:43-44).  Semantics:
       * the minibatch is sharded along dim 0, parameters replicated, forward/backward rank-local;

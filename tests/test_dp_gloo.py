@@ -112,6 +112,33 @@ def test_two_ranks_equal_single_process(tmp_path):
     assert got["calls"][:3] == [0, 1, 2]   # buckets become ready in gradient-completion order
 
 
+def decode_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    feats, _ = make_batch()
+    lo, hi = sat.decode_shard(feats.shape[0], rank, world)
+    ids, _ = OD.beam_search(fresh_params(), feats[lo:hi], 3, DIMS["L"], end_id=2)      # the oracle stands in for the HIP decoder
+    full = sat.gather_decoded(ids[:, 0].contiguous(), feats.shape[0])
+    if rank == 1:
+        torch.save(full, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_decode_shards_by_image_without_exchange(tmp_path):
+    """beam decode over 2 ranks == the same decode in one process: images are independent"""
+    assert [sat.decode_shard(7, r, 3) for r in range(3)] == [(0, 3), (3, 5), (5, 7)]
+    assert [sat.decode_shard(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    out = str(tmp_path / "ids.pt")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(decode_worker, args=(2, port, out), nprocs=2, join=True)
+    feats, _ = make_batch()
+    ref, _ = OD.beam_search(fresh_params(), feats, 3, DIMS["L"], end_id=2)
+    assert torch.equal(torch.load(out), ref[:, 0])
+
+
 def test_single_process_wrapper_is_identity():
     feats, caps = make_batch()
     eng = OracleEngine(fresh_params())
