@@ -79,7 +79,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // SPEC: wave specialisation -- waves 0..NW/2-1 own the accumulators (ds_read + MFMA only), waves NW/2..NW-1 only
 // issue the LDS-DMA (address walk + global_load_lds).  Each SIMD then holds one consumer and one loader, whose
 // instruction streams are complementary (matrix pipe vs memory issue) instead of two lock-stepped copies.
-template <int BN, int S, int NW, bool UNIFORM, bool SPEC = false>
+// PF: consumers prefetch the first MFMA fragments of K-step kt+1 during the last MFMAs of K-step kt, so no LDS read
+// latency is exposed behind the per-K-step barrier; the loaders' counted wait then has to cover K-step kt+1 at
+// barrier kt (one in-flight K-step fewer than the ring could hold, hence S >= 4).
+template <int BN, int S, int NW, bool UNIFORM, bool SPEC = false, bool PF = false>
 __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     constexpr int BM = 128, BK = 64, NT = NW * 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -92,6 +95,8 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     constexpr int NAI = BM / 8 / LW, NBI = BN / 8 / LW;   // LDS-DMA pieces (8 rows x 128 B) per loader wave per stage
     constexpr int LPW = NAI + NBI;
     constexpr int D = S - 1;                               // K-steps kept in flight
+    constexpr int WAITN = LPW * (PF ? D - 2 : D - 1);      // loader pieces that may still be in flight at a barrier
+    static_assert(!PF || S >= 4, "fragment prefetch needs one more landed stage");
     constexpr int CROW = BN * 2 + 16;                      // bf16 C-tile row stride in LDS (epilogue)
     static_assert(BM * CROW + 4 * WGM * BN * 4 <= S * STAGE, "epilogue tile + stat scratch must fit the ring");
     static_assert(TM >= 1 && TN >= 1 && NAI >= 1 && NBI >= 1, "bad tile/wave split");
@@ -344,6 +349,35 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         }
     };
 
+    // PF: fragments of (stage, substep 0) are carried in registers across the barrier
+    bf16x8 caf[TM], cbf[TN];
+    auto load_frag = [&](const char* st, int ks, bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *(const bf16x8*)(st + a_off[i][ks]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *(const bf16x8*)(st + b_off[j][ks]);
+    };
+    auto compute_pf = [&](int buf, bool first) {
+        const char* st = smem + buf * STAGE;
+        const char* nst = smem + (buf + 1 == S ? 0 : buf + 1) * STAGE;
+        if (first) load_frag(st, 0, caf, cbf);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 naf[TM], nbf[TN];
+            if (ks < 3) load_frag(st, ks + 1, naf, nbf);
+            else load_frag(nst, 0, naf, nbf);          // K-step kt+1 has landed (WAITN); past the end: a dummy stage
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(caf[i], cbf[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) caf[i] = naf[i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) cbf[j] = nbf[j];
+        }
+    };
+
     // Ring protocol (one raw s_barrier per K-step, all waves):
     //   loader : wait until its own pieces of K-step kt have landed (all but the D-1 younger K-steps done) -> barrier
     //            -> issue K-step kt+D into the slot K-step kt-1 occupied
@@ -356,7 +390,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             for (int s = 0; s < D; ++s) issue(s);
             int buf = 0;
             for (int kt = 0; kt < nk; ++kt) {
-                wait_vmcnt<LPW * (D - 1)>();
+                wait_vmcnt<WAITN>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 int nbuf = buf + D;
@@ -369,7 +403,10 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             for (int kt = 0; kt < nk; ++kt) {
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");        // no LDS read may be hoisted above the barrier
-                if (!(p.dbg & 2)) compute(buf);
+                if (!(p.dbg & 2)) {
+                    if constexpr (PF) compute_pf(buf, kt == 0);
+                    else compute(buf);
+                }
                 buf = (buf + 1 == S) ? 0 : buf + 1;
             }
         }
@@ -378,14 +415,18 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         for (int s = 0; s < D; ++s) issue(s);
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            wait_vmcnt<LPW * (D - 1)>();
+            wait_vmcnt<WAITN>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");            // no LDS read may be hoisted above the barrier
             int nbuf = buf + D;
             if (nbuf >= S) nbuf -= S;
             issue(nbuf);
-            if (p.in_affine) affine_stage(buf, kt);
-            if (!(p.dbg & 2)) compute(buf);
+            if constexpr (PF) {
+                if (!(p.dbg & 2)) compute_pf(buf, kt == 0);
+            } else {
+                if (p.in_affine) affine_stage(buf, kt);
+                if (!(p.dbg & 2)) compute(buf);
+            }
             buf = (buf + 1 == S) ? 0 : buf + 1;
         }
     }
@@ -472,13 +513,13 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     }
 }
 
-template <int BN, int S, int NW, bool SPEC = false>
+template <int BN, int S, int NW, bool SPEC = false, bool PF = false>
 int launch_glds(ConvArgs& a, hipStream_t s) {
     const int tm = sat_cdiv(a.M, 128), tn = sat_cdiv(a.N, BN);
     a.tiles_n = tn;
     const bool uniform = (a.Cin % 64 == 0) && (a.KH * a.KW <= 32);
-    if (uniform) hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
-    else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false, SPEC>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
+    if (uniform) hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
+    else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
@@ -489,11 +530,12 @@ int tune_env(const char* name, int dflt) {
 }
 
 // kernel variants: (tile width, ring stages, waves).  LDS = S * (16 + BN/8) KB decides workgroups per CU.
-struct Variant { int bn, s, nw, spec; };
+struct Variant { int bn, s, nw, spec, pf; };
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0}, {128, 3, 8, 0}, {128, 2, 8, 0}, {64, 4, 8, 0}, {64, 3, 8, 0}, {64, 2, 8, 0},
     {128, 4, 4, 0}, {128, 2, 4, 0}, {64, 3, 4, 0}, {64, 2, 4, 0},
     {128, 4, 8, 1}, {128, 3, 8, 1}, {128, 2, 8, 1}, {64, 4, 8, 1}, {64, 3, 8, 1},     // 4 consumer + 4 loader waves
+    {128, 4, 8, 1, 1}, {128, 4, 8, 0, 1}, {128, 4, 4, 0, 1}, {64, 4, 8, 1, 1}, {64, 4, 8, 0, 1}, {64, 4, 4, 0, 1},   // fragment prefetch
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -514,6 +556,12 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 12: return launch_glds<128, 2, 8, true>(a, s);
         case 13: return launch_glds<64, 4, 8, true>(a, s);
         case 14: return launch_glds<64, 3, 8, true>(a, s);
+        case 15: return launch_glds<128, 4, 8, true, true>(a, s);
+        case 16: return launch_glds<128, 4, 8, false, true>(a, s);
+        case 17: return launch_glds<128, 4, 4, false, true>(a, s);
+        case 18: return launch_glds<64, 4, 8, true, true>(a, s);
+        case 19: return launch_glds<64, 4, 8, false, true>(a, s);
+        case 20: return launch_glds<64, 4, 4, false, true>(a, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -574,7 +622,7 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
         }
     }
     int v = (op->variant > 0 && op->variant <= kNumVariants) ? op->variant - 1 : heuristic_variant(a);
-    if (a.in_affine && kVariants[v].spec) v = heuristic_variant(a);     // the in-LDS transform lives in the unified-wave loop
+    if (a.in_affine && (kVariants[v].spec || kVariants[v].pf)) v = heuristic_variant(a);   // the in-LDS transform lives in the plain unified-wave loop
     return launch_variant(v, a, s);
 }
 
@@ -615,7 +663,7 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
         int best_v = heuristic_variant(a);
         for (int v = 0; v < kNumVariants; ++v) {
             if (kVariants[v].bn == 128 && a.N <= 64) continue;
-            if (kVariants[v].spec && a.in_affine) continue;
+            if ((kVariants[v].spec || kVariants[v].pf) && a.in_affine) continue;
             float tmin = 1e30f;
             for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
                 if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
@@ -626,7 +674,7 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
                 if (round >= 1 && ms / reps < tmin) tmin = ms / reps;
             }
             if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d v%d(%d,%d,%d,%s) %.2f us\n", a.M, a.N, a.K, v, kVariants[v].bn,
-                                 kVariants[v].s, kVariants[v].nw, kVariants[v].spec ? "spec" : "-", tmin * 1e3f);
+                                 kVariants[v].s, kVariants[v].nw, kVariants[v].spec ? (kVariants[v].pf ? "spec+pf" : "spec") : (kVariants[v].pf ? "pf" : "-"), tmin * 1e3f);
             if (tmin < best) { best = tmin; best_v = v; }
         }
         if (verbose) fprintf(stderr, "tune M=%d N=%d K=%d -> v%d %.2f us (%.0f TFLOP/s)\n", a.M, a.N, a.K, best_v, best * 1e3f,

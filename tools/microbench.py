@@ -85,8 +85,13 @@ def bench_conv(shapes=None, reps=20):
         print("conv M=%d N=%d K=%d variant %d: %.1f us  %.0f TFLOP/s" % (N * Ho * Wo, Cout, k * k * Cin, ops[0].variant, us, fl / us / 1e6))
 
 
+ALL_SHAPES = [(64, 56, 56, 256, 64, 1, 1, 0), (64, 56, 56, 64, 64, 3, 1, 1), (64, 56, 56, 64, 256, 1, 1, 0),
+              (64, 28, 28, 512, 128, 1, 1, 0), (64, 28, 28, 128, 128, 3, 1, 1), (64, 28, 28, 128, 512, 1, 1, 0),
+              (64, 14, 14, 1024, 256, 1, 1, 0), (64, 14, 14, 256, 256, 3, 1, 1), (64, 14, 14, 256, 1024, 1, 1, 0),
+              (64, 7, 7, 2048, 512, 1, 1, 0), (64, 7, 7, 512, 512, 3, 1, 1), (64, 7, 7, 512, 2048, 1, 1, 0)]
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "conv":
-    bench_conv()
+    bench_conv(ALL_SHAPES if len(sys.argv) > 2 and sys.argv[2] == "all" else None)
 
 
 def bench_conv_inbn(reps=20):
