@@ -280,11 +280,12 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
 
     if (p.in_affine) {
         // (scale, shift) of the input's BatchNorm for all Cin (= K) channels, into LDS
+        const double inv = 1.0 / (kStatScale * p.in_count);     // same arithmetic as bn_table_from_acc
         for (int c = tid; c < p.Cin; c += NT) {
             float sc, sh;
             if (p.in_acc) {
-                const double mean = (double)p.in_acc[c] / kStatScale / p.in_count;
-                double var = (double)p.in_acc[p.Cin + c] / kStatScale / p.in_count - mean * mean;
+                const double mean = (double)p.in_acc[c] * inv;
+                double var = (double)p.in_acc[p.Cin + c] * inv - mean * mean;
                 if (var < 0.0) var = 0.0;
                 const float invstd = 1.0f / sqrtf((float)var + p.in_eps);
                 sc = p.in_gamma[c] * invstd;

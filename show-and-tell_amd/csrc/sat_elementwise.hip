@@ -138,9 +138,10 @@ struct BnSrc {
 
 __device__ __forceinline__ void bn_table_from_acc(const BnSrc& b, int C, double count, float momentum, float eps,
                                                   float* sc, float* sh) {
+    const double inv = 1.0 / (SAT_STAT_SCALE * count);      // one f64 division per thread, none per channel
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double mean = (double)b.acc[c] / SAT_STAT_SCALE / count;
-        double var = (double)b.acc[C + c] / SAT_STAT_SCALE / count - mean * mean;
+        const double mean = (double)b.acc[c] * inv;
+        double var = (double)b.acc[C + c] * inv - mean * mean;
         if (var < 0.0) var = 0.0;
         const float invstd = 1.0f / sqrtf((float)var + eps);
         const float s = b.gamma[c] * invstd;
