@@ -57,8 +57,22 @@ enum {
     SAT_OP_BN_RELU = 4,    /* out = relu(in0*scale0 + shift0) */
     SAT_OP_BN_ADD_RELU = 5,/* out = relu(in0*scale0+shift0 + (in1*scale1+shift1 | in1)) */
     SAT_OP_BN_RELU_MAXPOOL = 6, /* out = maxpool3x3/2(relu(in0*scale0+shift0)) */
-    SAT_OP_AVGPOOL = 7     /* out f32 [N][C] = mean over Hin*Win of in0 */
+    SAT_OP_AVGPOOL = 7,    /* out f32 [N][C] = mean over Hin*Win of in0 */
+    SAT_OP_BN_EVAL_BATCH = 8 /* eval mode: in0 = DEVICE array of `count` sat_bn_eval_item; every item's (scale, shift)
+                              * from its running statistics in ONE launch (replaces one BN_FINALIZE per layer); eps */
 };
+
+/* one BatchNorm of an eval-mode stack (all pointers device memory, C floats each) */
+typedef struct sat_bn_eval_item {
+    const float* gamma;
+    const float* beta;
+    const float* running_mean;
+    const float* running_var;
+    float* scale_out;
+    float* shift_out;
+    int32_t C;
+    int32_t reserved;
+} sat_bn_eval_item;
 
 typedef struct sat_op {
     int32_t kind;

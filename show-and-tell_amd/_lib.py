@@ -12,7 +12,15 @@ LIB_PATH = os.path.join(_HERE, "libsat_hip.so")
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
+OP_BN_EVAL_BATCH = 8
+
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class SatBnEvalItem(C.Structure):
+    """mirror of `struct sat_bn_eval_item` (include/sat_hip.h)"""
+    _fields_ = [("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
+                ("scale_out", _vp), ("shift_out", _vp), ("C", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SatOp(C.Structure):

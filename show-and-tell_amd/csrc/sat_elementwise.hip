@@ -121,6 +121,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
 }
 
+// eval mode: (scale, shift) of EVERY BatchNorm of the stack from its running statistics, one workgroup per layer
+// (same float arithmetic as bn_finalize_kernel's eval branch)
+__global__ __launch_bounds__(256) void bn_eval_batch_kernel(const sat_bn_eval_item* __restrict__ items, float eps) {
+    const sat_bn_eval_item it = items[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += 256) {
+        const float invstd = 1.0f / sqrtf(it.running_var[c] + eps);
+        const float sc = it.gamma[c] * invstd;
+        it.scale_out[c] = sc;
+        it.shift_out[c] = it.beta[c] - it.running_mean[c] * sc;
+    }
+}
+
 // Where a BatchNorm's (scale, shift) comes from: either a table the finalize kernel wrote, or -- `acc` set -- the
 // fixed-point integer sums the producing conv accumulated (sat_conv_glds.hip): then every workgroup derives the
 // table itself into LDS (a few KB of loads, f64 arithmetic identical to bn_finalize_kernel), and workgroup 0 also
@@ -682,6 +694,13 @@ int sat_image_prep_launch(const sat_op* op, hipStream_t s) {
     else
         hipLaunchKernelGGL(image_prep_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const float*)op->in0,
                            (float*)op->out, op->N, op->Hin, op->Win, op->Hout, op->Wout, op->pad);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+int sat_bn_eval_batch_launch(const sat_op* op, hipStream_t s) {
+    if (!op->in0 || op->count < 1 || op->count > 65535) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(bn_eval_batch_kernel, dim3((int)op->count), dim3(256), 0, s, (const sat_bn_eval_item*)op->in0, op->eps);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }

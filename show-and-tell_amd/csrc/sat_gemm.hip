@@ -328,10 +328,21 @@ template <int AMODE, int BMODE>
 int launch_f32_auto(GemmArgs& a, hipStream_t s) {
     // fill the 256 CUs: fall to smaller tiles when the big ones leave most of the chip idle
     const int ks = a.ksplit < 1 ? 1 : a.ksplit;
+    static int force = -1;              // SAT_GEMM_TILE=1/2/3: tuning override (128x128 / 128x64 / 64x64)
+    if (force < 0) { const char* e = getenv("SAT_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    if (force == 1) return launch<float, 128, 128, AMODE, BMODE>(a, s);
+    if (force == 2) return launch<float, 128, 64, AMODE, BMODE>(a, s);
+    if (force == 3) return launch<float, 64, 64, AMODE, BMODE>(a, s);
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128) * ks;
     const long t12864 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 64) * ks;
     if (t128 >= 384) return launch<float, 128, 128, AMODE, BMODE>(a, s);
-    if (t12864 >= 384) return launch<float, 128, 64, AMODE, BMODE>(a, s);
+    if (t12864 >= 384) {
+        // rounds of 256 workgroups x tile area x a per-flop penalty: 128x64 only where its last round is not mostly
+        // empty (measured on the decoder's shapes, tools/microbench.py gemm: dW_vocab 138 -> 125 us with 64x64)
+        const long t64 = (long)sat_cdiv(a.M, 64) * sat_cdiv(a.N, 64) * ks;
+        const double c12864 = (double)((t12864 + 255) / 256) * 128 * 64 * 1.1, c64 = (double)((t64 + 255) / 256) * 64 * 64 * 1.25;
+        if (c12864 <= c64) return launch<float, 128, 64, AMODE, BMODE>(a, s);
+    }
     return launch<float, 64, 64, AMODE, BMODE>(a, s);
 }
 

@@ -215,6 +215,8 @@ class ConvStackProgram:
         if atomic_stats:
             self.stat_acc = alloc((nbn, 2, 2, cmax), torch.int64, zero=True)
 
+        eval_items = []
+
         def fin_op(bn, c, count, tiles_m, consumer_can_derive=True):
             s, t = new_scale_shift(c)
             if atomic_stats and consumer_can_derive and tiles_m <= ATOMIC_MAX_TILES:
@@ -224,6 +226,16 @@ class ConvStackProgram:
                 cv.stat_partial = None
                 cv.stat_acc = self.stat_acc[i].data_ptr()
                 bnref[s.data_ptr()] = (self.stat_acc[i].data_ptr(), bn, count)
+                self.bn_list.append(bn)
+                return None, s, t
+            if not training:
+                # eval: (scale, shift) depend on parameters and running statistics only -> ONE batched launch for
+                # all BatchNorms at the head of the program instead of a finalize launch per layer
+                it = L.SatBnEvalItem()
+                it.gamma, it.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                it.running_mean, it.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                it.scale_out, it.shift_out, it.C = s.data_ptr(), t.data_ptr(), c
+                eval_items.append(it)
                 self.bn_list.append(bn)
                 return None, s, t
             o = L.SatOp()
@@ -334,6 +346,14 @@ class ConvStackProgram:
         ap.N, ap.Hin, ap.Win, ap.Cout = N, geo[-1][2], geo[-1][3], stack.feature_dim
         ops.append(ap)
         self.final_map = (y, N, geo[-1][2], geo[-1][3], stack.feature_dim)
+        if eval_items:
+            arr = (L.SatBnEvalItem * len(eval_items))(*eval_items)
+            self.eval_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+            self.keep.append(self.eval_table)
+            o = L.SatOp()
+            o.kind, o.dtype = L.OP_BN_EVAL_BATCH, dtype
+            o.in0, o.count, o.eps = self.eval_table.data_ptr(), len(eval_items), BN_EPS
+            ops.insert(1, o)                     # right after image prep, before the first consumer
         self.ops = (L.SatOp * len(ops))(*ops)
         self.n_ops = len(ops)
         # replay as a hipGraph (SAT_GRAPH=0: eager launches).  Per step parity: first run eager, then captured.

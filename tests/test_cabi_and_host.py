@@ -39,7 +39,8 @@ def test_sat_op_struct_layout_matches_c():
 #include <stdio.h>
 #include <stddef.h>
 #include "sat_hip.h"
-int main(){printf("%zu %zu %zu %zu %zu\n", sizeof(sat_op), offsetof(sat_op,N), offsetof(sat_op,sN), offsetof(sat_op,count), offsetof(sat_op,eps));return 0;}
+int main(){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(sat_op), offsetof(sat_op,N), offsetof(sat_op,sN), offsetof(sat_op,count), offsetof(sat_op,eps),
+ sizeof(sat_bn_eval_item), offsetof(sat_bn_eval_item,C));return 0;}
 '''
     d = os.path.join(ROOT, "tests", "_build")
     os.makedirs(d, exist_ok=True)
@@ -48,7 +49,8 @@ int main(){printf("%zu %zu %zu %zu %zu\n", sizeof(sat_op), offsetof(sat_op,N), o
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "layout.c"), "-o", exe])
     out = subprocess.check_output([exe]).decode().split()
     S = L.SatOp
-    assert [int(x) for x in out] == [C.sizeof(S), S.N.offset, S.sN.offset, S.count.offset, S.eps.offset]
+    E = L.SatBnEvalItem
+    assert [int(x) for x in out] == [C.sizeof(S), S.N.offset, S.sN.offset, S.count.offset, S.eps.offset, C.sizeof(E), E.C.offset]
 
 
 def test_argument_errors_are_reported_not_computed():

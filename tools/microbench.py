@@ -121,3 +121,38 @@ def bench_conv_inbn(reps=20):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "inbn":
     bench_conv_inbn()
+
+
+def bench_gemm(reps=30):
+    """the decoder's f32 GEMMs at cfg2 (rows N=1216, E=256, H=512, V=10000); SAT_GEMM_TILE=1/2/3 forces a tile"""
+    lib = L.load()
+    N, E, H, V = 1216, 256, 512, 10000
+    shapes = [("logits fwd      ", 0, 0, N, V, H, 1), ("dHs = dL.W      ", 0, 1, N, H, V, 3), ("dW  = dL^T.Hs   ", 2, 1, V, H, N, 1),
+              ("xg  = X.Wih^T   ", 0, 0, N, 4 * H, E, 1), ("dWih = DG^T.X   ", 2, 1, 4 * H, E, N, 1),
+              ("dWhh = DG^T.HP  ", 2, 1, 4 * H, H, N, 1), ("dX  = DG.Wih    ", 0, 1, N, E, 4 * H, 1)]
+    for name, am, bm, M, Nn, K, ks in shapes:
+        A = torch.randn((M, K) if am == 0 else (K, M), device="cuda")
+        B = torch.randn((Nn, K) if bm == 0 else (K, Nn), device="cuda")
+        Cm = torch.empty(ks, M, Nn, device="cuda")
+        def run():
+            if ks == 1:
+                L.check(lib.sat_gemm_f32(am, bm, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), Cm.data_ptr(), Nn, None, None,
+                                         M, Nn, K, L.stream()))
+            else:
+                L.check(lib.sat_gemm_f32_splitk(am, bm, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), Cm.data_ptr(), Nn,
+                                                None, None, M, Nn, K, ks, M * Nn, L.stream()))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        print("%s M=%5d N=%5d K=%5d ks=%d: %7.1f us  %5.1f TFLOP/s" % (name, M, Nn, K, ks, us, 2.0 * M * Nn * K / us / 1e6))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gemm":
+    bench_gemm()
