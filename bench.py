@@ -66,7 +66,8 @@ def conv_only_time_ms(sat, model, images, reps=3):
 
 def cpu_baseline(seed):
     """The CPU oracle (a port of the reference path, validated against the reference's goldens) timed on this
-    host's cores on a bounded sample of the same workload: batch 8 of the cfg-2 shapes, 1 warm-up + 2 steps."""
+    host's cores on a bounded sample of the same workload: batch 16 of the cfg-2 shapes, 6 timed steps at the best
+    torch thread count of a short probe."""
     from oracle import decoder as OD
     from oracle import encoder as OE
     from oracle import train_step as OT
@@ -178,11 +179,11 @@ def main():
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step_in_kernel": round(conv_ms, 3)},
         }
-        traffic_file = os.path.join(ROOT, "profiles", "r01_c_conv_pmc_traffic.json")
+        traffic_file = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
         if os.path.exists(traffic_file):      # HBM bytes per conv launch from the separate rocprofv3 --pmc passes (tools/run_gpu_pmc.sh)
             with open(traffic_file) as f:
                 out["roofline"]["traffic"] = round(json.load(f)["hbm_bytes_per_launch_corrected"])
-                out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c_conv_pmc_traffic.json)"
+                out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_g_pmc_traffic.json)"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(123)
         print(json.dumps(out), flush=True)

@@ -8,3 +8,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   ls -la $R/gpurun_out/pmc_$c | head
   find $R/gpurun_out/pmc_$c -name "*kernel_trace.csv" -delete
 done
+python3 $R/tools/pmc_traffic.py $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE > $R/gpurun_out/pmc_traffic.json
+head -c 1500 $R/gpurun_out/pmc_traffic.json
+find $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv" -size +20M -delete
