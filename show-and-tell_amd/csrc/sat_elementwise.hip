@@ -31,6 +31,20 @@ template <> __device__ __forceinline__ void load_chunk<bf16_t>(const bf16_t* p, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
 }
+// raw 16-byte load now, conversion later: lets a kernel put loads in flight before work they do not depend on
+template <typename T> __device__ __forceinline__ u32x4 load_raw(const T* p) { return *(const u32x4*)p; }
+template <typename T> __device__ __forceinline__ void unpack_chunk(const u32x4& r, float (&v)[Vec<T>::N]);
+template <> __device__ __forceinline__ void unpack_chunk<float>(const u32x4& r, float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(r[i]);
+}
+template <> __device__ __forceinline__ void unpack_chunk<bf16_t>(const u32x4& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // bf16 -> f32 is a 16-bit shift
+        v[2 * i] = __uint_as_float(r[i] << 16);
+        v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+    }
+}
 template <typename T> __device__ __forceinline__ void store_chunk(T* p, const float (&v)[Vec<T>::N]);
 template <> __device__ __forceinline__ void store_chunk<float>(float* p, const float (&v)[4]) {
     f32x4 x = {v[0], v[1], v[2], v[3]};
@@ -183,6 +197,23 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
     const float* t0 = b0.shift;
     const float* s1 = b1.scale;
     const float* t1 = b1.shift;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cch = C / V;
+    // 32-bit index math in the prologue (a 64-bit modulo costs more than the whole streaming loop of a small tensor)
+    const bool fast = ((unsigned)stride % (unsigned)cch) == 0;
+    constexpr int U = ADD ? 2 : 4;             // 4 independent 16-byte loads per lane and stage
+    u32x4 rx[U], rz[U];
+    if (fast) {     // first stage of the stream goes in flight BEFORE the table is derived: it does not depend on it
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long iu = i0 + u * stride;
+            if (iu < nchunks) {
+                rx[u] = load_raw<T>(in0 + iu * V);
+                if constexpr (ADD) rz[u] = load_raw<T>(in1 + iu * V);
+            }
+        }
+    }
     bool derived = false;
     if (b0.acc) {
         bn_table_from_acc(b0, C, count, momentum, eps, tab, tab + C);
@@ -193,11 +224,7 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
         s1 = tab + 2 * C; t1 = tab + 3 * C; derived = true;
     }
     if (derived) __syncthreads();
-    const long stride = (long)gridDim.x * blockDim.x;
-    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int cch = C / V;
-    // 32-bit index math in the prologue (a 64-bit modulo costs more than the whole streaming loop of a small tensor)
-    if (((unsigned)stride % (unsigned)cch) == 0) {
+    if (fast) {
         const int c0 = (int)((unsigned)i0 % (unsigned)cch) * V;
         float sc0[V], sh0[V], sc1[V], sh1[V];
 #pragma unroll
@@ -208,32 +235,41 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
 #pragma unroll
             for (int e = 0; e < 4; ++e) { sc0[k + e] = a[e]; sh0[k + e] = b[e]; sc1[k + e] = c[e]; sh1[k + e] = d[e]; }
         }
-        constexpr int U = ADD ? 2 : 4;             // 4 independent 16-byte loads in flight per lane
-        for (long i = i0; i < nchunks; i += stride * U) {
-            float x[U][V], z[U][V];
+        for (long i = i0; i < nchunks;) {
+            const long inext = i + stride * U;
+            u32x4 nx[U], nz[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const long iu = i + u * stride;
+            for (int u = 0; u < U; ++u) {          // next stage in flight while this one is computed and stored
+                const long iu = inext + u * stride;
                 if (iu < nchunks) {
-                    load_chunk<T>(in0 + iu * V, x[u]);
-                    if constexpr (ADD) load_chunk<T>(in1 + iu * V, z[u]);
+                    nx[u] = load_raw<T>(in0 + iu * V);
+                    if constexpr (ADD) nz[u] = load_raw<T>(in1 + iu * V);
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const long iu = i + u * stride;
                 if (iu < nchunks) {
-                    float y[V];
+                    float x[V], y[V];
+                    unpack_chunk<T>(rx[u], x);
                     if constexpr (ADD) {
+                        float z[V];
+                        unpack_chunk<T>(rz[u], z);
 #pragma unroll
-                        for (int k = 0; k < V; ++k) y[k] = fmaxf(x[u][k] * sc0[k] + sh0[k] + (z[u][k] * sc1[k] + sh1[k]), 0.0f);
+                        for (int k = 0; k < V; ++k) y[k] = fmaxf(x[k] * sc0[k] + sh0[k] + (z[k] * sc1[k] + sh1[k]), 0.0f);
                     } else {
 #pragma unroll
-                        for (int k = 0; k < V; ++k) y[k] = fmaxf(x[u][k] * sc0[k] + sh0[k], 0.0f);
+                        for (int k = 0; k < V; ++k) y[k] = fmaxf(x[k] * sc0[k] + sh0[k], 0.0f);
                     }
                     store_chunk<T>(out + iu * V, y);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rx[u] = nx[u];
+                if constexpr (ADD) rz[u] = nz[u];
+            }
+            i = inext;
         }
         return;
     }
