@@ -301,6 +301,45 @@ def test_full_train_step_matches_oracle():
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5, err_msg=k)
 
 
+def test_training_trajectory_eight_steps_vs_oracle():
+    """eight whole iterations (fresh batch every step) against the CPU oracle: covers the eager -> hipGraph capture ->
+    replay hand-over of the encoder program for both step parities, running-statistics updates and the Adam state"""
+    arch, E, H, V, Lh, B, T = TINY, 32, 64, 300, 1, 6, 12
+    gen = torch.Generator().manual_seed(61)
+    enc_params, enc_buffers = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
+    dec_params = OD.init_decoder_params(E, H, V, Lh, generator=gen)
+    model = sat.ShowAndTell(E, H, V, Lh, arch=arch, compute_dtype="f32")
+    sd = dict(enc_params)
+    sd.update(enc_buffers)
+    model.encoder.load_state_dict(sd)
+    model.decoder.load_state_dict(dec_params)
+    model.cuda().train()
+    ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+    state = {}
+    for it in range(8):
+        images = torch.randn(B, 3, 64, 64, generator=gen)
+        lengths = sorted(torch.randint(3, T + 1, (B,), generator=gen).tolist(), reverse=True)
+        caps = torch.zeros(B, T, dtype=torch.long)
+        for b, l in enumerate(lengths):
+            caps[b, 0] = 1
+            caps[b, 1:l - 1] = torch.randint(4, V, (l - 2,), generator=gen)
+            caps[b, l - 1] = 2
+        ref_loss, _ = OT.full_step(enc_params, enc_buffers, dec_params, images, caps, lengths, state, arch=arch, num_layers=Lh)
+        loss = ts.step(images.cuda(), caps.cuda(), lengths)
+        assert abs(loss.item() - ref_loss.item()) < 1e-4 * (it + 1), (it, loss.item(), ref_loss.item())
+    prog = next(iter(model.encoder._programs.values()))
+    assert prog._graphs[0] is not None and prog._graphs[1] is not None
+    got = model.encoder.state_dict()
+    for k in ("resnet.bn1.running_mean", "resnet.layer3.0.bn2.running_var", "resnet.layer4.0.downsample.1.running_var",
+              "bn.running_mean"):
+        # pooled features agree to ~2e-4 (f32 conv stack, different summation order); the statistics inherit that
+        np.testing.assert_allclose(got[k].cpu().numpy(), enc_buffers[k].numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
+    assert int(got["resnet.layer1.0.bn1.num_batches_tracked"]) == 8
+    for k, ref in dec_params.items():
+        g = dict(model.decoder.named_parameters())[k].detach().cpu()
+        np.testing.assert_allclose(g.numpy(), ref.numpy(), rtol=0, atol=2e-4, err_msg=k)
+
+
 def _small_model_and_batch(seed, dtype="bf16"):
     arch, E, H, V, Lh, B, T = SMALL, 32, 64, 300, 2, 8, 12
     torch.manual_seed(seed)
