@@ -1,0 +1,63 @@
+"""Host-side input plumbing on either side of the hot path: the batch invariant the kernels rely
+on, and an H2D prefetcher so the PCIe copy of batch i+1 hides under the step of batch i (PCIe note).
+
+`collate_batch` keeps the contract of the reference's `collate_fn` (`/root/reference/data_loader.py:48-62`): samples
+sorted by caption length, longest first (equal lengths keep their order), images stacked, captions zero-padded into
+one int64 matrix, `lengths` as a Python list.  No GPU work happens here.
+"""
+import torch
+
+
+def collate_batch(samples, pin_memory=False):
+    """samples: iterable of (image [3,H,W] float tensor, caption 1-D integer tensor, image id).
+    Returns (images [B,3,H,W], captions i64 [B,max_len] zero padded, lengths list[int] descending, image ids tuple)."""
+    ordered = sorted(samples, key=lambda s: int(s[1].shape[0]), reverse=True)      # stable, like list.sort(reverse=True)
+    if not ordered:
+        raise ValueError("empty batch")
+    lengths = [int(s[1].shape[0]) for s in ordered]
+    if lengths[-1] < 1:
+        raise ValueError("empty caption")
+    images = torch.stack([s[0] for s in ordered], 0)
+    captions = torch.nn.utils.rnn.pad_sequence([s[1].long() for s in ordered], batch_first=True, padding_value=0)
+    if pin_memory:
+        images, captions = images.pin_memory(), captions.pin_memory()
+    return images, captions, lengths, tuple(s[2] for s in ordered)
+
+
+class DevicePrefetcher:
+    """Wraps an iterable of (images, captions, lengths, ...) host batches: yields the same tuples with the two tensors
+    resident on `device`; the copy of the next batch runs on a side HIP stream while the caller works on the current
+    one.  Pinned host tensors make the copy truly asynchronous (`collate_batch(..., pin_memory=True)` or a DataLoader
+    with pin_memory)."""
+
+    def __init__(self, batches, device):
+        self.batches, self.device = batches, torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DevicePrefetcher copies to the MI355X; got device %s" % (device,))
+        self.stream = torch.cuda.Stream(self.device)
+
+    def _stage(self, batch):
+        images, captions = batch[0], batch[1]
+        with torch.cuda.stream(self.stream):
+            d_images = images.to(self.device, non_blocking=True)
+            d_captions = captions.to(self.device, non_blocking=True)
+        return (d_images, d_captions) + tuple(batch[2:])
+
+    def __iter__(self):
+        it = iter(self.batches)
+        try:
+            staged = self._stage(next(it))
+        except StopIteration:
+            return
+        while True:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.stream)                 # the staged copy is complete before the caller's kernels read it
+            ready = staged
+            for t in ready[:2]:
+                t.record_stream(cur)                     # allocator: these blocks are in use on the compute stream
+            try:
+                staged = self._stage(next(it))           # next copy goes in flight now
+            except StopIteration:
+                yield ready
+                return
+            yield ready

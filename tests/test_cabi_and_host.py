@@ -118,3 +118,25 @@ def test_state_dict_keys_equal_reference_names():
     trainable = [k for k, p in enc.named_parameters() if p.requires_grad]
     assert trainable == ["resnet.fc.weight", "resnet.fc.bias", "bn.weight", "bn.bias"]      # models.py:14-17
     assert abs(sat.conv_flops(sat.RESNET152) / 1e9 - 23.02) < 0.1
+
+
+def test_collate_batch_keeps_the_reference_invariant():
+    """data_loader.py:48-62: longest caption first (ties keep their order), zero padding, int64, lengths as a list --
+    and the result feeds pack_padded_sequence / PackInfo without re-sorting"""
+    g = torch.Generator().manual_seed(3)
+    lens = [5, 9, 5, 12, 9, 3]
+    samples = [(torch.full((3, 4, 4), float(i)), torch.randint(1, 50, (n,), generator=g).int(), 100 + i)
+               for i, n in enumerate(lens)]
+    images, caps, lengths, ids = sat.collate_batch(list(samples))
+    assert lengths == [12, 9, 9, 5, 5, 3] and ids == (103, 101, 104, 100, 102, 105)      # stable among equal lengths
+    assert caps.dtype == torch.int64 and caps.shape == (6, 12) and images.shape == (6, 3, 4, 4)
+    for row, i in enumerate([3, 1, 4, 0, 2, 5]):
+        n = lens[i]
+        assert torch.equal(caps[row, :n], samples[i][1].long()) and int(caps[row, n:].abs().sum()) == 0
+        assert float(images[row, 0, 0, 0]) == float(i)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(caps, lengths, batch_first=True)      # accepts it unsorted-check on
+    assert packed.batch_sizes.tolist() == sat.PackInfo(lengths, "cpu").batch_sizes
+    with pytest.raises(ValueError):
+        sat.collate_batch([])
+    with pytest.raises(RuntimeError):
+        sat.DevicePrefetcher([], "cpu")

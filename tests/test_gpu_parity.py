@@ -554,3 +554,21 @@ def test_decoder_rejects_bad_inputs():
         dec(f, c, [6, 6])               # wrong batch size
     with pytest.raises(ValueError):
         dec(f, c, [9, 3, 2])            # longer than captions + 1
+
+
+def test_device_prefetcher_feeds_the_step_like_direct_copies():
+    """H2D prefetch on a side stream (pinned host batches) must deliver exactly the tensors a blocking .cuda() would,
+    in order, and a TrainStep fed through it must reproduce the directly-fed run bit for bit"""
+    model, batches, (E, H, V, Lh, arch, dtype) = _small_model_and_batch(71)
+    host = [(im.cpu().pin_memory(), cp.cpu().pin_memory(), ln) for im, cp, ln in batches]
+    seen = list(sat.DevicePrefetcher(host, "cuda"))
+    assert len(seen) == len(host)
+    for (im, cp, ln), (him, hcp, hln) in zip(seen, host):
+        assert im.is_cuda and torch.equal(im.cpu(), him) and torch.equal(cp.cpu(), hcp) and ln == hln
+    assert list(sat.DevicePrefetcher([], "cuda")) == []
+    ts = sat.TrainStep(model, lr=1e-3)
+    ref = [ts.step(*b).item() for b in batches]
+    model2, _, _ = _small_model_and_batch(71)
+    ts2 = sat.TrainStep(model2, lr=1e-3)
+    got = [ts2.step(im, cp, ln).item() for im, cp, ln in sat.DevicePrefetcher(host, "cuda")]
+    assert got == ref
