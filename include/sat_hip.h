@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 4
+#define SAT_ABI_VERSION 5
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -99,7 +99,10 @@ typedef struct sat_op {
     int64_t count;            /* BN_FINALIZE: elements per channel (N*Hout*Wout) */
     float momentum, eps;
     int32_t variant;          /* SAT_OP_CONV: 0 = built-in heuristic, >0 = kernel variant chosen by sat_conv_autotune */
-    int32_t reserved;
+    int32_t flags;            /* SAT_OP_CONV, bf16, inference: scale1/shift1 [Cout] set => the epilogue writes
+                               * out = acc*scale1[n] + shift1[n] (+ in1[m][n], a residual shaped like out) and, with
+                               * bit 0 of flags, ReLU -- BatchNorm (eval) + add + ReLU of a bottleneck without a
+                               * separate launch (models.py:27 under eval.py:65 `model.eval()`) */
     /* Integer-atomic BatchNorm statistics (bf16, training, few M-tiles): stat_acc = int64 [2 step parities][2][C]
      * fixed-point (2^22) column sums, zero before first use.  On a SAT_OP_CONV the kernel ADDS this tile's sums into
      * parity p's half; on the consuming SAT_OP_BN_RELU / SAT_OP_BN_ADD_RELU (same pointer, plus gamma, beta, running_mean, running_var,
@@ -226,7 +229,9 @@ int sat_embed_rows(const float* embed, const int64_t* ids, int64_t ids_stride, i
  */
 int sat_beam_step(const float* logits /*[B*K, ldl]*/, int64_t ldl, const float* scores_in /*[B*K]*/,
                   const int64_t* last_tokens /*[B*K] or NULL*/, int64_t end_id, int B, int K, int V,
-                  int32_t* parent /*[B*K]*/, int64_t* token /*[B*K]*/, float* scores_out /*[B*K]*/, sat_stream_t stream);
+                  int32_t* parent /*[B*K]*/, int64_t* token /*[B*K]*/, float* scores_out /*[B*K]*/,
+                  void* workspace, int64_t ws_bytes, sat_stream_t stream);
+int64_t sat_beam_step_ws_bytes(int B, int K);
 int sat_beam_gather_rows(const float* src, const int32_t* parent, int B, int K, int width, float* dst,
                          sat_stream_t stream);
 int sat_beam_backtrack(const int32_t* parents, const int64_t* tokens, int T, int B, int K, int64_t* ids,

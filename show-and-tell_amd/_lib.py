@@ -37,7 +37,7 @@ class SatOp(C.Structure):
         ("training", C.c_int32), ("tiles_m", C.c_int32),
         ("sN", C.c_int64), ("sH", C.c_int64), ("sW", C.c_int64), ("count", C.c_int64),
         ("momentum", C.c_float), ("eps", C.c_float),
-        ("variant", C.c_int32), ("reserved", C.c_int32),
+        ("variant", C.c_int32), ("flags", C.c_int32),
         ("stat_acc", _vp), ("stat_acc1", _vp), ("gamma1", _vp), ("beta1", _vp),
         ("running_mean1", _vp), ("running_var1", _vp),
     ]
@@ -77,7 +77,8 @@ SIGNATURES = {
     "sat_vocab_argmax_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_embed_rows": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
-    "sat_beam_step": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sat_beam_step": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sat_beam_step_ws_bytes": (_i64, [_i, _i]),
     "sat_beam_gather_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_beam_backtrack": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_clamp_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
@@ -102,7 +103,7 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.sat_version() != 4:
+        if lib.sat_version() != 5:
             raise RuntimeError("libsat_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -1,13 +1,18 @@
 // Beam decode helpers (the reference has a stub only, model2.py:113-114; greedy loop models.py:56-67).
 // One decode step per image = log-softmax of K rows of logits + top-K over the K*V candidates + LSTM state
 // re-ordering by parent; the sequences are recovered at the end by walking the (parent, token) back-pointers.
-// HBM-bound byte/compare work: one workgroup per image streams its K rows of logits twice (max+sum, select).
+// HBM/L2-bound byte/compare work, two launches per step:
+//   beam_row_kernel   one workgroup per (image, hypothesis) row: log-sum-exp of the row (max pass, sum pass) and the
+//                     row's K best continuations (thread-local sorted lists in registers, K rounds of block arg-best);
+//   beam_merge_kernel one wave per image: the K best of its K*K row candidates.
+// The union of per-row top-K lists contains the global top-K, and both kernels order candidates by (score desc, flat
+// index k*V+v asc), so the result is the exact top-K with a deterministic tie rule.
 #include "sat_internal.h"
 #include <limits.h>
 
 namespace {
 
-constexpr int KMAX = 8;   // beam width limit (thread-local candidate lists live in registers)
+constexpr int KMAX = 8;   // beam width limit (thread-local candidate lists live in registers; K*K <= one wave)
 
 // a better than b: higher score, ties -> lower flat candidate index (k*V + v)
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
@@ -23,40 +28,56 @@ __device__ __forceinline__ float block_reduce256(float v, bool is_max, float* sh
     return r;
 }
 
-__global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logits, long ldl,
-                                                        const float* __restrict__ scores_in,
-                                                        const int64_t* __restrict__ last_tok, long end_id, int K, int V,
-                                                        int* __restrict__ parent, int64_t* __restrict__ token,
-                                                        float* __restrict__ scores_out) {
+// insert (cv, ci) into a list sorted by (value desc, index asc); the caller visits candidates in increasing index
+// order, so an equal value goes BEHIND the ones already stored
+__device__ __forceinline__ void list_insert(float (&val)[KMAX], int (&idx)[KMAX], float cv, int ci) {
+    bool shifted = false;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        const bool sw = shifted || cv > val[j];
+        const float tv = val[j];
+        const int ti = idx[j];
+        if (sw) {
+            val[j] = cv;
+            idx[j] = ci;
+            cv = tv;
+            ci = ti;
+        }
+        shifted = sw;
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_row_kernel(const float* __restrict__ logits, long ldl,
+                                                       const float* __restrict__ scores_in,
+                                                       const int64_t* __restrict__ last_tok, long end_id, int K, int V,
+                                                       float* __restrict__ cand_val, int* __restrict__ cand_idx) {
     __shared__ float sh[4];
-    __shared__ float s_lse[KMAX], s_base[KMAX];
-    __shared__ int s_frozen[KMAX];
     __shared__ float s_rv[4];
     __shared__ int s_ri[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    // ---- phase 1: log-sum-exp of every live row ----
-    for (int k = 0; k < K; ++k) {
-        const float base = scores_in[b * K + k];
-        const bool frozen = last_tok != nullptr && end_id >= 0 && last_tok[b * K + k] == end_id;
-        float lse = 0.0f;
-        if (base != -INFINITY && !frozen) {           // uniform across the block
-            const float* x = logits + (long)(b * K + k) * ldl;
-            float m = -INFINITY;
-            for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
-            m = block_reduce256(m, true, sh);
-            float s = 0.0f;
-            for (int i = tid; i < V; i += 256) s += expf(x[i] - m);
-            s = block_reduce256(s, false, sh);
-            lse = m + logf(s);
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int k = row % K;
+    const float base = scores_in[row];
+    const bool frozen = last_tok != nullptr && end_id >= 0 && last_tok[row] == end_id;
+    float* cv_out = cand_val + (long)row * K;
+    int* ci_out = cand_idx + (long)row * K;
+    if (base == -INFINITY || frozen) {              // uniform across the block: a dead or a finished hypothesis
+        if (tid < K) {
+            // finished: one continuation, end_id again at unchanged score; dead: nothing
+            const bool live = frozen && base != -INFINITY && tid == 0 && end_id < V;
+            cv_out[tid] = live ? base : -INFINITY;
+            ci_out[tid] = live ? k * V + (int)end_id : INT_MAX;
         }
-        if (tid == 0) {
-            s_lse[k] = lse;
-            s_base[k] = base;
-            s_frozen[k] = frozen ? 1 : 0;
-        }
+        return;
     }
-    __syncthreads();
-    // ---- phase 2: thread-local best KMAX candidates, kept sorted (score desc, index asc) ----
+    const float* x = logits + (long)row * ldl;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
+    m = block_reduce256(m, true, sh);
+    float s = 0.0f;
+    for (int i = tid; i < V; i += 256) s += expf(x[i] - m);
+    s = block_reduce256(s, false, sh);
+    const float lse = m + logf(s);
+    // thread-local best KMAX continuations of this row
     float val[KMAX];
     int idx[KMAX];
 #pragma unroll
@@ -64,54 +85,11 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
         val[j] = -INFINITY;
         idx[j] = INT_MAX;
     }
-    for (int k = 0; k < K; ++k) {
-        const float base = s_base[k];
-        if (base == -INFINITY) continue;
-        const float* x = logits + (long)(b * K + k) * ldl;
-        if (s_frozen[k]) {
-            // a finished hypothesis has one continuation: end_id again, score unchanged
-            if (tid == (int)(end_id % 256) && end_id < V) {
-                float cv = base;
-                int ci = k * V + (int)end_id;
-                bool shifted = false;
-#pragma unroll
-                for (int j = 0; j < KMAX; ++j) {
-                    const bool sw = shifted || cv > val[j];
-                    const float tv = val[j];
-                    const int ti = idx[j];
-                    if (sw) {
-                        val[j] = cv;
-                        idx[j] = ci;
-                        cv = tv;
-                        ci = ti;
-                    }
-                    shifted = sw;
-                }
-            }
-            continue;
-        }
-        const float lse = s_lse[k];
-        for (int i = tid; i < V; i += 256) {
-            float cv = base + (x[i] - lse);
-            if (!(cv > val[KMAX - 1])) continue;     // visited in increasing flat index: ties keep the earlier one
-            int ci = k * V + i;
-            bool shifted = false;
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j) {
-                const bool sw = shifted || cv > val[j];
-                const float tv = val[j];
-                const int ti = idx[j];
-                if (sw) {
-                    val[j] = cv;
-                    idx[j] = ci;
-                    cv = tv;
-                    ci = ti;
-                }
-                shifted = sw;
-            }
-        }
+    for (int i = tid; i < V; i += 256) {
+        const float cv = base + (x[i] - lse);
+        if (cv > val[KMAX - 1]) list_insert(val, idx, cv, k * V + i);
     }
-    // ---- phase 3: K rounds of block arg-best over the threads' list heads; the winner pops its head ----
+    // K rounds of block arg-best over the list heads; the winner pops its head
     for (int r = 0; r < K; ++r) {
         float bv = val[0];
         int bi = idx[0];
@@ -148,6 +126,39 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
             idx[KMAX - 1] = INT_MAX;
         }
         if (tid == 0) {
+            cv_out[r] = bv;
+            ci_out[r] = bi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                        int K, int V, int* __restrict__ parent,
+                                                        int64_t* __restrict__ token, float* __restrict__ scores_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float v = -INFINITY;
+    int ix = INT_MAX;
+    if (lane < K * K) {
+        v = cand_val[(long)b * K * K + lane];
+        ix = cand_idx[(long)b * K * K + lane];
+    }
+    for (int r = 0; r < K; ++r) {
+        float bv = v;
+        int bi = ix;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(ov, oi, bv, bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (ix == bi && bi != INT_MAX) {             // the winner leaves the pool
+            v = -INFINITY;
+            ix = INT_MAX;
+        }
+        if (lane == 0) {
             const bool ok = bi != INT_MAX;
             parent[b * K + r] = ok ? bi / V : 0;
             token[b * K + r] = ok ? bi % V : 0;
@@ -182,14 +193,22 @@ __global__ __launch_bounds__(256) void beam_backtrack_kernel(const int* __restri
 
 }  // namespace
 
+extern "C" int64_t sat_beam_step_ws_bytes(int B, int K) { return (int64_t)B * K * K * 8; }
+
 extern "C" int sat_beam_step(const float* logits, int64_t ldl, const float* scores_in, const int64_t* last_tokens,
                              int64_t end_id, int B, int K, int V, int32_t* parent, int64_t* token, float* scores_out,
-                             sat_stream_t stream) {
-    if (!logits || !scores_in || !parent || !token || !scores_out) return SAT_ERR_ARG;
+                             void* workspace, int64_t ws_bytes, sat_stream_t stream) {
+    if (!logits || !scores_in || !parent || !token || !scores_out || !workspace) return SAT_ERR_ARG;
     if (B <= 0 || K <= 0 || V <= 0 || ldl < V) return SAT_ERR_ARG;
     if (K > KMAX || (long)K * V > INT_MAX - 1) return SAT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl, scores_in,
-                       last_tokens, (long)end_id, K, V, parent, token, scores_out);
+    if (ws_bytes < sat_beam_step_ws_bytes(B, K)) return SAT_ERR_WORKSPACE;
+    float* cand_val = (float*)workspace;                       // [B*K rows][K]
+    int* cand_idx = (int*)(cand_val + (long)B * K * K);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(beam_row_kernel, dim3(B * K), dim3(256), 0, s, logits, (long)ldl, scores_in, last_tokens,
+                       (long)end_id, K, V, cand_val, cand_idx);
+    SAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, s, cand_val, cand_idx, K, V, parent, token, scores_out);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }

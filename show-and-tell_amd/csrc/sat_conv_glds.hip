@@ -53,6 +53,12 @@ struct ConvArgs {
     double in_count;
     float in_momentum, in_eps;
     int in_affine;
+    // Output-side fusion (inference: BatchNorm is a fixed per-channel affine): out = [relu](acc*out_scale[n] +
+    // out_shift[n] [+ residual[m][n]]) straight from the f32 accumulators -- no normalise / add launch at all.
+    const float* out_scale;
+    const float* out_shift;
+    const bf16_t* residual;  // [M][ldc] like C, or NULL
+    int out_relu;
     int dbg;                 // diagnostics only (SAT_CONV_DBG): 1 = no loads, 2 = no MFMA, 4 = no epilogue
 };
 // fixed-point scale of the atomic statistics is SAT_STAT_SCALE (sat_internal.h)
@@ -478,15 +484,22 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     // ---- epilogue 2: bf16 C tile through LDS (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ----
     if (is_consumer)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * WN + j * 32 + r;
+        float osc = 1.0f, osh = 0.0f;
+        if (p.out_scale && n0 + col < p.N) { osc = p.out_scale[n0 + col]; osh = p.out_shift[n0 + col]; }
+        const bool relu_now = p.out_relu && !p.residual;      // with a residual the ReLU follows the add (store phase)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int col = wn * WN + j * 32 + r;
-                *(bf16_t*)(smem + row * CROW + col * 2) = (bf16_t)acc[i][j][e];
+                float v = acc[i][j][e];
+                if (p.out_scale) v = v * osc + osh;
+                if (relu_now) v = fmaxf(v, 0.0f);
+                *(bf16_t*)(smem + row * CROW + col * 2) = (bf16_t)v;
             }
+    }
     __syncthreads();
     if (p.stat_partial) {
         for (int c = tid; c < BN; c += NT) {
@@ -509,8 +522,22 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         const int qid = tid + it * NT;
         const int row = qid / CPR, cc = qid - row * CPR;
         const int grow = m0 + row, gcol = n0 + cc * 8;
-        if (grow < p.M && gcol < p.N)             // N % 8 == 0: a chunk is all in or all out
-            *(u32x4*)(p.C + (long)grow * p.ldc + gcol) = *(const u32x4*)(smem + row * CROW + cc * 16);
+        if (grow < p.M && gcol < p.N) {           // N % 8 == 0: a chunk is all in or all out
+            if (p.residual) {                     // out = [relu](affine(acc) + residual), 16 bytes of each per thread
+                const bf16x8 c = *(const bf16x8*)(smem + row * CROW + cc * 16);
+                const bf16x8 z = *(const bf16x8*)(p.residual + (long)grow * p.ldc + gcol);
+                bf16x8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float v = (float)c[k] + (float)z[k];
+                    if (p.out_relu) v = fmaxf(v, 0.0f);
+                    o[k] = (bf16_t)v;
+                }
+                *(bf16x8*)(p.C + (long)grow * p.ldc + gcol) = o;
+            } else {
+                *(u32x4*)(p.C + (long)grow * p.ldc + gcol) = *(const u32x4*)(smem + row * CROW + cc * 16);
+            }
+        }
     }
 }
 
@@ -581,6 +608,9 @@ ConvArgs make_args(const sat_op* op) {
         a.in_running_mean = op->running_mean1; a.in_running_var = op->running_var1;
         a.in_count = (double)op->count; a.in_momentum = op->momentum; a.in_eps = op->eps;
     }
+    a.out_scale = op->scale1; a.out_shift = op->shift1;        // inference epilogue: affine (+ residual) (+ ReLU)
+    a.residual = (const bf16_t*)op->in1;
+    a.out_relu = op->flags & 1;
     a.M = op->N * op->Hout * op->Wout; a.N = op->Cout; a.K = op->KH * op->KW * op->Cin;
     a.ldb = a.K; a.ldc = op->Cout;
     a.Hin = op->Hin; a.Win = op->Win; a.Cin = op->Cin; a.Hout = op->Hout; a.Wout = op->Wout;
@@ -611,6 +641,9 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
     if (op->Cout % 8) return SAT_ERR_UNSUPPORTED;
     ConvArgs a = make_args(op);
     if (a.acc) a.acc += (long)parity * 2 * a.N;          // [2 parities][2][N]
+    if ((a.out_scale != nullptr) != (a.out_shift != nullptr)) return SAT_ERR_ARG;
+    if (a.residual && (!a.out_scale || (const void*)a.residual == (const void*)a.C)) return SAT_ERR_ARG;
+    if (a.out_scale && (a.stat_partial || a.acc)) return SAT_ERR_ARG;     // batch statistics and a fixed affine exclude each other
     if (a.in_affine) {
         if (!a.linear || a.Cin > 512 || (a.Cin % 64)) return SAT_ERR_UNSUPPORTED;
         if (a.in_acc) {
@@ -644,7 +677,8 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
         sat_op* op = ops + i;
         if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) continue;
         const Key key(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
-                      ((op->stat_partial || op->stat_acc) ? 1 : 0) + ((op->scale0 || op->stat_acc1) ? 2 : 0));
+                      ((op->stat_partial || op->stat_acc) ? 1 : 0) + ((op->scale0 || op->stat_acc1) ? 2 : 0) +
+                          (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0));
         auto it = cache.find(key);
         if (it != cache.end()) { op->variant = it->second; continue; }
         ConvArgs a = make_args(op);

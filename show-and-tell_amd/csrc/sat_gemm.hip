@@ -415,6 +415,7 @@ int sat_conv_launch(const sat_op* op, int parity, hipStream_t s) {
     a.sN = op->sN; a.sH = op->sH; a.sW = op->sW;
     if (op->stat_partial && op->tiles_m != sat_cdiv(a.M, 128)) return SAT_ERR_ARG;
     if (op->dtype == SAT_BF16 && (op->Cout % 8) == 0 && !conv_legacy()) return sat_conv_glds_launch(op, parity, s);
+    if (op->scale1 || op->shift1 || op->in1) return SAT_ERR_UNSUPPORTED;   // fused inference epilogue: bf16 LDS-DMA kernel only
     // register-staged kernel (f32 parity mode, odd shapes).  BM is always 128 (it fixes the partial-slab geometry); BN 64 for narrow layers or to fill the chip
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const bool narrow = (a.N <= 64) || (t128 < 512);

@@ -374,6 +374,7 @@ class DecoderRNN(nn.Module):
         scores = torch.full((B, K), float("-inf"), device=dev)
         scores[:, 0] = 0.0                       # step 0: K identical rows per image, only hypothesis 0 is live
         scores2 = torch.empty(B, K, device=dev)
+        bws = torch.empty(lib.sat_beam_step_ws_bytes(B, K), dtype=torch.uint8, device=dev)
         parents = torch.empty(steps, R, dtype=torch.int32, device=dev)
         tokens = torch.empty(steps, R, dtype=torch.int64, device=dev)
         x = features.repeat_interleave(K, 0).contiguous()
@@ -391,7 +392,7 @@ class DecoderRNN(nn.Module):
                                              L.ptr(logits), ldl, st), "sat_vocab_logits_fwd")
             last = tokens[i - 1].data_ptr() if (i > 0 and eid >= 0) else None
             L.check(lib.sat_beam_step(L.ptr(logits), ldl, L.ptr(scores), last, eid, B, K, V, parents[i].data_ptr(),
-                                      tokens[i].data_ptr(), L.ptr(scores2), st), "sat_beam_step")
+                                      tokens[i].data_ptr(), L.ptr(scores2), L.ptr(bws), bws.numel(), st), "sat_beam_step")
             scores, scores2 = scores2, scores
             if K > 1:
                 for l in range(self.num_layers):

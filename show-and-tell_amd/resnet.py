@@ -212,6 +212,7 @@ class ConvStackProgram:
         self._parity = 0
         bnref = {}
         fuse_in_bn = dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_INPUT_BN", "1") != "0"   # bn2+ReLU inside conv3
+        fuse_out_bn = (not training) and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_EVAL_BN", "1") != "0"
         if atomic_stats:
             self.stat_acc = alloc((nbn, 2, 2, cmax), torch.int64, zero=True)
 
@@ -307,6 +308,25 @@ class ConvStackProgram:
         for blk, (h, w_, h2, w2, inpl, planes, stride) in zip(stack.blocks(), geo):
             tm1 = L.load().sat_conv_tiles_m(N * h * w_)
             tm2 = L.load().sat_conv_tiles_m(N * h2 * w2)
+            if fuse_out_bn:
+                # inference: every BatchNorm is a fixed per-channel affine -> it rides in the producing conv's epilogue
+                # together with the residual add and the ReLU: 3-4 launches per bottleneck instead of 6-8
+                def fused(conv, bn, x, out, hin, win, hout, wout, count, relu, resid=None):
+                    cv = std_conv(conv, x, out, N, hin, win, hout, wout)
+                    _, s_, t_ = fin_op(bn, conv.cout, count, 0)
+                    cv.scale1, cv.shift1, cv.flags = s_.data_ptr(), t_.data_ptr(), 1 if relu else 0
+                    if resid is not None:
+                        cv.in1 = resid.data_ptr()
+                    ops.append(cv)
+                fused(blk.conv1, blk.bn1, y, self.a1, h, w_, h, w_, N * h * w_, True)
+                fused(blk.conv2, blk.bn2, self.a1, self.a2, h, w_, h2, w2, N * h2 * w2, True)
+                resid = y
+                if blk.downsample is not None:
+                    fused(blk.downsample[0], blk.downsample[1], y, self.cd, h, w_, h2, w2, N * h2 * w2, False)
+                    resid = self.cd
+                fused(blk.conv3, blk.bn3, self.a2, ynext, h2, w2, h2, w2, N * h2 * w2, True, resid)
+                y, ynext = ynext, y
+                continue
             ops.append(std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_))
             f, s1, t1 = fin_op(blk.bn1, planes, N * h * w_, tm1)
             add(f)

@@ -163,8 +163,9 @@ def test_beam_step_ties_dead_and_finished_hypotheses():
     token = torch.empty(B * K, dtype=torch.int64, device="cuda")
     out = torch.empty(B * K, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(lib.sat_beam_step_ws_bytes(B, K), dtype=torch.uint8, device="cuda")
     L.check(lib.sat_beam_step(logits.data_ptr(), V, scores.data_ptr(), last.data_ptr(), 2, B, K, V, parent.data_ptr(),
-                              token.data_ptr(), out.data_ptr(), st))
+                              token.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), st))
     parent, token, out = parent.cpu().view(B, K), token.cpu().view(B, K), out.cpu().view(B, K)
     # image 0: everything ties at -log(V): flat indices 0, 1, 2 of hypothesis 0
     assert parent[0].tolist() == [0, 0, 0] and token[0].tolist() == [0, 1, 2]
@@ -175,8 +176,10 @@ def test_beam_step_ties_dead_and_finished_hypotheses():
     np.testing.assert_allclose(out[1].numpy(), [-0.5, -1.0 + 3.0 - lse1, -1.0 - math.log(V)], atol=1e-5)
     # argument errors
     assert lib.sat_beam_step(logits.data_ptr(), V, scores.data_ptr(), None, -1, B, 9, V, parent.data_ptr(),
-                             token.data_ptr(), out.data_ptr(), st) == 1003
-    assert lib.sat_beam_step(None, V, scores.data_ptr(), None, -1, B, K, V, None, None, None, st) == 1001
+                             token.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), st) == 1003
+    assert lib.sat_beam_step(logits.data_ptr(), V, scores.data_ptr(), None, -1, B, K, V, parent.data_ptr(),
+                             token.data_ptr(), out.data_ptr(), ws.data_ptr(), 8, st) == 1002
+    assert lib.sat_beam_step(None, V, scores.data_ptr(), None, -1, B, K, V, None, None, None, None, 0, st) == 1001
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -237,6 +240,31 @@ def test_encoder_bf16_close_to_oracle():
     d2 = (pooled.cpu() - ref_bf)
     assert (d2.norm() / ref_bf.norm()).item() < 0.01, (d2.norm() / ref_bf.norm()).item()
     assert d2.abs().max().item() < 0.03 * ref_bf.abs().max().item() + 0.01
+
+
+def test_encoder_bf16_eval_fused_epilogues_vs_unfused_and_oracle(monkeypatch):
+    """eval mode (eval.py:65): BatchNorm + add + ReLU ride in the conv epilogues (SAT_FUSE_EVAL_BN=1, default) -- against
+    the unfused op sequence (same kernels + separate normalise launches) and against the f32 oracle in eval mode"""
+    arch, E, B = SMALL, 32, 8
+    x = torch.randn(B, 3, 96, 96, generator=torch.Generator().manual_seed(26))
+    monkeypatch.setenv("SAT_FUSE_EVAL_BN", "0")
+    plain, params, buffers = _encoder_pair(arch, E, 25, "bf16")
+    ref_plain = plain.eval().pooled_features(x.cuda()).clone()
+    n_plain = next(iter(plain._programs.values())).n_ops
+    monkeypatch.setenv("SAT_FUSE_EVAL_BN", "1")
+    fused, _, _ = _encoder_pair(arch, E, 25, "bf16")
+    out = fused.eval().pooled_features(x.cuda()).clone()
+    n_fused = next(iter(fused._programs.values())).n_ops
+    assert n_plain - n_fused >= 2 * sum(arch["layers"])  # per bottleneck at least the bn1+ReLU and bn3+add+ReLU launches are gone
+    d = (out - ref_plain).float()
+    assert (d.norm() / ref_plain.float().norm()).item() < 0.01          # one bf16 rounding fewer per BatchNorm
+    bufs = {k: v.clone() for k, v in buffers.items()}
+    pooled_ref, _ = OE.resnet_forward(params, bufs, x, arch, training=False)
+    rel = ((out.cpu() - pooled_ref).norm() / pooled_ref.norm()).item()
+    rel_plain = ((ref_plain.cpu() - pooled_ref).norm() / pooled_ref.norm()).item()
+    assert rel < 0.05 and rel <= rel_plain * 1.25 + 1e-3, (rel, rel_plain)
+    for k in ("resnet.bn1.running_mean", "resnet.layer2.0.bn3.running_var"):      # eval never touches the statistics
+        assert torch.equal(fused.state_dict()[k].cpu(), buffers[k])
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
