@@ -2,7 +2,7 @@
 // One decode step per image = log-softmax of K rows of logits + top-K over the K*V candidates + LSTM state
 // re-ordering by parent; the sequences are recovered at the end by walking the (parent, token) back-pointers.
 // HBM/L2-bound byte/compare work, two launches per step:
-//   beam_row_kernel   one workgroup per (image, hypothesis) row: log-sum-exp of the row (max pass, sum pass) and the
+//   beam_row_kernel   one workgroup per (image, hypothesis) row, the row read ONCE into registers: log-sum-exp and the
 //                     row's K best continuations (thread-local sorted lists in registers, K rounds of block arg-best);
 //   beam_merge_kernel one wave per image: the K best of its K*K row candidates.
 // The union of per-row top-K lists contains the global top-K, and both kernels order candidates by (score desc, flat
@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int KMAX = 8;   // beam width limit (thread-local candidate lists live in registers; K*K <= one wave)
+constexpr int RC = 12;    // 16-byte chunks of a logits row a thread keeps in registers (V <= 12288 rows are read once)
 
 // a better than b: higher score, ties -> lower flat candidate index (k*V + v)
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
@@ -70,13 +71,6 @@ __global__ __launch_bounds__(256) void beam_row_kernel(const float* __restrict__
         return;
     }
     const float* x = logits + (long)row * ldl;
-    float m = -INFINITY;
-    for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
-    m = block_reduce256(m, true, sh);
-    float s = 0.0f;
-    for (int i = tid; i < V; i += 256) s += expf(x[i] - m);
-    s = block_reduce256(s, false, sh);
-    const float lse = m + logf(s);
     // thread-local best KMAX continuations of this row
     float val[KMAX];
     int idx[KMAX];
@@ -85,9 +79,60 @@ __global__ __launch_bounds__(256) void beam_row_kernel(const float* __restrict__
         val[j] = -INFINITY;
         idx[j] = INT_MAX;
     }
-    for (int i = tid; i < V; i += 256) {
-        const float cv = base + (x[i] - lse);
-        if (cv > val[KMAX - 1]) list_insert(val, idx, cv, k * V + i);
+    const int nq = V >> 2;                                   // whole 16-byte chunks (rows are 16-byte aligned: ldl % 4 == 0)
+    if ((ldl & 3) == 0 && nq <= RC * 256) {
+        // the row lives in registers: ONE pass over memory, then max, sum and selection from registers.
+        // A thread's elements are visited in increasing index order (chunk tid, tid+256, ...; tail last).
+        f32x4 rc[RC];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            const int q = tid + c * 256;
+            if (q < nq) rc[c] = *(const f32x4*)(x + 4 * q);
+        }
+        const int tail = (nq << 2) + tid;                    // V % 4 leftover elements, one per thread
+        const float xt = tail < V ? x[tail] : -INFINITY;
+        float m = xt;
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+            if (tid + c * 256 < nq) m = fmaxf(fmaxf(fmaxf(m, rc[c][0]), fmaxf(rc[c][1], rc[c][2])), rc[c][3]);
+        m = block_reduce256(m, true, sh);
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+            if (tid + c * 256 < nq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += expf(rc[c][e] - m);
+            }
+        if (tail < V) s += expf(xt - m);
+        s = block_reduce256(s, false, sh);
+        const float lse = m + logf(s);
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            const int q = tid + c * 256;
+            if (q < nq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float cv = base + (rc[c][e] - lse);
+                    if (cv > val[KMAX - 1]) list_insert(val, idx, cv, k * V + 4 * q + e);
+                }
+            }
+        }
+        if (tail < V) {
+            const float cv = base + (xt - lse);
+            if (cv > val[KMAX - 1]) list_insert(val, idx, cv, k * V + tail);
+        }
+    } else {
+        float m = -INFINITY;
+        for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
+        m = block_reduce256(m, true, sh);
+        float s = 0.0f;
+        for (int i = tid; i < V; i += 256) s += expf(x[i] - m);
+        s = block_reduce256(s, false, sh);
+        const float lse = m + logf(s);
+        for (int i = tid; i < V; i += 256) {
+            const float cv = base + (x[i] - lse);
+            if (cv > val[KMAX - 1]) list_insert(val, idx, cv, k * V + i);
+        }
     }
     // K rounds of block arg-best over the list heads; the winner pops its head
     for (int r = 0; r < K; ++r) {
