@@ -12,7 +12,10 @@ Layout: activations NHWC (channels contiguous -> the implicit-GEMM K axis is con
     c2 = conv3x3(a1)     stats -> (s2,t2)    a2 = relu(c2*s2+t2)
     c3 = conv1x1(a2)     stats -> (s3,t3)    [cd = conv1x1(y), stats -> (sd,td)]
     y' = relu(c3*s3+t3 + (cd*sd+td | y))
-Batch statistics come out of the conv epilogue as per-tile column sums (fixed-order reduction, no atomics).
+Training: batch statistics come out of the conv epilogue, as per-tile column sums reduced in fixed order by a finalize
+launch, or (bf16, few M-tiles) as fixed-point integer atomics the consuming kernel turns into (scale, shift) itself;
+conv3 applies bn2+ReLU to its operand in LDS.  Inference (bf16): every BatchNorm is a per-channel affine folded into
+the producing conv's epilogue with the residual add and the ReLU.  The whole program replays as one hipGraph.
 """
 import ctypes as C
 import math
