@@ -175,7 +175,9 @@ int sat_lstm_fwd(const float* X /*[N,In]*/, const float* w_ih /*[4H,In]*/, const
                  const float* b_ih, const float* b_hh, const int32_t* batch_sizes /*[T] host*/, int T,
                  int In, int H, float* GA, float* CS, float* HS, float* HP, float* c_state,
                  sat_stream_t stream);
-int64_t sat_lstm_bwd_ws_bytes(int B, int H);
+int64_t sat_lstm_bwd_ws_bytes(int B, int H);          /* minimum */
+/* size that also lets the batched dW_ih / dX GEMMs run split-K when they would leave most CUs idle (N = packed rows) */
+int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H);
 int sat_lstm_bwd(const float* dHS /*[N,H]*/, const float* X, const float* w_ih, const float* w_hh,
                  const float* GA, const float* CS, const float* HP,
                  const int32_t* batch_sizes /*[T] host*/, int T, int In, int H,

@@ -183,6 +183,26 @@ extern "C" int64_t sat_lstm_bwd_ws_bytes(int B, int H) {
     return (int64_t)(lstm_bwd_split(H) + 1) * B * H * sizeof(float);
 }
 
+// split-K factor that fills the chip when a GEMM has fewer than ~192 tiles of 64x64 (the batched dX / dW_ih GEMMs at
+// small In): the K range is dealt over grid.y and the slabs are summed in fixed order
+static int fill_split(long M, long Nn, long K) {
+    const long tiles = (long)sat_cdiv(M, 64) * sat_cdiv(Nn, 64);
+    if (tiles >= 192 || K < 256) return 1;
+    long ks = 384 / (tiles > 0 ? tiles : 1);
+    const long max_by_k = K / 128;
+    if (ks > max_by_k) ks = max_by_k;
+    return (int)(ks < 1 ? 1 : (ks > 8 ? 8 : ks));
+}
+
+// workspace that additionally lets sat_lstm_bwd run its under-filled weight/input-gradient GEMMs split-K
+extern "C" int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H) {
+    const int64_t base = sat_lstm_bwd_ws_bytes(B, H);
+    const int64_t dx = (int64_t)fill_split(N, In, 4L * H) * N * In * sizeof(float);
+    const int64_t dw = (int64_t)fill_split(4L * H, In, N) * 4 * H * In * sizeof(float);
+    const int64_t extra = dx > dw ? dx : dw;
+    return base > extra ? base : extra;
+}
+
 extern "C" int sat_lstm_bwd(const float* dHS, const float* X, const float* w_ih, const float* w_hh, const float* GA,
                             const float* CS, const float* HP, const int32_t* batch_sizes, int T, int In, int H,
                             float* DG, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dX,
@@ -213,13 +233,31 @@ extern "C" int sat_lstm_bwd(const float* dHS, const float* X, const float* w_ih,
         if (t > 0)   // dh_{t-1} partial slabs = DG_t * W_hh   (K = 4H split over nz workgroup slices)
             SAT_TRY(sat_skinny_store(DG + off * 4 * H, 4L * H, w_hh, H, 1, n, H, 4 * H, nz, dh_part, H, slab, nullptr, s));
     }
-    // batched weight gradients over all packed rows
-    SAT_TRY(sat_gemm_f32(2, 1, DG, 4L * H, X, In, dw_ih, In, nullptr, nullptr, 4 * H, In, (int)N, stream));
+    // batched weight gradients over all packed rows (the recurrence above is done with the workspace: it is free for
+    // split-K slabs when the caller sized it with sat_lstm_bwd_ws_bytes_full)
+    const bool roomy = ws_bytes >= sat_lstm_bwd_ws_bytes_full((int)N, B, In, H);
+    const int ks_dw = roomy ? fill_split(4L * H, In, N) : 1;
+    if (ks_dw > 1) {
+        SAT_TRY(sat_gemm_f32_splitk(2, 1, DG, 4L * H, X, In, workspace, In, nullptr, nullptr, 4 * H, In, (int)N, ks_dw,
+                                    (int64_t)4 * H * In, stream));
+        SAT_TRY(sat_sum_slabs_f32(workspace, ks_dw, (int64_t)4 * H * In, (int64_t)4 * H * In, dw_ih, stream));
+    } else {
+        SAT_TRY(sat_gemm_f32(2, 1, DG, 4L * H, X, In, dw_ih, In, nullptr, nullptr, 4 * H, In, (int)N, stream));
+    }
     SAT_TRY(sat_gemm_f32(2, 1, DG, 4L * H, HP, H, dw_hh, H, nullptr, nullptr, 4 * H, H, (int)N, stream));
     SAT_TRY(sat_colsum_f32(DG, 4L * H, (int)N, 4 * H, db_ih, stream));
     e = hipMemcpyAsync(db_hh, db_ih, (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return (int)e;
-    if (dX) SAT_TRY(sat_gemm_f32(0, 1, DG, 4L * H, w_ih, In, dX, In, nullptr, nullptr, (int)N, In, 4 * H, stream));
+    if (dX) {
+        const int ks_dx = roomy ? fill_split(N, In, 4L * H) : 1;
+        if (ks_dx > 1) {
+            SAT_TRY(sat_gemm_f32_splitk(0, 1, DG, 4L * H, w_ih, In, workspace, In, nullptr, nullptr, (int)N, In, 4 * H, ks_dx,
+                                        (int64_t)N * In, stream));
+            SAT_TRY(sat_sum_slabs_f32(workspace, ks_dx, (int64_t)N * In, (int64_t)N * In, dX, stream));
+        } else {
+            SAT_TRY(sat_gemm_f32(0, 1, DG, 4L * H, w_ih, In, dX, In, nullptr, nullptr, (int)N, In, 4 * H, stream));
+        }
+    }
     return SAT_OK;
 }
 

@@ -13,6 +13,8 @@ signatures (`/root/reference/models.py:9-67`), every tensor op behind them a lib
 `clip_gradient` + `optim.Adam` loop works unchanged; `trainer.TrainStep` is the fused HIP replacement.
 The modules run on the GPU only: there is no CPU fallback.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -20,6 +22,7 @@ from . import _lib as L
 from .pack import PackInfo
 from .resnet import RESNET152, ConvStackProgram, ResNetStack
 
+_LSTM_SPLITK = os.environ.get("SAT_LSTM_SPLITK", "1") != "0"   # roomy LSTM-backward workspace => split-K dW_ih / dX GEMMs
 BN1D_MOMENTUM = 0.01   # models.py:17
 BN_EPS = 1e-5
 
@@ -223,7 +226,7 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
         GA, CS, HP = tapes["layers"][l]
         DG = torch.empty(N, 4 * H, device=dev)
         dX = torch.empty(N, In, device=dev)
-        wsb = lib.sat_lstm_bwd_ws_bytes(B, H)
+        wsb = lib.sat_lstm_bwd_ws_bytes_full(N, B, In, H) if _LSTM_SPLITK else lib.sat_lstm_bwd_ws_bytes(B, H)
         ws = torch.empty(wsb // 4, device=dev)
         L.check(lib.sat_lstm_bwd(L.ptr(dH), L.ptr(tapes["X"][l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(GA), L.ptr(CS),
                                  L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
