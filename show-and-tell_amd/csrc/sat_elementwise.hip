@@ -470,6 +470,57 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(float* __restrict__ logits
     __shared__ float sh[4];
     const int row = blockIdx.x;
     float* x = logits + (long)row * ldl;
+    constexpr int RC = 12;                       // 16-byte chunks of the row a thread keeps in registers
+    const int nq = V >> 2;
+    if ((ldl & 3) == 0 && nq <= RC * 256 && (((uintptr_t)logits) & 15) == 0) {
+        // V <= 12288: the row is read ONCE into registers; max, sum and the gradient come from there (one read + one
+        // write of the logits instead of three reads + one write)
+        const int tid = threadIdx.x;
+        f32x4 rc[RC];
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+            if (tid + c * 256 < nq) rc[c] = *(const f32x4*)(x + 4 * (tid + c * 256));
+        const int tail = (nq << 2) + tid;
+        const float xt = tail < V ? x[tail] : -INFINITY;
+        float m = xt;
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+            if (tid + c * 256 < nq) m = fmaxf(fmaxf(fmaxf(m, rc[c][0]), fmaxf(rc[c][1], rc[c][2])), rc[c][3]);
+        m = block_reduce(m, true, sh);
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+            if (tid + c * 256 < nq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += expf(rc[c][e] - m);
+            }
+        if (tail < V) s += expf(xt - m);
+        s = block_reduce(s, false, sh);
+        const float lse = m + logf(s);
+        long tgt = targets[row];
+        tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+        const int tq = (int)(tgt >> 2), te = (int)(tgt & 3);
+        // the thread that holds the target logit reports the row loss
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+            if (tid + c * 256 == tq && tq < nq) row_loss[row] = lse - rc[c][te];
+        if (tail == (int)tgt && tq >= nq) row_loss[row] = lse - xt;
+        if (write_grad) {
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                const int q = tid + c * 256;
+                if (q < nq) {
+                    f32x4 g;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        g[e] = (expf(rc[c][e] - lse) - ((4 * q + e) == (int)tgt ? 1.0f : 0.0f)) * inv_denom;
+                    *(f32x4*)(x + 4 * q) = g;
+                }
+            }
+            if (tail < V) x[tail] = (expf(xt - lse) - (tail == (int)tgt ? 1.0f : 0.0f)) * inv_denom;
+        }
+        return;
+    }
     float m = -INFINITY;
     for (int i = threadIdx.x; i < V; i += 256) m = fmaxf(m, x[i]);
     m = block_reduce(m, true, sh);
