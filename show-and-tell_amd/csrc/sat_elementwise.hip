@@ -304,12 +304,14 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ in, T* __restrict__
     const int cch = C / V;
     const long total = (long)N * Hout * Wout * cch;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cc = (int)(i % cch);
-        long r = i / cch;
-        const int wo = (int)(r % Wout); r /= Wout;
-        const int ho = (int)(r % Hout);
-        const int n = (int)(r / Hout);
-        const int c0 = cc * V;
+        // 32-bit index math (the launcher guarantees total < 2^31): 64-bit div/mod would cost more than the 9 loads
+        const unsigned iu = (unsigned)i;
+        const unsigned cc = iu % (unsigned)cch;
+        unsigned r = iu / (unsigned)cch;
+        const int wo = (int)(r % (unsigned)Wout); r /= (unsigned)Wout;
+        const int ho = (int)(r % (unsigned)Hout);
+        const int n = (int)(r / (unsigned)Hout);
+        const int c0 = (int)cc * V;
         float sc[V], sh[V], best[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) { sc[k] = s[c0 + k]; sh[k] = t[c0 + k]; best[k] = 0.0f; }  // relu >= 0
@@ -338,15 +340,32 @@ __global__ void avgpool_kernel(const T* __restrict__ in, float* __restrict__ out
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cc = (int)(i % cch);
         const int n = (int)(i / cch);
-        float acc[V];
+        // 4 independent partial sums (pixels p, p+1, p+2, p+3 of every group of 4) keep 4 loads in flight; combined in
+        // a fixed order
+        float part[4][V], acc[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) acc[k] = 0.0f;
-        for (int p = 0; p < HW; ++p) {
-            float x[V];
-            load_chunk<T>(in + ((long)n * HW + p) * C + cc * V, x);
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int k = 0; k < V; ++k) acc[k] += x[k];
+            for (int k = 0; k < V; ++k) part[u][k] = 0.0f;
+        const T* base = in + (long)n * HW * C + cc * V;
+        int p = 0;
+        for (; p + 3 < HW; p += 4) {
+            float x[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load_chunk<T>(base + (long)(p + u) * C, x[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < V; ++k) part[u][k] += x[u][k];
         }
+        for (; p < HW; ++p) {
+            float x[V];
+            load_chunk<T>(base + (long)p * C, x);
+#pragma unroll
+            for (int k = 0; k < V; ++k) part[0][k] += x[k];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
         const float inv = 1.0f / (float)HW;
 #pragma unroll
         for (int k = 0; k < V; ++k) out[(long)n * C + cc * V + k] = acc[k] * inv;
@@ -875,11 +894,13 @@ int sat_bn_relu_maxpool_launch(const sat_op* op, hipStream_t s) {
     if (op->dtype == SAT_BF16) {
         if (C % 8) return SAT_ERR_ARG;
         const long total = (long)op->N * op->Hout * op->Wout * (C / 8);
+        if (total >= (1L << 31)) return SAT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const bf16_t*)op->in0,
                            (bf16_t*)op->out, op->scale0, op->shift0, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
     } else {
         if (C % 4) return SAT_ERR_ARG;
         const long total = (long)op->N * op->Hout * op->Wout * (C / 4);
+        if (total >= (1L << 31)) return SAT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const float*)op->in0,
                            (float*)op->out, op->scale0, op->shift0, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
     }
