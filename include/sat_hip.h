@@ -53,7 +53,8 @@ int sat_gemm_f32(int amode, int bmode, const float* A, int64_t lda, const float*
 enum {
     SAT_OP_IMAGE_PREP = 1, /* NCHW f32 image -> zero-padded NHWC4 (in0 -> out); H/W = Hin/Win, pad = border */
     SAT_OP_CONV = 2,       /* implicit-GEMM conv: in0 (NHWC) * w [Cout][KH*KW*Cin] -> out [M][Cout] (+ stat_partial) */
-    SAT_OP_BN_FINALIZE = 3,/* partials -> scale/shift (+ running stats update) */
+    SAT_OP_BN_FINALIZE = 3,/* partials -> scale/shift (+ running stats update); with stat_acc set ("acc mode"):
+                            * partials -> the fixed-point integer accumulators stat_acc (parity half), consumers derive */
     SAT_OP_BN_RELU = 4,    /* out = relu(in0*scale0 + shift0) */
     SAT_OP_BN_ADD_RELU = 5,/* out = relu(in0*scale0+shift0 + (in1*scale1+shift1 | in1)) */
     SAT_OP_BN_RELU_MAXPOOL = 6, /* out = maxpool3x3/2(relu(in0*scale0+shift0)) */

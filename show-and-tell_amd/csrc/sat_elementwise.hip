@@ -135,6 +135,46 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
 }
 
+// per-tile slabs -> fixed-point integer accumulators: workgroup (x, y) sums tiles [128y, 128y+128) of channels
+// [32x, 32x+32) in f64 (fixed order) and adds the two totals with 64-bit INTEGER atomics (order-independent)
+constexpr int SLAB_TILES_PER_WG = 128;
+__global__ __launch_bounds__(1024) void bn_slab_to_acc_kernel(const float* __restrict__ partial, int tiles_m, int C,
+                                                              long long* __restrict__ acc) {
+    __shared__ double ss[FIN_G][32], sq[FIN_G][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int t0 = blockIdx.y * SLAB_TILES_PER_WG;
+    const int t1 = (t0 + SLAB_TILES_PER_WG < tiles_m) ? t0 + SLAB_TILES_PER_WG : tiles_m;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        float a[SLAB_TILES_PER_WG / FIN_G], b[SLAB_TILES_PER_WG / FIN_G];
+#pragma unroll
+        for (int u = 0; u < SLAB_TILES_PER_WG / FIN_G; ++u) {        // all of a thread's loads in flight together
+            const int t = t0 + rg + u * FIN_G;
+            a[u] = t < t1 ? partial[((long)t * 2 + 0) * C + c] : 0.0f;
+            b[u] = t < t1 ? partial[((long)t * 2 + 1) * C + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < SLAB_TILES_PER_WG / FIN_G; ++u) {
+            s += (double)a[u];
+            q += (double)b[u];
+        }
+    }
+    ss[rg][cl] = s;
+    sq[rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int g = 0; g < FIN_G; ++g) {
+            S += ss[g][cl];
+            Q += sq[g][cl];
+        }
+        atomicAdd((unsigned long long*)(acc + c), (unsigned long long)__double2ll_rn(S * SAT_STAT_SCALE));
+        atomicAdd((unsigned long long*)(acc + C + c), (unsigned long long)__double2ll_rn(Q * SAT_STAT_SCALE));
+    }
+}
+
 // eval mode: (scale, shift) of EVERY BatchNorm of the stack from its running statistics, one workgroup per layer
 // (same float arithmetic as bn_finalize_kernel's eval branch)
 __global__ __launch_bounds__(256) void bn_eval_batch_kernel(const sat_bn_eval_item* __restrict__ items, float eps) {
@@ -298,9 +338,18 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
 
 // out[n][ho][wo][c] = max_{3x3, stride 2, pad 1} relu(in*s + t)
 template <typename T>
-__global__ void bn_relu_maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ s,
-                                       const float* __restrict__ t, int N, int Hin, int Win, int C, int Hout, int Wout) {
+__global__ void bn_relu_maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, const BnSrc b, double count,
+                                       float momentum, float eps, int N, int Hin, int Win, int C, int Hout, int Wout) {
     constexpr int V = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float tab[];      // [2][C] when the table is derived here
+    const float* s = b.scale;
+    const float* t = b.shift;
+    if (b.acc) {                // statistics arrive as integer sums: derive (scale, shift) like bn_act_kernel does
+        bn_table_from_acc(b, C, count, momentum, eps, tab, tab + C);
+        __syncthreads();
+        s = tab;
+        t = tab + C;
+    }
     const int cch = C / V;
     const long total = (long)N * Hout * Wout * cch;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -811,7 +860,18 @@ int sat_bn_eval_batch_launch(const sat_op* op, hipStream_t s) {
     return SAT_OK;
 }
 
-int sat_bn_finalize_launch(const sat_op* op, hipStream_t s) {
+int sat_bn_finalize_launch(const sat_op* op, int parity, hipStream_t s) {
+    if (op->stat_acc) {
+        // "acc mode": many-tile layers.  The per-tile slabs are reduced by MANY small workgroups (128 tiles each) into
+        // the same fixed-point integer accumulators the few-tile convs feed directly, and the consuming kernel derives
+        // (scale, shift) itself: ~3 us of wide parallel work instead of a 5-11 us latency-bound tail of 2-16 workgroups.
+        if (!op->stat_partial || op->tiles_m < 1 || op->Cout < 1) return SAT_ERR_ARG;
+        long long* acc = (long long*)op->stat_acc + (long)parity * 2 * op->Cout;
+        hipLaunchKernelGGL(bn_slab_to_acc_kernel, dim3(sat_cdiv(op->Cout, 32), sat_cdiv(op->tiles_m, SLAB_TILES_PER_WG)),
+                           dim3(1024), 0, s, op->stat_partial, op->tiles_m, op->Cout, acc);
+        SAT_LAUNCH_CHECK();
+        return SAT_OK;
+    }
     if (!op->gamma || !op->beta || !op->scale_out || !op->shift_out) return SAT_ERR_ARG;
     if (op->training && !op->stat_partial) return SAT_ERR_ARG;
     if (!op->training && (!op->running_mean || !op->running_var)) return SAT_ERR_ARG;
@@ -864,7 +924,7 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
     int grid = ew_grid(nch);
     if (lds) {          // every workgroup derives the affine table first: fewer, fatter workgroups amortise that prologue
         static int cap = 0;
-        if (cap == 0) { const char* e = getenv("SAT_BN_DERIVE_GRID"); cap = e ? atoi(e) : 768; if (cap < 1) cap = 768; }
+        if (cap == 0) { const char* e = getenv("SAT_BN_DERIVE_GRID"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
         if (grid > cap) grid = cap;
     }
     if (cch > EW_BLOCK && (cch % EW_BLOCK) == 0) {
@@ -888,21 +948,36 @@ int sat_bn_act_launch(const sat_op* op, bool add, int parity, hipStream_t s) {
     return op->dtype == SAT_BF16 ? bn_act_launch_t<bf16_t>(op, add, parity, s) : bn_act_launch_t<float>(op, add, parity, s);
 }
 
-int sat_bn_relu_maxpool_launch(const sat_op* op, hipStream_t s) {
-    if (!op->in0 || !op->out || !op->scale0 || !op->shift0) return SAT_ERR_ARG;
+int sat_bn_relu_maxpool_launch(const sat_op* op, int parity, hipStream_t s) {
+    if (!op->in0 || !op->out) return SAT_ERR_ARG;
     const int C = op->Cout;
+    BnSrc b = {};
+    b.scale = op->scale0; b.shift = op->shift0;
+    size_t lds = 0;
+    if (op->stat_acc) {
+        if (!op->gamma || !op->beta || op->count < 1) return SAT_ERR_ARG;
+        long long* base = (long long*)op->stat_acc;
+        b.acc = base + (long)parity * 2 * C;
+        b.acc_clear = base + (long)(1 - parity) * 2 * C;
+        b.gamma = op->gamma; b.beta = op->beta; b.running_mean = op->running_mean; b.running_var = op->running_var;
+        lds = (size_t)2 * C * sizeof(float);
+        if (lds > 64 * 1024) return SAT_ERR_UNSUPPORTED;
+    } else if (!op->scale0 || !op->shift0) {
+        return SAT_ERR_ARG;
+    }
+    const double count = (double)op->count;
     if (op->dtype == SAT_BF16) {
         if (C % 8) return SAT_ERR_ARG;
         const long total = (long)op->N * op->Hout * op->Wout * (C / 8);
         if (total >= (1L << 31)) return SAT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const bf16_t*)op->in0,
-                           (bf16_t*)op->out, op->scale0, op->shift0, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_BLOCK), lds, s, (const bf16_t*)op->in0,
+                           (bf16_t*)op->out, b, count, op->momentum, op->eps, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
     } else {
         if (C % 4) return SAT_ERR_ARG;
         const long total = (long)op->N * op->Hout * op->Wout * (C / 4);
         if (total >= (1L << 31)) return SAT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const float*)op->in0,
-                           (float*)op->out, op->scale0, op->shift0, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), lds, s, (const float*)op->in0,
+                           (float*)op->out, b, count, op->momentum, op->eps, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
     }
     SAT_LAUNCH_CHECK();
     return SAT_OK;

@@ -30,10 +30,10 @@ extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_
         switch (op->kind) {
             case SAT_OP_IMAGE_PREP: rc = sat_image_prep_launch(op, s); break;
             case SAT_OP_CONV: rc = sat_conv_launch(op, parity, s); break;
-            case SAT_OP_BN_FINALIZE: rc = sat_bn_finalize_launch(op, s); break;
+            case SAT_OP_BN_FINALIZE: rc = sat_bn_finalize_launch(op, parity, s); break;
             case SAT_OP_BN_RELU: rc = sat_bn_act_launch(op, false, parity, s); break;
             case SAT_OP_BN_ADD_RELU: rc = sat_bn_act_launch(op, true, parity, s); break;
-            case SAT_OP_BN_RELU_MAXPOOL: rc = sat_bn_relu_maxpool_launch(op, s); break;
+            case SAT_OP_BN_RELU_MAXPOOL: rc = sat_bn_relu_maxpool_launch(op, parity, s); break;
             case SAT_OP_AVGPOOL: rc = sat_avgpool_launch(op, s); break;
             case SAT_OP_BN_EVAL_BATCH: rc = sat_bn_eval_batch_launch(op, s); break;
             default: rc = SAT_ERR_UNSUPPORTED;
@@ -96,7 +96,7 @@ extern "C" int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, 
         return SAT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     SAT_TRY(sat_conv_launch(conv, 0, s));
-    SAT_TRY(sat_bn_finalize_launch(finalize, s));
+    SAT_TRY(sat_bn_finalize_launch(finalize, 0, s));
     return sat_bn_act_launch(bnrelu, false, 0, s);
 }
 

@@ -5,10 +5,10 @@
 
 int sat_conv_launch(const sat_op* op, int parity, hipStream_t s);
 int sat_image_prep_launch(const sat_op* op, hipStream_t s);
-int sat_bn_finalize_launch(const sat_op* op, hipStream_t s);
+int sat_bn_finalize_launch(const sat_op* op, int parity, hipStream_t s);
 int sat_bn_eval_batch_launch(const sat_op* op, hipStream_t s);
 int sat_bn_act_launch(const sat_op* op, bool add, int parity, hipStream_t s);
-int sat_bn_relu_maxpool_launch(const sat_op* op, hipStream_t s);
+int sat_bn_relu_maxpool_launch(const sat_op* op, int parity, hipStream_t s);
 int sat_avgpool_launch(const sat_op* op, hipStream_t s);
 
 int sat_skinny_store(const float* A, long lda, const float* W, long ldw, int wkm, int M, int N, int K, int nz,

@@ -215,6 +215,7 @@ class ConvStackProgram:
         self._parity = 0
         bnref = {}
         fuse_in_bn = dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_INPUT_BN", "1") != "0"   # bn2+ReLU inside conv3
+        slab_to_acc = os.environ.get("SAT_SLAB_TO_ACC", "1") != "0"
         fuse_out_bn = (not training) and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_EVAL_BN", "1") != "0"
         if atomic_stats:
             self.stat_acc = alloc((nbn, 2, 2, cmax), torch.int64, zero=True)
@@ -232,6 +233,17 @@ class ConvStackProgram:
                 bnref[s.data_ptr()] = (self.stat_acc[i].data_ptr(), bn, count)
                 self.bn_list.append(bn)
                 return None, s, t
+            if atomic_stats and consumer_can_derive and slab_to_acc:
+                # many M-tiles: the conv keeps writing per-tile slabs (no contended atomics), a wide reducer launch
+                # folds them into the same integer accumulators, and the consumer derives (scale, shift) as above
+                i = bn_idx[0] - 1
+                o = L.SatOp()
+                o.kind, o.dtype = L.OP_BN_FINALIZE, dtype
+                o.stat_partial, o.stat_acc = self.partial.data_ptr(), self.stat_acc[i].data_ptr()
+                o.Cout, o.tiles_m, o.training = c, tiles_m, 1
+                bnref[s.data_ptr()] = (self.stat_acc[i].data_ptr(), bn, count)
+                self.bn_list.append(bn)
+                return o, s, t
             if not training:
                 # eval: (scale, shift) depend on parameters and running statistics only -> ONE batched launch for
                 # all BatchNorms at the head of the program instead of a finalize launch per layer
@@ -300,12 +312,21 @@ class ConvStackProgram:
         ops.append(o)
         self._prep_index = 0
         ops.append(conv_op(self.img_pad, wst, self.c0, N, Hp, Wp, 32, Ho, Wo, width, 7, 1, 2, 0, Hp * Wp * 4, Wp * 4, 4))
-        f, s, t = fin_op(stack.bn1, width, N * Ho * Wo, L.load().sat_conv_tiles_m(N * Ho * Wo), consumer_can_derive=False)
+        f, s, t = fin_op(stack.bn1, width, N * Ho * Wo, L.load().sat_conv_tiles_m(N * Ho * Wo))
         add(f)
         y, ynext = self.ybuf
         mp = L.SatOp()
         mp.kind, mp.dtype = L.OP_BN_RELU_MAXPOOL, dtype
-        mp.in0, mp.out, mp.scale0, mp.shift0 = self.c0.data_ptr(), y.data_ptr(), s.data_ptr(), t.data_ptr()
+        mp.in0, mp.out = self.c0.data_ptr(), y.data_ptr()
+        ref = bnref.get(s.data_ptr())
+        if ref is None:
+            mp.scale0, mp.shift0 = s.data_ptr(), t.data_ptr()
+        else:                                      # the pooling kernel derives (scale, shift) from the integer sums
+            acc, bn_, count_ = ref
+            mp.stat_acc = acc
+            mp.gamma, mp.beta = bn_.weight.data_ptr(), bn_.bias.data_ptr()
+            mp.running_mean, mp.running_var = bn_.running_mean.data_ptr(), bn_.running_var.data_ptr()
+            mp.count, mp.momentum, mp.eps = count_, BN_MOMENTUM, BN_EPS
         mp.N, mp.Hin, mp.Win, mp.Cout, mp.Hout, mp.Wout = N, Ho, Wo, width, hp_, wp_
         ops.append(mp)
         for blk, (h, w_, h2, w2, inpl, planes, stride) in zip(stack.blocks(), geo):
