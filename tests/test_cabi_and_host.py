@@ -120,6 +120,14 @@ def test_state_dict_keys_equal_reference_names():
     assert abs(sat.conv_flops(sat.RESNET152) / 1e9 - 23.02) < 0.1
 
 
+def test_graft_entry_build_runs_clean():
+    """the driver's build check: compiles (incrementally) for gfx950, loads the library, versions agree"""
+    ge = importlib.import_module("__graft_entry__")
+    assert ge.build() is None
+    hdr = open(os.path.join(ROOT, "include", "sat_hip.h")).read()
+    assert L.load().sat_version() == int(re.search(r"#define SAT_ABI_VERSION (\d+)", hdr).group(1))
+
+
 def test_collate_batch_keeps_the_reference_invariant():
     """data_loader.py:48-62: longest caption first (ties keep their order), zero padding, int64, lengths as a list --
     and the result feeds pack_padded_sequence / PackInfo without re-sorting"""
