@@ -705,7 +705,7 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
                 for (int r = 0; r < reps && rc == SAT_OK; ++r) rc = launch_variant(v, a, s);
                 if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
                 float ms = 0.f;
-                hipEventElapsedTime(&ms, e0, e1);
+                if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
                 if (round >= 1 && ms / reps < tmin) tmin = ms / reps;
             }
             if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d v%d(%d,%d,%d,%s) %.2f us\n", a.M, a.N, a.K, v, kVariants[v].bn,
@@ -717,7 +717,7 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
         cache[key] = best_v + 1;
         op->variant = best_v + 1;
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return rc;
 }

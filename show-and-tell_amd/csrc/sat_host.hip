@@ -55,21 +55,21 @@ extern "C" int sat_graph_create(const sat_op* ops, int n_ops, int parity, sat_gr
     if (e != hipSuccess) return (int)e;
     e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) {
-        hipStreamDestroy(cs);
+        (void)hipStreamDestroy(cs);
         return (int)e;
     }
     const int rc = sat_run_ops_parity(ops, n_ops, parity, (sat_stream_t)cs);
     hipGraph_t g = nullptr;
     e = hipStreamEndCapture(cs, &g);           // always end the capture, also after a failed launch
-    hipStreamDestroy(cs);
+    (void)hipStreamDestroy(cs);
     if (rc != SAT_OK || e != hipSuccess || !g) {
-        if (g) hipGraphDestroy(g);
+        if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
         return rc != SAT_OK ? rc : (e != hipSuccess ? (int)e : SAT_ERR_UNSUPPORTED);
     }
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) return (int)e;
     sat_graph* out = new sat_graph;
     out->exec = exec;
