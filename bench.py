@@ -2,7 +2,11 @@
 """Headline benchmark: images/sec of one Show-and-Tell training step (the reference's hot-loop window
 `/root/reference/train.py:123-149`: forward, CE, backward, elementwise clamp, Adam) on synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: when not already running under torch.distributed.run, this process starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N`, spawned BEFORE anything here touches the GPU) and passes their
+exit code on; under torch.distributed.run (RANK / WORLD_SIZE set) it is one rank.  One rank per GPU over RCCL.
 
 Workload (BASELINE.json configs[1]): per-GPU batch 64, 224x224x3 images, length-20 captions, embed 256,
 hidden 512, vocab 10000, 1 LSTM layer, ResNet-152 encoder (frozen, train-mode batch statistics).
@@ -14,10 +18,10 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -26,9 +30,38 @@ if ROOT not in sys.path:
 CFG = dict(batch=64, image=224, embed=256, hidden=512, vocab=10000, layers=1, cap_len=20)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
-def synth_batch(B, V, T, H, device, seed):
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-mode", action="store_true", help="skip the secondary f32 parity-mode measurement")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket all-reduces even with one rank")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="CPU-only check of the rank plumbing (spawn, rendezvous, barrier, max-over-ranks, one JSON line): gloo, no GPU work")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child process tree and hand
+    their exit code on.  Nothing in this parent has touched the GPU (torch is not even imported yet), and the parent
+    is never replaced by exec."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def synth_batch(torch, B, V, T, H, device, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)          # SURVEY 8d synthetic inputs
     images = torch.randn(B, 3, H, H, generator=g)
     caps = torch.randint(4, V, (B, T), generator=g)
@@ -36,35 +69,22 @@ def synth_batch(B, V, T, H, device, seed):
     return images.to(device), caps.to(device), [T] * B
 
 
-def conv_only_time_ms(sat, model, images, reps=3):
-    """Average duration of ONE pass over every implicit-GEMM conv launch of the stack (the dominant kernel),
-    timed with HIP events on the stream the kernels are launched on."""
-    L = sat._lib
+def conv_in_sequence_us(torch, model, images, reps=3):
+    """Duration of every implicit-GEMM conv launch of the stack (the dominant kernel) measured IN SEQUENCE: the whole
+    encoder program runs in order (BatchNorm kernels between the convs, as in the step) and each conv launch reports
+    its own dispatch begin/end timestamps (HIP events attached to the launch on the stream it runs on) -- the same
+    quantity rocprofv3 --kernel-trace lists per launch.  Returns (sum of conv durations per pass in ms, launches)."""
     prog = model.encoder._program(images)
-    conv_ops = [prog.ops[i] for i in range(prog.n_ops) if prog.ops[i].kind == L.OP_CONV]
-    arr = (L.SatOp * len(conv_ops))(*conv_ops)
-    scratch = torch.zeros(2 * 2 * 2048, dtype=torch.int64, device=images.device)
-    ones, zeros = torch.ones(2048, device=images.device), torch.zeros(2048, device=images.device)
-    for j in range(len(conv_ops)):            # same kernels incl. the BatchNorm-statistics epilogue, but the integer
-        if arr[j].stat_acc:                   # sums go to a scratch buffer, not into the model's live accumulators,
-            arr[j].stat_acc = scratch.data_ptr()
-        if arr[j].stat_acc1:                  # and a fused input BatchNorm uses a neutral table instead of deriving
-            arr[j].stat_acc1 = None           # from (and clearing) the live ones
-            arr[j].scale0, arr[j].shift0 = ones.data_ptr(), zeros.data_ptr()
-    lib = L.load()
-    prog.run(images)                                   # fills the activation buffers with real data
-    L.check(lib.sat_run_ops(arr, len(conv_ops), L.stream()))
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    prog.run_timed(images)                                 # warm
+    tot, n = 0.0, 0
     for _ in range(reps):
-        L.check(lib.sat_run_ops(arr, len(conv_ops), L.stream()))
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps, len(conv_ops)
+        _, us = prog.run_timed(images)
+        tot += sum(us)
+        n = len(us)
+    return tot / reps * 1e-3, n
 
 
-def cpu_baseline(seed):
+def cpu_baseline(torch, seed):
     """The CPU oracle (a port of the reference path, validated against the reference's goldens) timed on this
     host's cores on a bounded sample of the same workload: batch 16 of the cfg-2 shapes, 6 timed steps at the best
     torch thread count of a short probe."""
@@ -107,21 +127,59 @@ def cpu_baseline(seed):
                       "steps at the best of {8,16,32,%d} torch threads" % (B, n, default_threads)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket all-reduces even with one rank")
-    args = ap.parse_args()
+def f32_mode_rate(torch, sat, dev, images, caps, lengths, steps=4):
+    """Secondary figure: the same step with the conv stack in the f32 PARITY mode (exact-f32 MFMA everywhere; the mode
+    whose CE matches the CPU oracle to 1e-4, tests/test_gpu_parity.py)."""
+    torch.manual_seed(123)
+    model = sat.ShowAndTell(CFG["embed"], CFG["hidden"], CFG["vocab"], CFG["layers"], compute_dtype="f32").to(dev).train()
+    ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+    for _ in range(2):
+        loss = ts.step(images, caps, lengths)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = ts.step(images, caps, lengths)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(CFG["batch"] * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
+            "steps": steps, "final_loss": round(float(loss.item()), 4),
+            "note": "conv stack f32 (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak): the oracle-parity mode, not the headline"}
 
+
+def selftest_launch(torch, rank, world):
+    """The multi-rank skeleton of main() on the CPU (tests/test_bench_launch.py): same env contract, barrier + timed
+    region + barrier, MAX over ranks, ONE JSON line from rank 0."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "max_dt": float(t.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.selftest_launch:
+        return selftest_launch(torch, rank, world)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -139,7 +197,7 @@ def main():
     dp = sat.DataParallelStep(ts)
     if args.force_dist:
         dp.world = 2          # take the multi-rank code path (async bucket all-reduces) on the single rank
-    images, caps, lengths = synth_batch(CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 123 + rank)
+    images, caps, lengths = synth_batch(torch, CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 123 + rank)
     global_tokens = world * sum(l - 1 for l in lengths)
 
     for _ in range(args.warmup):
@@ -159,11 +217,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    ts.check_ids()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * CFG["batch"] * args.steps / dt
-        conv_ms, n_conv = conv_only_time_ms(sat, model, images)
+        conv_ms, n_conv = conv_in_sequence_us(torch, model, images)
         conv_flops = sat.conv_flops(sat.RESNET152, CFG["image"], CFG["image"]) * CFG["batch"]
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
         out = {
@@ -174,18 +233,24 @@ def main():
                        "global_batch": world * CFG["batch"], "parallelism": "dp%d" % world,
                        "precision": "conv stack bf16 MFMA / f32 accumulate; head, LSTM, vocab, CE, Adam f32 (exact-f32 MFMA)",
                        "final_loss": round(final_loss, 4)},
-            "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel<BN,S,NW,UNIFORM> (bf16 implicit-GEMM conv, %d launches/step, variants autotuned per geometry)" % n_conv,
+            "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel (bf16 implicit-GEMM conv, %d launches/step, variants autotuned per geometry)" % n_conv,
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step_in_kernel": round(conv_ms, 3)},
+                         "algorithmic_gflop_per_launch": round(conv_flops / n_conv / 1e9, 3),
+                         "avg_launch_us": round(conv_ms * 1e3 / n_conv, 2),
+                         "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step_in_kernel": round(conv_ms, 3),
+                         "how": "per-launch dispatch timestamps (HIP events attached to each conv launch), whole encoder program in sequence, mean of 3 passes"},
         }
-        traffic_file = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
-        if os.path.exists(traffic_file):      # HBM bytes per conv launch from the separate rocprofv3 --pmc passes (tools/run_gpu_pmc.sh)
-            with open(traffic_file) as f:
+        if os.path.exists(TRAFFIC_FILE):      # HBM bytes per conv launch from the separate rocprofv3 --pmc passes (tools/run_gpu_pmc.sh)
+            with open(TRAFFIC_FILE) as f:
                 out["roofline"]["traffic"] = round(json.load(f)["hbm_bytes_per_launch_corrected"])
-                out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_g_pmc_traffic.json)"
+                out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % os.path.relpath(TRAFFIC_FILE, ROOT)
+        if world == 1 and not args.no_f32_mode:
+            del dp, ts, model
+            torch.cuda.empty_cache()
+            out["f32_parity_mode"] = f32_mode_rate(torch, sat, dev, images, caps, lengths)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(123)
+            out["cpu_baseline"] = cpu_baseline(torch, 123)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 5
+#define SAT_ABI_VERSION 6
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -129,14 +129,23 @@ typedef struct sat_graph sat_graph;
 int sat_graph_create(const sat_op* ops /*[host]*/, int n_ops, int parity, sat_graph** graph_out);
 int sat_graph_launch(sat_graph* graph, sat_stream_t stream);
 int sat_graph_destroy(sat_graph* graph);
-/* conv + batch-stat finalize + normalise/ReLU as one call (three ops) -- `conv -> bn -> relu` of a bottleneck */
+/* conv -> train-mode BatchNorm -> ReLU of one bottleneck stage (models.py:27) as one call over three op records:
+ * conv (statistics in its epilogue), finalize (scale/shift + running statistics), bnrelu (in0 must be conv->out) */
 int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, const sat_op* bnrelu, sat_stream_t stream);
 /* rows of SAT_OP_CONV partials the conv kernel writes for M output pixels */
 int sat_conv_tiles_m(int64_t M);
 /* Build-time tuner (NOT for the hot path: it times launches with HIP events and synchronises): for every bf16
  * SAT_OP_CONV in ops[] run each kernel variant `reps` times on the op's own buffers and record the fastest in
- * ops[i].variant.  Results are cached per conv geometry inside the library. */
-int sat_conv_autotune(sat_op* ops /*[host]*/, int n_ops, int reps, sat_stream_t stream);
+ * ops[i].variant.  Results are cached per conv geometry inside the library (mutex-protected).  `scratch`: >= 4096
+ * bytes of device memory owned by the caller (a neutral BatchNorm table for the input-fused convs lives there while
+ * the tuner runs): like every other entry point, this one allocates no device memory. */
+int sat_conv_autotune(sat_op* ops /*[host]*/, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
+                      sat_stream_t stream);
+/* Diagnostics, NOT the hot path (creates events, synchronises `stream`): run ops[0..n) once, in order, and return in
+ * op_us[i] [host] the duration in microseconds of every bf16 SAT_OP_CONV launch taken from its own dispatch
+ * timestamps (what rocprofv3 --kernel-trace reports for that launch); 0 for the other ops.  bench.py uses it for the
+ * roofline figure of the dominant kernel. */
+int sat_run_ops_timed(const sat_op* ops /*[host]*/, int n_ops, int parity, sat_stream_t stream, float* op_us /*[host]*/);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder head: resnet.fc (Linear 2048->E) + BatchNorm1d(E, momentum=0.01)  (models.py:16-17,27-28)
@@ -164,6 +173,13 @@ int sat_embed_concat_fwd(const float* features /*[B,E]*/, const float* embed /*[
 int sat_embed_concat_bwd(const float* dX /*[N,E]*/, const int64_t* captions, int64_t cap_stride,
                          const int32_t* prefix /*device*/, int T, int N, int B, int E, int V,
                          float* d_embed /*[V,E]*/, float* d_features /*[B,E]*/, sat_stream_t stream);
+
+/* Range check of an id matrix ids[rows][row_stride] (first `cols` columns): status[0] |= 1 when any id is outside
+ * [lo, hi).  nn.Embedding (models.py:49) and nn.CrossEntropyLoss (train.py:143) raise on such ids; the kernels below
+ * clamp them for memory safety only, the host wrappers launch this check on the caption matrix and raise when the
+ * status word (device int32, zero-initialised by the caller) comes back set. */
+int sat_validate_ids(const int64_t* ids, int64_t row_stride, int rows, int cols, int64_t lo, int64_t hi,
+                     int32_t* status, sat_stream_t stream);
 
 /* targets = pack_padded_sequence(captions[:,1:], lengths-1).data (train.py:134-135); prefix/T/N describe lengths-1 */
 int sat_pack_targets(const int64_t* captions /*[B][cap_stride]*/, int64_t cap_stride, const int32_t* prefix /*device*/,

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
+ABI_VERSION = 6
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -55,7 +56,9 @@ SIGNATURES = {
     "sat_graph_destroy": (_i, [_vp]),
     "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
     "sat_conv_tiles_m": (_i, [_i64]),
-    "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp]),
+    "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp, _i64, _vp]),
+    "sat_run_ops_timed": (_i, [C.POINTER(SatOp), _i, _i, _vp, C.POINTER(C.c_float)]),
+    "sat_validate_ids": (_i, [_vp, _i64, _i, _i, _i64, _i64, _vp, _vp]),
     "sat_fc_bn1d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_fc_bn1d_ws_bytes": (_i64, [_i, _i, _i]),
     "sat_fc_bn1d_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -104,7 +107,7 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.sat_version() != 5:
+        if lib.sat_version() != ABI_VERSION:
             raise RuntimeError("libsat_hip.so ABI version mismatch")
         _lib = lib
     return _lib

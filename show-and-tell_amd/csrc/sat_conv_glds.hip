@@ -18,6 +18,12 @@
 //     LDS so global stores are full 16-byte-per-lane rows;
 //   * blockIdx -> tile map is XCD-aware (tiles sharing an activation panel share an L2).
 #include "sat_internal.h"
+#include <hip/hip_ext.h>
+
+// diagnostics (sat_run_ops_timed): when armed, the NEXT conv launch of this thread records its own begin / end
+// timestamps into these events (hipExtLaunchKernelGGL: the dispatch packet's timestamps, what rocprofv3 reports)
+static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
+void sat_conv_arm_timer(hipEvent_t start, hipEvent_t stop) { t_ev_start = start; t_ev_stop = stop; }
 
 namespace {
 
@@ -546,6 +552,14 @@ int launch_glds(ConvArgs& a, hipStream_t s) {
     const int tm = sat_cdiv(a.M, 128), tn = sat_cdiv(a.N, BN);
     a.tiles_n = tn;
     const bool uniform = (a.Cin % 64 == 0) && (a.KH * a.KW <= 32);
+    if (t_ev_start) {                      // timed diagnostic launch: same kernel, same grid, plus the packet's timestamps
+        hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;
+        t_ev_start = t_ev_stop = nullptr;
+        if (uniform) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, e0, e1, 0, a);
+        SAT_LAUNCH_CHECK();
+        return SAT_OK;
+    }
     if (uniform) hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
     else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
     SAT_LAUNCH_CHECK();
@@ -625,6 +639,14 @@ ConvArgs make_args(const sat_op* op) {
     return a;
 }
 
+// a variant the kernel can run for these arguments (the in-LDS input transform lives in the plain unified-wave loop)
+bool variant_ok(int v, const ConvArgs& a) {
+    if (v < 0 || v >= kNumVariants) return false;
+    if (kVariants[v].bn == 128 && a.N <= 64) return false;
+    if ((kVariants[v].spec || kVariants[v].pf) && a.in_affine) return false;
+    return true;
+}
+
 int heuristic_variant(const ConvArgs& a) {
     // 128x128 with a deep ring when it still leaves >= 2 tiles per CU and K is long enough to use the ring;
     // otherwise 128x64 with a shallower ring (more workgroups per CU to overlap prologue/epilogue phases)
@@ -661,15 +683,23 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
 }
 
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <stdio.h>
 
-extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t stream) {
+extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
+                                 sat_stream_t stream) {
     if (!ops || n_ops < 0 || reps < 1) return SAT_ERR_ARG;
+    if (!scratch || scratch_bytes < (int64_t)(1024 * sizeof(float))) return SAT_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int> Key;
     static std::map<Key, int> cache;
+    static std::mutex cache_mu;                       // the per-geometry result cache is shared by every caller thread
     const bool verbose = getenv("SAT_TUNE_VERBOSE") != nullptr;
+    // neutral input-BatchNorm table (scale 1, shift 0) in the CALLER's scratch: the library allocates nothing
+    if (hipMemsetD32Async((hipDeviceptr_t)scratch, 0x3f800000, 512, s) != hipSuccess ||
+        hipMemsetAsync(scratch + 512, 0, 512 * sizeof(float), s) != hipSuccess)
+        return SAT_ERR_UNSUPPORTED;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SAT_ERR_UNSUPPORTED;
     int rc = SAT_OK;
@@ -679,26 +709,22 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
         const Key key(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
                       ((op->stat_partial || op->stat_acc) ? 1 : 0) + ((op->scale0 || op->stat_acc1) ? 2 : 0) +
                           (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0));
-        auto it = cache.find(key);
-        if (it != cache.end()) { op->variant = it->second; continue; }
+        {
+            std::lock_guard<std::mutex> lk(cache_mu);
+            auto it = cache.find(key);
+            if (it != cache.end()) { op->variant = it->second; continue; }
+        }
         ConvArgs a = make_args(op);
         a.acc = nullptr;             // tuning launches must not touch the statistics / running buffers
-        if (a.in_affine) {           // ... nor derive from / clear the live accumulators: a neutral table stands in
-            static float* neutral = nullptr;
-            if (!neutral) {
-                if (hipMalloc((void**)&neutral, 1024 * sizeof(float)) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-                if (hipMemsetD32((hipDeviceptr_t)neutral, 0x3f800000, 512) != hipSuccess ||          // scale 1.0
-                    hipMemset(neutral + 512, 0, 512 * sizeof(float)) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-            }
+        if (a.in_affine) {           // ... nor derive from / clear the live accumulators: the neutral table stands in
             a.in_acc = nullptr; a.in_acc_clear = nullptr; a.in_running_mean = nullptr;
-            a.in_scale = neutral; a.in_shift = neutral + 512;
+            a.in_scale = scratch; a.in_shift = scratch + 512;
             if (!a.linear || a.Cin > 512 || (a.Cin % 64)) continue;
         }
         float best = 1e30f;
         int best_v = heuristic_variant(a);
         for (int v = 0; v < kNumVariants; ++v) {
-            if (kVariants[v].bn == 128 && a.N <= 64) continue;
-            if ((kVariants[v].spec || kVariants[v].pf) && a.in_affine) continue;
+            if (!variant_ok(v, a)) continue;
             float tmin = 1e30f;
             for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
                 if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
@@ -714,7 +740,10 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, sat_stream_t 
         }
         if (verbose) fprintf(stderr, "tune M=%d N=%d K=%d -> v%d %.2f us (%.0f TFLOP/s)\n", a.M, a.N, a.K, best_v, best * 1e3f,
                              2.0 * a.M * a.N * a.K / (best * 1e-3) / 1e12);
-        cache[key] = best_v + 1;
+        {
+            std::lock_guard<std::mutex> lk(cache_mu);
+            cache[key] = best_v + 1;
+        }
         op->variant = best_v + 1;
     }
     (void)hipEventDestroy(e0);

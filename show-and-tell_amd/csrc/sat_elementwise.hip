@@ -465,14 +465,14 @@ __global__ __launch_bounds__(256) void embed_concat_bwd_kernel(const float* __re
                                                                float* __restrict__ d_features) {
     extern __shared__ __attribute__((aligned(16))) int tok[];   // [Nrows]; -1 for step-0 rows
     const int row = blockIdx.x;
-    for (int i = threadIdx.x; i < Nrows; i += blockDim.x) {
-        const int t = find_step(prefix, T, i);
-        int v = -1;
-        if (t > 0) {
-            long x = captions[(long)(i - prefix[t]) * cap_stride + (t - 1)];
-            v = (int)(x < 0 ? 0 : (x >= V ? V - 1 : x));
+    // packed token list, walked step by step (rows of step t are contiguous: no per-row search of the prefix array)
+    for (int i = threadIdx.x; i < prefix[1]; i += blockDim.x) tok[i] = -1;
+    for (int t = 1; t < T; ++t) {
+        const int p0 = prefix[t], n = prefix[t + 1] - p0;
+        for (int b = threadIdx.x; b < n; b += blockDim.x) {
+            const long x = captions[(long)b * cap_stride + (t - 1)];
+            tok[p0 + b] = (int)(x < 0 ? 0 : (x >= V ? V - 1 : x));     // memory safety only: sat_validate_ids reports bad ids
         }
-        tok[i] = v;
     }
     __syncthreads();
     const int v = tok[row];
@@ -1041,7 +1041,13 @@ extern "C" int sat_embed_concat_bwd(const float* dX, const int64_t* captions, in
                                     float* d_features, sat_stream_t stream) {
     if (!dX || !prefix || !d_embed || !d_features || T < 1 || B < 1 || N < B) return SAT_ERR_ARG;
     if (T > 1 && !captions) return SAT_ERR_ARG;
-    if ((long)N * 4 > 150 * 1024) return SAT_ERR_UNSUPPORTED;   // token list is LDS resident
+    // the packed token list is LDS resident: 4 B per row next to the kernel's 5 KB of static LDS
+    const size_t dyn = (size_t)N * 4;
+    if (dyn > 150 * 1024) return SAT_ERR_UNSUPPORTED;
+    if (dyn > 48 * 1024) {      // beyond the default dynamic-LDS limit the kernel has to opt in
+        hipError_t ea = hipFuncSetAttribute((const void*)embed_concat_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (ea != hipSuccess) return (int)ea;
+    }
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(d_embed, 0, (size_t)V * E * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
@@ -1103,6 +1109,35 @@ extern "C" int sat_cast_f32_bf16(const float* in, void* out, int64_t n, sat_stre
 extern "C" int sat_cast_bf16_f32(const void* in, float* out, int64_t n, sat_stream_t stream) {
     if (!in || !out || n < 1) return SAT_ERR_ARG;
     hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)in, out, (long)n);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+// Range check of a caption / id matrix: nn.Embedding and nn.CrossEntropyLoss raise on an id outside [0, V)
+// (models.py:49, train.py:143); the gather / CE kernels here only clamp for memory safety, so the wrappers launch
+// this first and turn a set status word into an exception.
+namespace {
+__global__ __launch_bounds__(256) void validate_ids_kernel(const int64_t* __restrict__ ids, long row_stride, int rows, int cols,
+                                                           long lo, long hi, int* __restrict__ status) {
+    const long total = (long)rows * cols;
+    int bad = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols, c = i - r * cols;
+        const long v = ids[r * row_stride + c];
+        bad |= (v < lo || v >= hi) ? 1 : 0;
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(status, 1);
+}
+}  // namespace
+
+extern "C" int sat_validate_ids(const int64_t* ids, int64_t row_stride, int rows, int cols, int64_t lo, int64_t hi,
+                                int32_t* status, sat_stream_t stream) {
+    if (!ids || !status || rows < 0 || cols < 0 || row_stride < cols) return SAT_ERR_ARG;
+    if (rows == 0 || cols == 0) return SAT_OK;
+    const long total = (long)rows * cols;
+    const int grid = (int)(total < 256L * 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(validate_ids_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, (long)row_stride, rows, cols,
+                       (long)lo, (long)hi, (int*)status);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }

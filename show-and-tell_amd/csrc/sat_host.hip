@@ -89,15 +89,58 @@ extern "C" int sat_graph_destroy(sat_graph* graph) {
     return (int)e;
 }
 
+// conv -> BatchNorm(batch statistics) -> ReLU of one bottleneck stage as a single call over three op records
+// (SURVEY 8b names this entry point): statistics leave the conv epilogue, finalize makes (scale, shift), bnrelu applies.
 extern "C" int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, const sat_op* bnrelu,
                                     sat_stream_t stream) {
     if (!conv || !finalize || !bnrelu) return SAT_ERR_ARG;
     if (conv->kind != SAT_OP_CONV || finalize->kind != SAT_OP_BN_FINALIZE || bnrelu->kind != SAT_OP_BN_RELU)
         return SAT_ERR_ARG;
+    if (conv->out != bnrelu->in0 || conv->Cout != finalize->Cout || conv->Cout != bnrelu->Cout) return SAT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     SAT_TRY(sat_conv_launch(conv, 0, s));
     SAT_TRY(sat_bn_finalize_launch(finalize, 0, s));
     return sat_bn_act_launch(bnrelu, false, 0, s);
+}
+
+void sat_conv_arm_timer(hipEvent_t start, hipEvent_t stop);      // sat_conv_glds.hip
+
+// Diagnostics, NOT the hot path (creates events and synchronises the stream): run the program once in order and
+// report every bf16 SAT_OP_CONV launch's own duration (the dispatch packet's begin/end timestamps, i.e. what
+// rocprofv3 --kernel-trace reports for that launch) in op_us[i]; 0 for every other op.
+extern "C" int sat_run_ops_timed(const sat_op* ops, int n_ops, int parity, sat_stream_t stream, float* op_us) {
+    if (!ops || n_ops < 0 || !op_us || (parity != 0 && parity != 1)) return SAT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t* ev = new hipEvent_t[2 * (size_t)(n_ops > 0 ? n_ops : 1)];
+    int n_ev = 0, rc = SAT_OK;
+    for (int i = 0; i < n_ops && rc == SAT_OK; ++i) {
+        const sat_op* op = ops + i;
+        op_us[i] = 0.0f;
+        const bool timed = op->kind == SAT_OP_CONV && op->dtype == SAT_BF16 && (op->Cout % 8) == 0;
+        if (timed) {
+            if (hipEventCreate(&ev[n_ev]) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+            if (hipEventCreate(&ev[n_ev + 1]) != hipSuccess) { (void)hipEventDestroy(ev[n_ev]); rc = SAT_ERR_UNSUPPORTED; break; }
+            sat_conv_arm_timer(ev[n_ev], ev[n_ev + 1]);
+            op_us[i] = -1.0f;          // marks "events n_ev, n_ev+1 belong to this op"
+            n_ev += 2;
+        }
+        rc = sat_run_ops_parity(op, 1, parity, stream);
+        sat_conv_arm_timer(nullptr, nullptr);     // a launch path that ignored the timer must not leave it armed
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    if (rc == SAT_OK && e != hipSuccess) rc = (int)e;
+    int k = 0;
+    for (int i = 0; i < n_ops; ++i) {
+        if (op_us[i] >= 0.0f) continue;
+        if (k + 2 > n_ev) { op_us[i] = 0.0f; continue; }       // event creation failed part-way
+        float ms = 0.0f;
+        if (rc == SAT_OK && hipEventElapsedTime(&ms, ev[k], ev[k + 1]) == hipSuccess) op_us[i] = ms * 1e3f;
+        else op_us[i] = 0.0f;
+        k += 2;
+    }
+    for (int j = 0; j < n_ev; ++j) (void)hipEventDestroy(ev[j]);
+    delete[] ev;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------------

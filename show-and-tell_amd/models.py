@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .pack import PackInfo
-from .resnet import RESNET152, ConvStackProgram, ResNetStack
+from .resnet import RESNET152, ConvStackProgram, ResNetStack, weights_signature
 
 _LSTM_SPLITK = os.environ.get("SAT_LSTM_SPLITK", "1") != "0"   # roomy LSTM-backward workspace => split-K dW_ih / dX GEMMs
 BN1D_MOMENTUM = 0.01   # models.py:17
@@ -100,6 +100,9 @@ class EncoderCNN(nn.Module):
         self.compute_dtype = compute_dtype
         self._programs = {}
         self.register_load_state_dict_post_hook(lambda m, k: m._programs.clear())
+        # `encoder.resnet.load_state_dict(torchvision_sd)` -- the natural way to load the pretrained ResNet-152 the
+        # reference uses (models.py:13) -- does not fire the parent's hook: hook the stack too
+        self.resnet.register_load_state_dict_post_hook(lambda m, k: self._programs.clear())
 
     def init_weights(self):
         """models.py:20-23."""
@@ -113,7 +116,7 @@ class EncoderCNN(nn.Module):
     def _program(self, images):
         N, _, H, W = images.shape
         dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
-        key = (N, H, W, dt, self.training, str(images.device), self.resnet.conv1.weight.data_ptr())
+        key = (N, H, W, dt, self.training, str(images.device), weights_signature(self.resnet))
         prog = self._programs.get(key)
         if prog is None:
             if len(self._programs) >= 4:
@@ -121,15 +124,28 @@ class EncoderCNN(nn.Module):
             prog = self._programs[key] = ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device)
         return prog
 
-    def pooled_features(self, images):
-        """conv stack + global average pool: f32 [B, 2048] (no autograd: the stack is frozen, models.py:14-15)."""
+    def refresh_weights(self):
+        """Drop the cached op programs (and their kernel-layout weight copies); needed only after writing conv weights
+        through `.data`, which no version counter sees."""
+        self._programs.clear()
+
+    def _pooled_raw(self, images):
+        """The program-owned pooled buffer (overwritten by the next forward of the same shape): internal use within
+        one step only (`TrainStep`)."""
         L.require_gpu(images, "images")
         with torch.no_grad():
             return self._program(images).run(images)
 
+    def pooled_features(self, images):
+        """conv stack + global average pool: f32 [B, 2048] (no autograd: the stack is frozen, models.py:14-15).
+        Returns a tensor the caller owns (a copy of the program's output buffer, B x 2048 f32)."""
+        return self._pooled_raw(images).clone()
+
     def forward(self, images):
         """Extract the image feature vectors (models.py:25-29)."""
-        pooled = self.pooled_features(images)
+        # the head's backward needs `pooled`: it must not alias the program's buffer, which a second forward (two
+        # micro-batches before one backward, or model(images) followed by model.sample(images)) would overwrite
+        pooled = self.pooled_features(images) if torch.is_grad_enabled() else self._pooled_raw(images)
         out = _HeadFn.apply(pooled, self.resnet.fc.weight, self.resnet.fc.bias, self.bn.weight, self.bn.bias,
                             self.bn.running_mean, self.bn.running_var, self.training)
         if self.training:
@@ -139,6 +155,57 @@ class EncoderCNN(nn.Module):
 
 # ------------------------------------------------------------------------------------------------------
 # decoder
+class IdGuard:
+    """Out-of-range caption ids.  `nn.Embedding` (models.py:49) and `nn.CrossEntropyLoss` (train.py:143) raise on an id
+    outside [0, V); the gather / CE kernels here clamp such ids for memory safety only, so every batch is range-checked
+    on the device (`sat_validate_ids`, one tiny launch) and the verdict is read back WITHOUT stalling the stream: the
+    status word is copied to pinned host memory behind the check and looked at when the next batch is submitted (or
+    at once with `poll(block=True)`).  A corrupt caption therefore raises at the latest one step later."""
+
+    DEPTH = 4     # verdicts in flight: the host may run this many submits ahead of the GPU without waiting
+
+    def __init__(self, device):
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)       # sticky: only a raise clears it
+        self.host = torch.zeros(self.DEPTH, dtype=torch.int32).pin_memory()
+        self.pending = []           # (slot, event, description), oldest first
+        self.slot = 0
+
+    def submit(self, ids, ncols, V, what):
+        self.poll(block=False)
+        if ids.dim() != 2 or ids.dtype != torch.int64 or ids.stride(1) != 1:
+            raise TypeError("%s must be an int64 matrix with contiguous rows" % what)
+        while len(self.pending) >= self.DEPTH:
+            self._retire(block=True)
+        L.check(L.load().sat_validate_ids(ids.data_ptr(), ids.stride(0), ids.shape[0], min(int(ncols), ids.shape[1]), 0, int(V),
+                                          self.status.data_ptr(), L.stream()), "sat_validate_ids")
+        slot = self.slot
+        self.slot = (slot + 1) % self.DEPTH
+        self.host[slot:slot + 1].copy_(self.status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((slot, ev, "%s: id outside [0, %d)" % (what, V)))
+
+    def _retire(self, block):
+        slot, ev, what = self.pending[0]
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return False
+        self.pending.pop(0)
+        if int(self.host[slot]) != 0:
+            torch.cuda.current_stream().synchronize()
+            self.status.zero_()
+            self.host.zero_()
+            self.pending.clear()
+            raise IndexError("show-and-tell_amd: %s (nn.Embedding / CrossEntropyLoss would raise here: "
+                             "models.py:49, train.py:143)" % what)
+        return True
+
+    def poll(self, block=False):
+        while self.pending and self._retire(block):
+            pass
+
+
 class _LSTMParams(nn.Module):
     """Parameter holder with nn.LSTM's names and default init U(-1/sqrt(H), 1/sqrt(H)) (models.py:36)."""
 
@@ -289,7 +356,14 @@ class DecoderRNN(nn.Module):
         self.linear = _Weight(vocab_size, hidden_size, bias=vocab_size)  # nn.Linear (models.py:37)
         self.embed_size, self.hidden_size, self.vocab_size, self.num_layers = embed_size, hidden_size, vocab_size, num_layers
         self.ss_prob = 0                                                 # inert in the reference too (models.py:38)
+        self._id_guard = None
         self.init_weights()
+
+    def id_guard(self):
+        dev = self.embed.weight.device
+        if self._id_guard is None or self._id_guard.status.device != dev:
+            self._id_guard = IdGuard(dev)
+        return self._id_guard
 
     def init_weights(self):
         """models.py:41-45."""
@@ -313,6 +387,10 @@ class DecoderRNN(nn.Module):
         pi = PackInfo.get(lengths, features.device)
         if pi.T > captions.shape[1] + 1:
             raise ValueError("a length exceeds captions.shape[1] + 1")
+        if captions.dtype != torch.int64 or captions.stride(1) != 1:
+            captions = captions.long().contiguous()
+        if pi.T > 1:
+            self.id_guard().submit(captions, pi.T - 1, self.vocab_size, "captions")
         return _DecoderFn.apply(features, captions, pi, self.num_layers, self.embed.weight, self.linear.weight,
                                 self.linear.bias, *self._lstm_flat())
 
@@ -423,6 +501,16 @@ class ShowAndTell(nn.Module):
         super().__init__()
         self.encoder = EncoderCNN(embed_size, arch, compute_dtype)
         self.decoder = DecoderRNN(embed_size, hidden_size, vocab_size, num_layers)
+
+    @classmethod
+    def from_trainer_args(cls, hidden_size, context_size, vocab_size, embed_size, opt=None, **kw):
+        """The argument order of the model the reference trainer constructs, train.py:37
+        `ShowAttendTellModel(opt.hidden_size, opt.embed_size, len(vocab), opt.embed_size, opt)`: hidden FIRST, then a
+        context size this architecture has no use for, vocab, embed, and the options namespace (its `num_layers`,
+        config.py:30, is honoured).  Dropping `ShowAndTell.from_trainer_args` in at that call site keeps every
+        dimension where the trainer put it."""
+        num_layers = int(getattr(opt, "num_layers", 1)) if opt is not None else 1
+        return cls(embed_size, hidden_size, vocab_size, num_layers, **kw)
 
     def forward(self, images, captions, lengths):
         return self.decoder(self.encoder(images), captions, lengths)

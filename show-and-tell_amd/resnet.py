@@ -18,7 +18,7 @@ conv3 applies bn2+ReLU to its operand in LDS.  Inference (bf16): every BatchNorm
 the producing conv's epilogue with the residual add and the ReLU.  The whole program replays as one hipGraph.
 """
 import ctypes as C
-import math
+import json
 import os
 
 import torch
@@ -104,6 +104,18 @@ class ResNetStack(nn.Module):
             yield blk.bn3
             if blk.downsample is not None:
                 yield blk.downsample[1]
+
+
+def weights_signature(stack):
+    """Changes whenever a frozen conv weight is replaced or written in place through the Parameter (load_state_dict,
+    copy_): the op program keeps permuted (bf16) copies of the conv weights and must be rebuilt then.  Writes through
+    `.data` bypass the version counter -- call `EncoderCNN.refresh_weights()` after those."""
+    sig = 0
+    for m in stack.modules():
+        if isinstance(m, _Conv):
+            sig = sig * 1000003 + m.weight._version * 7 + (m.weight.data_ptr() & 0xffffffff)
+            sig &= (1 << 61) - 1
+    return sig
 
 
 def _tdtype(dtype):
@@ -403,12 +415,42 @@ class ConvStackProgram:
         # replay as a hipGraph (SAT_GRAPH=0: eager launches).  Per step parity: first run eager, then captured.
         self._use_graph = os.environ.get("SAT_GRAPH", "1") != "0" and torch.device(device).type == "cuda"
         self._runs, self._graphs = [0, 0], [None, None]
-        # build-time kernel selection per conv geometry (bf16): time every variant on this program's own buffers
+        # build-time kernel selection per conv geometry (bf16): time every variant on this program's own buffers.
+        # The choice is timing dependent and the tile shape fixes the BatchNorm summation order, so bf16 results are
+        # bit-reproducible across processes only with the same choices: SAT_TUNE_FILE=<json> saves them / loads them back.
         if dtype == L.SAT_BF16 and os.environ.get("SAT_AUTOTUNE", "1") != "0" and torch.device(device).type == "cuda":
-            for t in (self.c0, self.c1, self.a1, self.c2, self.a2, self.c3, self.cd, *self.ybuf):
-                t.normal_()
-            L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 5, L.stream()), "sat_conv_autotune")
-            torch.cuda.synchronize()
+            tune_file = os.environ.get("SAT_TUNE_FILE")
+            table = {}
+            if tune_file and os.path.exists(tune_file):
+                with open(tune_file) as f:
+                    table = json.load(f)
+            missing = False
+            for i in range(self.n_ops):
+                if self.ops[i].kind == L.OP_CONV:
+                    v = table.get(self._tune_key(self.ops[i]))
+                    if v is None:
+                        missing = True
+                    else:
+                        self.ops[i].variant = int(v)
+            if missing:
+                for t in (self.c0, self.c1, self.a1, self.c2, self.a2, self.c3, self.cd, *self.ybuf):
+                    t.normal_()
+                scratch = alloc((1024,), torch.float32)           # the tuner's neutral BatchNorm table lives in OUR memory
+                L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 5, scratch.data_ptr(), scratch.numel() * 4,
+                                                   L.stream()), "sat_conv_autotune")
+                torch.cuda.synchronize()
+                if tune_file:
+                    for i in range(self.n_ops):
+                        if self.ops[i].kind == L.OP_CONV:
+                            table[self._tune_key(self.ops[i])] = int(self.ops[i].variant)
+                    with open(tune_file, "w") as f:
+                        json.dump(table, f, indent=0, sort_keys=True)
+
+    @staticmethod
+    def _tune_key(o):
+        fused = (1 if (o.stat_partial or o.stat_acc) else 0) + (2 if (o.scale0 or o.stat_acc1) else 0) + \
+                (4 if o.scale1 else 0) + (8 if o.in1 else 0)
+        return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d" % (o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout, o.KH, o.KW, o.stride, fused)
 
     def __del__(self):
         for g in getattr(self, "_graphs", ()):
@@ -443,6 +485,26 @@ class ConvStackProgram:
         if self.training:
             self.stack._nbt_flat += 1
         return self.pooled
+
+
+def _run_timed(self, images):
+    """Diagnostics (bench.py's roofline figure): one eager, in-order run of the whole program -- same kernels, same
+    statistics / parity bookkeeping as `run` -- that also returns every conv launch's own duration in microseconds
+    (dispatch timestamps via `sat_run_ops_timed`).  Synchronises the stream."""
+    L.require_gpu(images, "images")
+    images = images.contiguous()
+    lib, p = L.load(), self._parity
+    self.ops[0].in0 = images.data_ptr()
+    us = (C.c_float * self.n_ops)()
+    L.check(lib.sat_run_ops_timed(self.ops, self.n_ops, p, L.stream(), us), "sat_run_ops_timed")
+    self._runs[p] += 1
+    self._parity ^= 1
+    if self.training:
+        self.stack._nbt_flat += 1
+    return self.pooled, [float(us[i]) for i in range(self.n_ops) if self.ops[i].kind == L.OP_CONV]
+
+
+ConvStackProgram.run_timed = _run_timed
 
 
 def conv_flops(arch, H=224, W=224):

@@ -104,7 +104,16 @@ class TrainStep:
         B = images.shape[0]
         if captions.dtype != torch.int64 or captions.stride(1) != 1:
             captions = captions.long().contiguous()
-        l1 = [int(l) - 1 for l in lengths]                                   # train.py:134
+        lengths = [int(l) for l in lengths]
+        # sat_pack_targets reads captions[b][t+1] up to column lengths[0]-1 and the embedding gather captions[b][t-1]:
+        # every caption must hold at least <start> + one target, and no length may exceed the matrix width
+        if len(lengths) != B or captions.dim() != 2 or captions.shape[0] != B:
+            raise ValueError("captions must be [B, T] with one length per image")
+        if lengths[-1] < 2 or lengths[0] > captions.shape[1]:
+            raise ValueError("need 2 <= every length <= captions.shape[1] (got min %d, max %d, width %d)"
+                             % (lengths[-1], lengths[0], captions.shape[1]))
+        dec.id_guard().submit(captions, lengths[0], dec.vocab_size, "captions")   # raises for a bad EARLIER batch at the latest here
+        l1 = [l - 1 for l in lengths]                                        # train.py:134
         pi = PackInfo.get(l1, dev)
         N, V, E = pi.N, dec.vocab_size, dec.embed_size
         key = (B, N)
@@ -127,7 +136,7 @@ class TrainStep:
             feats_in = images.contiguous()
             pooled = None
         else:
-            pooled = enc.pooled_features(images)
+            pooled = enc._pooled_raw(images)       # program-owned buffer: consumed within this step
             F = pooled.shape[1]
             fc, bn = enc.resnet.fc, enc.bn
             L.check(lib.sat_fc_bn1d_fwd(L.ptr(pooled), L.ptr(fc.weight), L.ptr(fc.bias), L.ptr(bn.weight), L.ptr(bn.bias),
@@ -162,6 +171,10 @@ class TrainStep:
         if on_bucket_ready is not None:
             on_bucket_ready(2)   # encoder head + embedding gradients (and the loss slot) are final
         return loss_slot
+
+    def check_ids(self):
+        """Block until the range check of the last submitted batch is known; raises IndexError on a bad caption id."""
+        self.model.decoder.id_guard().poll(block=True)
 
     def optimizer_step(self, lr=None):
         """clip_gradient + Adam (train.py:145-146) as one launch over the flat buffers."""

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libsat_hip.so does not export %s" % n
         assert n in L.SIGNATURES, "no ctypes signature for %s" % n
     assert set(L.SIGNATURES) == set(names)
-    assert lib.sat_version() == 5
+    assert lib.sat_version() == L.ABI_VERSION == int(re.search(r"#define SAT_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "sat_hip.h")).read()).group(1))
     assert b"workspace" in lib.sat_error_string(1002)
 
 

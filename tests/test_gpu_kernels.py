@@ -107,7 +107,10 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("variant", list(range(1, 22)))
+NUM_CONV_VARIANTS = 21
+
+
+@pytest.mark.parametrize("variant", list(range(1, NUM_CONV_VARIANTS + 1)))
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(3, 15, 13, 64, 192, 3, 1, 1), (2, 9, 9, 24, 72, 3, 2, 1),
                                                          (5, 8, 8, 320, 64, 1, 1, 0)])
 def test_conv_bf16_every_kernel_variant(lib, variant, N, H, W, Cin, Cout, k, stride, pad):
@@ -135,8 +138,10 @@ def test_conv_autotune_sets_a_variant_and_keeps_results(lib):
     ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, 256)
     o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1)
     ops = (L.SatOp * 1)(o)
-    L.check(lib.sat_conv_autotune(ops, 1, 2, st()))
-    assert 1 <= ops[0].variant <= 21
+    scratch = torch.empty(1024, device="cuda")          # the tuner works in caller-owned memory
+    assert lib.sat_conv_autotune(ops, 1, 2, None, 0, st()) == 1002
+    L.check(lib.sat_conv_autotune(ops, 1, 2, scratch.data_ptr(), scratch.numel() * 4, st()))
+    assert 1 <= ops[0].variant <= NUM_CONV_VARIANTS
     L.check(lib.sat_run_ops(ops, 1, st()))
     sync()
     assert (keep[2].float().cpu().double() - ref).abs().max().item() < 2e-2
@@ -472,3 +477,116 @@ def test_conv_inference_epilogue_affine_residual_relu(lib, variant, k, stride, p
     o2, keep2, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), stride, pad, stats=True)
     o2.scale1, o2.shift1 = scd.data_ptr(), shd.data_ptr()
     assert lib.sat_run_ops(C.pointer(o2), 1, st()) == 1001
+
+
+# ------------------------------------------------------------------------------------------------------
+# entry points that had no test in round 1 + the round-2 additions
+@pytest.mark.parametrize("dtype", [L.SAT_F32, L.SAT_BF16])
+def test_conv_bn_relu_fwd_one_call(lib, dtype):
+    """sat_conv_bn_relu_fwd: conv (statistics in the epilogue) -> finalize -> normalise + ReLU, vs fp64 arithmetic"""
+    g = torch.Generator().manual_seed(81)
+    N, H, W, Cin, Cout = 3, 9, 9, 64, 72
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24.0
+    if dtype == L.SAT_BF16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    o, keep, (n, ho, wo, co) = _conv_op(dtype, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1)
+    rm, rv = cu(torch.zeros(Cout)), cu(torch.ones(Cout))
+    sc, sh, gd, bd = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda"), cu(gamma), cu(beta)
+    f = L.SatOp()
+    f.kind, f.dtype = L.OP_BN_FINALIZE, dtype
+    f.stat_partial, f.gamma, f.beta = keep[3].data_ptr(), gd.data_ptr(), bd.data_ptr()
+    f.running_mean, f.running_var, f.scale_out, f.shift_out = rm.data_ptr(), rv.data_ptr(), sc.data_ptr(), sh.data_ptr()
+    f.Cout, f.count, f.tiles_m, f.training, f.momentum, f.eps = Cout, n * ho * wo, o.tiles_m, 1, 0.1, 1e-5
+    y = torch.empty_like(keep[2])
+    a = L.SatOp()
+    a.kind, a.dtype = L.OP_BN_RELU, dtype
+    a.in0, a.out, a.scale0, a.shift0 = keep[2].data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr()
+    a.N, a.Hout, a.Wout, a.Cout = n, ho, wo, co
+    L.check(lib.sat_conv_bn_relu_fwd(C.pointer(o), C.pointer(f), C.pointer(a), st()))
+    sync()
+    c = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    mean, var = c.mean(0), c.var(0, unbiased=False)
+    ref = ((c - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()).clamp(min=0)
+    tol = 2e-4 if dtype == L.SAT_F32 else 6e-2
+    assert (y.float().cpu().double() - ref).abs().max().item() < tol
+    bad = L.SatOp()
+    bad.kind = L.OP_BN_RELU
+    assert lib.sat_conv_bn_relu_fwd(C.pointer(o), C.pointer(f), C.pointer(bad), st()) == 1001   # bnrelu.in0 != conv.out
+
+
+def test_casts_round_to_nearest_even_and_back(lib):
+    g = torch.Generator().manual_seed(82)
+    x = torch.randn(100003, generator=g) * 3
+    x[:4] = torch.tensor([0.0, -0.0, 1.00390625, 65504.0])       # 1 + 2^-8: a tie, rounds to even (1.0)
+    xd = cu(x)
+    b = torch.empty(x.numel(), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.sat_cast_f32_bf16(xd.data_ptr(), b.data_ptr(), x.numel(), st()))
+    back = torch.empty_like(xd)
+    L.check(lib.sat_cast_bf16_f32(b.data_ptr(), back.data_ptr(), x.numel(), st()))
+    sync()
+    assert torch.equal(b.cpu(), x.bfloat16())
+    assert torch.equal(back.cpu(), x.bfloat16().float())
+
+
+def test_validate_ids_flags_only_out_of_range(lib):
+    ids = torch.randint(0, 50, (7, 12))
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d = cu(ids)
+    L.check(lib.sat_validate_ids(d.data_ptr(), 12, 7, 12, 0, 50, status.data_ptr(), st()))
+    assert int(status.item()) == 0
+    ids2 = ids.clone()
+    ids2[6, 11] = 50
+    d2 = cu(ids2)
+    L.check(lib.sat_validate_ids(d2.data_ptr(), 12, 7, 11, 0, 50, status.data_ptr(), st()))     # bad id outside the checked columns
+    assert int(status.item()) == 0
+    L.check(lib.sat_validate_ids(d2.data_ptr(), 12, 7, 12, 0, 50, status.data_ptr(), st()))
+    assert int(status.item()) == 1
+    status.zero_()
+    ids3 = ids.clone()
+    ids3[0, 0] = -3
+    d3 = cu(ids3)
+    L.check(lib.sat_validate_ids(d3.data_ptr(), 12, 7, 12, 0, 50, status.data_ptr(), st()))
+    assert int(status.item()) == 1
+    assert lib.sat_validate_ids(d3.data_ptr(), 4, 7, 12, 0, 50, status.data_ptr(), st()) == 1001    # stride < cols
+
+
+def test_run_ops_timed_reports_conv_durations_and_computes_the_same(lib):
+    g = torch.Generator().manual_seed(83)
+    x = torch.randn(8, 128, 14, 14, generator=g).bfloat16().float()
+    w = (torch.randn(256, 128, 3, 3, generator=g) / 34.0).bfloat16().float()
+    o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1)
+    ops = (L.SatOp * 1)(o)
+    L.check(lib.sat_run_ops(ops, 1, st()))
+    sync()
+    ref = keep[2].clone()
+    keep[2].fill_(float("nan"))
+    us = (C.c_float * 1)()
+    L.check(lib.sat_run_ops_timed(ops, 1, 0, st(), us))
+    assert torch.equal(keep[2], ref)
+    assert 1.0 < us[0] < 500.0, us[0]             # a 0.9 GFLOP conv: a few microseconds, not 0 and not a millisecond
+
+
+def test_embed_concat_bwd_beyond_the_default_lds_limit(lib):
+    """N = 20000 packed rows: the token list needs 80 KB of dynamic LDS (opt-in above 48 KB); first-occurrence scatter
+    equals index_add in fp64"""
+    g = torch.Generator().manual_seed(84)
+    B, T, E, V = 1000, 21, 16, 300
+    lengths = [T - 1] * B                                      # packed steps T-1 = 20 -> N = 20000
+    caps = torch.randint(0, V, (B, T), generator=g)
+    pi = sat.PackInfo.get(lengths, "cuda")
+    N = pi.N
+    dX = torch.randn(N, E, generator=g)
+    dXd, cd = cu(dX), cu(caps)
+    d_embed = torch.full((V, E), float("nan"), device="cuda")
+    d_feat = torch.full((B, E), float("nan"), device="cuda")
+    L.check(lib.sat_embed_concat_bwd(dXd.data_ptr(), cd.data_ptr(), cd.stride(0), pi.prefix_dev.data_ptr(), pi.T, N, B, E, V,
+                                     d_embed.data_ptr(), d_feat.data_ptr(), st()))
+    sync()
+    ref = torch.zeros(V, E, dtype=torch.float64)
+    for t in range(1, pi.T):
+        rows = dX[pi.prefix[t]:pi.prefix[t + 1]].double()
+        ref.index_add_(0, caps[:pi.batch_sizes[t], t - 1], rows)
+    np.testing.assert_allclose(d_embed.cpu().double().numpy(), ref.numpy(), rtol=0, atol=5e-5)
+    assert torch.equal(d_feat.cpu(), dX[:B])

@@ -1,0 +1,222 @@
+"""GPU (MI355X) parity AT THE BENCHMARKED CONFIGURATION: the real ResNet-152 [3,8,36,3] stack at 224x224 in the bf16
+mode `bench.py` measures -- against the CPU oracle with bf16 storage emulated (`oracle.encoder.
+resnet_forward_bf16_storage`), against the f32 oracle, and against this library's own f32 parity mode -- and whole
+training steps at BASELINE configs[1] (batch 64) in both modes against `oracle.train_step.full_step`.
+
+Tolerances (measured values are printed; DESIGN.md section 4 quotes them):
+  * f32 mode: mean CE within 1e-4 of the oracle on every step (north_star's bar).
+  * bf16 mode: the conv stack stores bf16 (2^-8 relative rounding per stored tensor, 155 convs deep, BatchNorm
+    renormalising after each), so pooled features agree with the bf16-storage oracle to a few percent relative L2 --
+    what is left is summation order plus the 1-ulp bf16 flips it causes downstream -- and the CE, which at these
+    weights depends on the features only through the BatchNorm1d-normalised head, moves by <= 2e-3.
+Encoder parity is build-internal either way ("parity unpinned": torchvision is absent)."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sat = importlib.import_module("show-and-tell_amd")
+from oracle import decoder as OD  # noqa: E402
+from oracle import encoder as OE  # noqa: E402
+from oracle import train_step as OT  # noqa: E402
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+def _cos(a, b):
+    return torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+
+
+def _encoder(arch, E, params, buffers, dtype):
+    enc = sat.EncoderCNN(E, arch=arch, compute_dtype=dtype)
+    sd = dict(params)
+    sd.update(buffers)
+    enc.load_state_dict(sd)
+    return enc.cuda()
+
+
+@pytest.mark.timeout(900)
+def test_resnet152_bf16_train_mode_cfg1_vs_bf16_storage_oracle():
+    """BASELINE cfg-1 shape (batch 4, 224x224), all 152 layers, bf16 TRAIN mode (batch statistics): models.py:25-29"""
+    arch, E, B = OE.RESNET152, 256, 4
+    gen = torch.Generator().manual_seed(41)
+    params, buffers = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(42))
+    enc = _encoder(arch, E, params, buffers, "bf16").train()
+    got = [enc.pooled_features(x.cuda()).cpu() for _ in range(3)]      # eager, eager (other parity), graph replay
+    ref_bf = OE.resnet_forward_bf16_storage(params, x, arch)
+    bufs = {k: v.clone() for k, v in buffers.items()}
+    ref_f32, _ = OE.resnet_forward(params, bufs, x, arch, training=True)
+    r_bf, r_f32, r_or = _rel(got[0], ref_bf), _rel(got[0], ref_f32), _rel(ref_bf, ref_f32)
+    print("cfg1 bf16 pooled: rel-L2 vs bf16-storage oracle %.4f, vs f32 oracle %.4f (bf16-storage oracle vs f32 oracle %.4f), cos %.5f"
+          % (r_bf, r_f32, r_or, _cos(got[0], ref_bf)))
+    assert torch.isfinite(got[0]).all()
+    # the HIP path must be as close to the bf16-storage oracle as that oracle's own rounding noise allows: both sit
+    # the same distance from the f32 result (r_or), and from each other by no more than that
+    assert r_bf < max(0.05, 1.5 * r_or), (r_bf, r_or)
+    assert r_f32 < max(0.08, 2.0 * r_or), (r_f32, r_or)
+    assert _cos(got[0], ref_bf) > 0.995
+    for g in got[1:]:                                      # same input, same statistics: every pass reproduces the first
+        assert torch.equal(g, got[0])
+
+
+def _cfg2_models(dtype, seed=123, B=64):
+    gen = torch.Generator().manual_seed(seed)
+    ep, eb = OE.init_encoder_params(256, OE.RESNET152, generator=gen)
+    dp = OD.init_decoder_params(256, 512, 10000, 1, generator=gen)
+    images = torch.randn(B, 3, 224, 224, generator=gen)
+    caps = torch.randint(4, 10000, (B, 20), generator=gen)
+    caps[:, 0], caps[:, 19] = 1, 2
+    model = sat.ShowAndTell(256, 512, 10000, 1, compute_dtype=dtype)
+    sd = dict(ep)
+    sd.update(eb)
+    model.encoder.load_state_dict(sd)
+    model.decoder.load_state_dict(dp)
+    return model.cuda().train(), ep, eb, dp, images, caps, [20] * B
+
+
+@pytest.mark.timeout(1500)
+def test_cfg2_whole_train_steps_f32_and_bf16_vs_oracle():
+    """BASELINE configs[1]: batch 64, 224x224, E=256 H=512 V=10000 -- three whole train.py:126-146 iterations (both step
+    parities and the captured hipGraph are exercised) in the f32 parity mode AND the benchmarked bf16 mode against
+    `oracle.train_step.full_step` on the same weights and batch."""
+    model32, ep, eb, dp, images, caps, lengths = _cfg2_models("f32")
+    model16, _, _, _, _, _, _ = _cfg2_models("bf16")
+    ts32, ts16 = sat.TrainStep(model32), sat.TrainStep(model16)
+    di, dc = images.cuda(), caps.cuda()
+    ebo = {k: v.clone() for k, v in eb.items()}
+    epo = {k: v.clone() for k, v in ep.items()}
+    dpo = {k: v.clone() for k, v in dp.items()}
+    state = {}
+    ref, l32, l16 = [], [], []
+    for step in range(3):
+        rl, _ = OT.full_step(epo, ebo, dpo, images, caps, lengths, state)
+        ref.append(rl.item())
+        l32.append(ts32.step(di, dc, lengths).item())
+        l16.append(ts16.step(di, dc, lengths).item())
+    print("cfg2 CE per step: oracle %s | f32 %s | bf16 %s" % (ref, l32, l16))
+    print("cfg2 |dCE| f32 %.2e, bf16 %.2e" % (max(abs(a - b) for a, b in zip(l32, ref)), max(abs(a - b) for a, b in zip(l16, ref))))
+    for a, b in zip(l32, ref):
+        assert abs(a - b) < 1e-4, (l32, ref)                 # north_star: CE within 1e-4 fp32
+    for a, b in zip(l16, ref):
+        assert abs(a - b) < 2e-3, (l16, ref)                 # bf16 conv stack: stated tolerance (module docstring)
+    # parameters after three clamp+Adam steps (f32 mode; resnet.fc.bias has a mathematically zero gradient under
+    # train-mode BatchNorm1d: Adam turns its rounding noise into +-lr steps in torch as here -- excluded)
+    got = {k: v.detach().cpu() for k, v in model32.decoder.state_dict().items()}
+    for k in dpo:
+        assert torch.allclose(got[k], dpo[k], rtol=0, atol=1e-4), (k, (got[k] - dpo[k]).abs().max().item())
+    fc = model32.encoder.resnet.fc.weight.detach().cpu()
+    assert torch.allclose(fc, epo["resnet.fc.weight"], rtol=0, atol=2e-3)       # +-lr Adam steps on near-zero gradients can flip sign
+    # head output of the two HIP modes on the SAME (now trained-for-3-steps-apart) weights is not comparable; compare
+    # encoder features on the f32 model's weights instead
+    sd = model32.encoder.state_dict()
+    model16.encoder.load_state_dict(sd)
+    p32 = model32.encoder.pooled_features(di)
+    p16 = model16.encoder.pooled_features(di)
+    print("cfg2 pooled bf16 vs f32 HIP: rel-L2 %.4f cos %.5f" % (_rel(p16.cpu(), p32.cpu()), _cos(p16, p32)))
+    assert _rel(p16.cpu(), p32.cpu()) < 0.08 and _cos(p16, p32) > 0.995
+
+
+@pytest.mark.timeout(900)
+def test_cfg2_bf16_vs_f32_hip_train_two_steps_and_eval():
+    """Full size, autotuned variants, atomic statistics, slab-to-acc, hipGraph replay: bf16 pooled features and head
+    output against this library's f32 mode (itself oracle-checked at cfg1/cfg2 above) on the same weights -- train
+    mode (3 passes: both parities + the captured graph) and eval mode (fused epilogues)."""
+    model32, ep, eb, dp, images, caps, lengths = _cfg2_models("f32", seed=7)
+    model16, _, _, _, _, _, _ = _cfg2_models("bf16", seed=7)
+    di = images.cuda()
+    e32, e16 = model32.encoder.train(), model16.encoder.train()
+    with torch.no_grad():
+        for i in range(3):
+            p32, p16 = e32.pooled_features(di), e16.pooled_features(di)
+            r, c = _rel(p16.cpu(), p32.cpu()), _cos(p16, p32)
+            print("train pass %d: pooled rel-L2 %.4f cos %.5f" % (i, r, c))
+            assert r < 0.08 and c > 0.995, (i, r, c)
+        f32o, f16o = e32(di), e16(di)
+        r = _rel(f16o.cpu(), f32o.cpu())
+        print("train head output rel-L2 %.4f" % r)
+        assert r < 0.15                                        # BatchNorm1d over 64 rows renormalises the feature error
+        # eval: let the running statistics converge on the f32 model (momentum 0.1), copy them, compare eval passes
+        for _ in range(40):
+            e32.pooled_features(di)
+        e16.load_state_dict(e32.state_dict())
+        e32.eval()
+        e16.eval()
+        q32, q16 = e32.pooled_features(di), e16.pooled_features(di)
+        assert torch.isfinite(q32).all() and torch.isfinite(q16).all()
+        r, c = _rel(q16.cpu(), q32.cpu()), _cos(q16, q32)
+        print("eval: pooled rel-L2 %.4f cos %.5f" % (r, c))
+        assert r < 0.08 and c > 0.995, (r, c)
+
+
+def test_encoder_sees_weights_loaded_into_the_stack_after_a_forward():
+    """`encoder.resnet.load_state_dict(...)` (how the pretrained ResNet-152 of models.py:13 would be loaded) after a
+    forward must rebuild the op program's kernel-layout weight copies: output == a fresh model with those weights"""
+    arch, E, B = dict(layers=(1, 1, 1, 1), width=8), 32, 4
+    gen = torch.Generator().manual_seed(5)
+    p1, b1 = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
+    p2, b2 = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
+    x = torch.randn(B, 3, 64, 64, generator=gen).cuda()
+    for dtype in ("f32", "bf16"):
+        enc = _encoder(arch, E, p1, b1, dtype).eval()
+        y1 = enc.pooled_features(x)
+        stack_sd = {k[len("resnet."):]: v for k, v in {**p2, **b2}.items() if k.startswith("resnet.")}
+        enc.resnet.load_state_dict(stack_sd)                   # the PARENT's hook does not fire here
+        y2 = enc.pooled_features(x)
+        fresh = _encoder(arch, E, p2, b2, dtype).eval()
+        assert torch.equal(y2, fresh.pooled_features(x)) and not torch.equal(y1, y2)
+        # in-place write through the Parameter (version counter) is seen too
+        with torch.no_grad():
+            enc.resnet.conv1.weight.mul_(0.5)
+            fresh.resnet.conv1.weight.mul_(0.5)
+        fresh.refresh_weights()
+        assert torch.equal(enc.pooled_features(x), fresh.pooled_features(x))
+
+
+def test_two_forwards_before_one_backward_keep_their_own_activations():
+    """grad accumulation on the drop-in path: model(a); model(b); backward of both -- the head's saved `pooled` must not
+    alias the program's output buffer"""
+    arch, E = dict(layers=(1, 1, 1, 1), width=8), 32
+    gen = torch.Generator().manual_seed(9)
+    p, b = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
+    xa, xb = torch.randn(4, 3, 64, 64, generator=gen).cuda(), torch.randn(4, 3, 64, 64, generator=gen).cuda()
+    enc = _encoder(arch, E, p, b, "f32").train()
+    ya = enc(xa)
+    ya.sum().backward()
+    ref = enc.resnet.fc.weight.grad.clone()
+    enc2 = _encoder(arch, E, p, b, "f32").train()
+    ya2 = enc2(xa)
+    enc2(xb)                                  # second forward of the same shape before the backward
+    ya2.sum().backward()
+    assert torch.allclose(enc2.resnet.fc.weight.grad, ref, rtol=1e-5, atol=1e-7)
+
+
+def test_out_of_range_caption_id_raises_instead_of_training_silently():
+    model = sat.ShowAndTell(32, 64, 100, 1, arch=dict(layers=(1, 1, 1, 1), width=8), compute_dtype="f32").cuda().train()
+    ts = sat.TrainStep(model)
+    images = torch.randn(4, 3, 64, 64, device="cuda")
+    caps = torch.randint(4, 100, (4, 8), device="cuda")
+    ts.step(images, caps, [8] * 4)
+    ts.check_ids()                            # fine
+    bad = caps.clone()
+    bad[2, 3] = 100                           # == V
+    ts.step(images, bad, [8] * 4)
+    with pytest.raises(IndexError):
+        ts.check_ids()
+    ts.step(images, caps, [8] * 4)            # the guard is usable again
+    ts.check_ids()
+    neg = caps.clone()
+    neg[0, 1] = -1
+    dec = model.decoder
+    feats = torch.randn(4, 32, device="cuda")
+    dec(feats, neg[:, :-1], [8] * 4)
+    with pytest.raises(IndexError):
+        dec.id_guard().poll(block=True)
+    with pytest.raises(ValueError):
+        ts.step(images, caps, [9] * 4)        # a length beyond the caption matrix: sat_pack_targets would read past the row
+    with pytest.raises(ValueError):
+        ts.step(images, caps, [8, 8, 8, 1])   # no target token
