@@ -116,6 +116,12 @@ typedef struct sat_op {
     const float* beta1;
     float* running_mean1;
     float* running_var1;
+    /* SAT_OP_CONV, bf16, training, dense 1x1: dual-source input.  out1 != NULL => the A operand is
+     * y = relu(in0*scale + shift + in1) -- the previous bottleneck's bn3 (scale0/shift0, or derived from stat_acc1 like
+     * the single-source input fusion), residual add (in1, shaped like in0) and ReLU, torchvision Bottleneck.forward under
+     * models.py:27 -- formed in LDS, and y is also stored to out1 (shaped like in0: the next block's residual).  Replaces
+     * the SAT_OP_BN_ADD_RELU launch between two bottlenecks. */
+    void* out1;
 } sat_op;
 
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
@@ -136,7 +142,7 @@ int sat_conv_bn_relu_fwd(const sat_op* conv, const sat_op* finalize, const sat_o
 int sat_conv_tiles_m(int64_t M);
 /* Build-time tuner (NOT for the hot path: it times launches with HIP events and synchronises): for every bf16
  * SAT_OP_CONV in ops[] run each kernel variant `reps` times on the op's own buffers and record the fastest in
- * ops[i].variant.  Results are cached per conv geometry inside the library (mutex-protected).  `scratch`: >= 4096
+ * ops[i].variant.  Results are cached per conv geometry inside the library (mutex-protected).  `scratch`: >= 16384
  * bytes of device memory owned by the caller (a neutral BatchNorm table for the input-fused convs lives there while
  * the tuner runs): like every other entry point, this one allocates no device memory. */
 int sat_conv_autotune(sat_op* ops /*[host]*/, int n_ops, int reps, float* scratch, int64_t scratch_bytes,

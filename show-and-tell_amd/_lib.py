@@ -40,7 +40,7 @@ class SatOp(C.Structure):
         ("momentum", C.c_float), ("eps", C.c_float),
         ("variant", C.c_int32), ("flags", C.c_int32),
         ("stat_acc", _vp), ("stat_acc1", _vp), ("gamma1", _vp), ("beta1", _vp),
-        ("running_mean1", _vp), ("running_var1", _vp),
+        ("running_mean1", _vp), ("running_var1", _vp), ("out1", _vp),
     ]
 
 

@@ -65,6 +65,14 @@ struct ConvArgs {
     const float* out_shift;
     const bf16_t* residual;  // [M][ldc] like C, or NULL
     int out_relu;
+    // Dual-source input (1x1 convs, training): the A operand is y = relu(A*in_scale + in_shift + R) -- the previous
+    // bottleneck's bn3 + residual add + ReLU (models.py:27, torchvision Bottleneck.forward's `out += identity; relu`)
+    // applied to each landed LDS stage from TWO LDS-DMA sources (A = raw conv3 output, R = the block input), so the
+    // separate normalise+add launch and its re-read disappear; the tile_n == 0 workgroups also store y (the next
+    // residual) to Y.  R, Y: [M][ldy] like A.
+    const bf16_t* R;
+    bf16_t* Y;
+    long ldy;
     int dbg;                 // diagnostics only (SAT_CONV_DBG): 1 = no loads, 2 = no MFMA, 4 = no epilogue
 };
 // fixed-point scale of the atomic statistics is SAT_STAT_SCALE (sat_internal.h)
@@ -74,8 +82,15 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16 || N == 18 || N == 24,
+    static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 9 || N == 10 || N == 12 ||
+                      N == 15 || N == 16 || N == 18 || N == 20 || N == 24,
                   "add the vmcnt literal");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -94,25 +109,29 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // PF: consumers prefetch the first MFMA fragments of K-step kt+1 during the last MFMAs of K-step kt, so no LDS read
 // latency is exposed behind the per-K-step barrier; the loaders' counted wait then has to cover K-step kt+1 at
 // barrier kt (one in-flight K-step fewer than the ring could hold, hence S >= 4).
-template <int BN, int S, int NW, bool UNIFORM, bool SPEC = false, bool PF = false>
+// DUAL: two-source A operand (ConvArgs::R/Y); BM: tile rows (128; 64 for the wide dual tiles, whose A side is the
+// expensive one: two sources and an in-LDS pass, so it is kept short and the tile covers all of N instead).
+template <int BN, int S, int NW, bool UNIFORM, bool SPEC = false, bool PF = false, int BM = 128, bool DUAL = false>
 __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
-    constexpr int BM = 128, BK = 64, NT = NW * 64;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int BK = 64, NT = NW * 64;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES + (DUAL ? A_BYTES : 0);
+    constexpr int R_OFF = A_BYTES + B_BYTES;               // DUAL: the residual source's half of a stage
     constexpr int LW = SPEC ? NW / 2 : NW;                // waves that issue the LDS-DMA
     constexpr int CW = SPEC ? NW / 2 : NW;                // waves that own accumulators
-    // consumer wave grid: 4 waves: 2x2;  8 waves: 2(M)x4(N) for BN=128, 4(M)x2(N) for BN=64
-    constexpr int WGM = (CW == 4) ? 2 : (BN == 128 ? 2 : 4);
+    // consumer wave grid: 4 waves: 2x2;  8 waves: 4(M)x2(N) for the 128x64 tile, 2(M)x4(N) otherwise
+    constexpr int WGM = (CW == 4) ? 2 : ((BM == 128 && BN == 64) ? 4 : 2);
     constexpr int WGN = CW / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int NAI = BM / 8 / LW, NBI = BN / 8 / LW;   // LDS-DMA pieces (8 rows x 128 B) per loader wave per stage
-    constexpr int LPW = NAI + NBI;
+    constexpr int LPW = NAI + NBI + (DUAL ? NAI : 0);
+    static_assert(!DUAL || (UNIFORM && !SPEC && !PF), "the dual-source transform lives in the plain unified-wave loop");
     constexpr int D = S - 1;                               // K-steps kept in flight
     constexpr int WAITN = LPW * (PF ? D - 2 : D - 1);      // loader pieces that may still be in flight at a barrier
     static_assert(!PF || S >= 4, "fragment prefetch needs one more landed stage");
     constexpr int CROW = BN * 2 + 16;                      // bf16 C-tile row stride in LDS (epilogue)
     static_assert(BM * CROW + 4 * WGM * BN * 4 <= S * STAGE, "epilogue tile + stat scratch must fit the ring");
     static_assert(TM >= 1 && TN >= 1 && NAI >= 1 && NBI >= 1, "bad tile/wave split");
-    constexpr int TAB_BYTES = 2 * 512 * 4;                 // input-BN (scale, shift) table: up to 512 input channels
+    constexpr int TAB_BYTES = 2 * (DUAL ? 2048 : 512) * 4;  // input-BN (scale, shift) table: up to 512 (2048) input channels
     __shared__ __attribute__((aligned(16))) char smem[S * STAGE + TAB_BYTES];   // ONE LDS object (ring + table)
     float* in_tab = (float*)(smem + S * STAGE);
 
@@ -181,6 +200,13 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         b_ptr[i] = b_ok[i] ? p.B + ((long)gn * p.ldb + b_c[i]) : zero;
     }
     const int nk = (p.K + BK - 1) / BK;
+    // DUAL: the residual source walks K exactly like A (same rows, same chunk swizzle)
+    const bf16_t* r_ptr[NAI];
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+        const int grow = m0 + lw * (NAI * 8) + i * 8 + (lane >> 3);
+        r_ptr[i] = (DUAL && grow < p.M) ? p.R + ((long)grow * p.ldy + a_c[i]) : zero;
+    }
     // linear (1x1) walk: per-lane pointers advance by one K-step; invalid rows stay on the zero word
     int a_step[NAI], b_step[NBI];
     const bf16_t* b_walk[NBI];
@@ -206,6 +232,11 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int i = 0; i < NBI; ++i)
                     __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sB + (lw * (NBI * 8) + i * 8) * 128), 16, 0, 0);
+                if constexpr (DUAL) {
+#pragma unroll
+                    for (int i = 0; i < NAI; ++i)
+                        __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sA + R_OFF + (lw * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+                }
                 ++is_kt;
                 return;
             }
@@ -221,6 +252,13 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 for (int i = 0; i < NBI; ++i) {
                     __builtin_amdgcn_global_load_lds((gptr_t)b_walk[i], (lptr_t)(sB + (lw * (NBI * 8) + i * 8) * 128), 16, 0, 0);
                     b_walk[i] += b_step[i];
+                }
+                if constexpr (DUAL) {
+#pragma unroll
+                    for (int i = 0; i < NAI; ++i) {
+                        __builtin_amdgcn_global_load_lds((gptr_t)r_ptr[i], (lptr_t)(sA + R_OFF + (lw * (NAI * 8) + i * 8) * 128), 16, 0, 0);
+                        r_ptr[i] += a_step[i];
+                    }
                 }
                 ++is_kt;
                 return;
@@ -332,10 +370,20 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 bf16x8 v = *(const bf16x8*)(sA + row * 128 + pos * 16);
                 const f32x4 s0 = *(const f32x4*)(in_tab + c0), s1 = *(const f32x4*)(in_tab + c0 + 4);
                 const f32x4 t0 = *(const f32x4*)(in_tab + p.Cin + c0), t1 = *(const f32x4*)(in_tab + p.Cin + c0 + 4);
+                if constexpr (DUAL) {
+                    const bf16x8 z = *(const bf16x8*)(sA + R_OFF + row * 128 + pos * 16);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e], 0.0f);
-                    v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e], 0.0f);
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e] + (float)z[e], 0.0f);
+                        v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e] + (float)z[e + 4], 0.0f);
+                    }
+                    if (tile_n == 0) *(bf16x8*)(p.Y + (long)(m0 + row) * p.ldy + c0) = v;     // the next block's residual
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e], 0.0f);
+                        v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e], 0.0f);
+                    }
                 }
                 *(bf16x8*)(sA + row * 128 + pos * 16) = v;
             }
@@ -547,21 +595,25 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     }
 }
 
-template <int BN, int S, int NW, bool SPEC = false, bool PF = false>
+template <int BN, int S, int NW, bool SPEC = false, bool PF = false, int BM = 128, bool DUAL = false>
 int launch_glds(ConvArgs& a, hipStream_t s) {
-    const int tm = sat_cdiv(a.M, 128), tn = sat_cdiv(a.N, BN);
+    const int tm = sat_cdiv(a.M, BM), tn = sat_cdiv(a.N, BN);
     a.tiles_n = tn;
     const bool uniform = (a.Cin % 64 == 0) && (a.KH * a.KW <= 32);
-    if (t_ev_start) {                      // timed diagnostic launch: same kernel, same grid, plus the packet's timestamps
-        hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;
-        t_ev_start = t_ev_stop = nullptr;
-        if (uniform) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, e0, e1, 0, a);
-        else hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, e0, e1, 0, a);
-        SAT_LAUNCH_CHECK();
-        return SAT_OK;
+    const dim3 grid(tm * tn), block(NW * 64);
+    hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;     // armed: timed diagnostic launch (same kernel, same grid, + the packet's timestamps)
+    t_ev_start = t_ev_stop = nullptr;
+    if constexpr (DUAL) {
+        if (!uniform) return SAT_ERR_UNSUPPORTED;
+        if (e0) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM, true>), grid, block, 0, s, e0, e1, 0, a);
+        else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM, true>), grid, block, 0, s, a);
+    } else if (uniform) {
+        if (e0) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM>), grid, block, 0, s, e0, e1, 0, a);
+        else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM>), grid, block, 0, s, a);
+    } else {
+        if (e0) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false, SPEC, PF, BM>), grid, block, 0, s, e0, e1, 0, a);
+        else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false, SPEC, PF, BM>), grid, block, 0, s, a);
     }
-    if (uniform) hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
-    else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, false, SPEC, PF>), dim3(tm * tn), dim3(NW * 64), 0, s, a);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
@@ -571,13 +623,18 @@ int tune_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// kernel variants: (tile width, ring stages, waves).  LDS = S * (16 + BN/8) KB decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf; };
+// kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows, dual-source A).
+// LDS = S * (BM/8 + BN/8 [+ BM/8]) KB (+ the table) decides workgroups per CU.
+struct Variant { int bn, s, nw, spec, pf, bm, dual; };
 constexpr Variant kVariants[] = {
-    {128, 4, 8, 0}, {128, 3, 8, 0}, {128, 2, 8, 0}, {64, 4, 8, 0}, {64, 3, 8, 0}, {64, 2, 8, 0},
-    {128, 4, 4, 0}, {128, 2, 4, 0}, {64, 3, 4, 0}, {64, 2, 4, 0},
-    {128, 4, 8, 1}, {128, 3, 8, 1}, {128, 2, 8, 1}, {64, 4, 8, 1}, {64, 3, 8, 1},     // 4 consumer + 4 loader waves
-    {128, 4, 8, 1, 1}, {128, 4, 8, 0, 1}, {128, 4, 4, 0, 1}, {64, 4, 8, 1, 1}, {64, 4, 8, 0, 1}, {64, 4, 4, 0, 1},   // fragment prefetch
+    {128, 4, 8, 0, 0, 128, 0}, {128, 3, 8, 0, 0, 128, 0}, {128, 2, 8, 0, 0, 128, 0}, {64, 4, 8, 0, 0, 128, 0}, {64, 3, 8, 0, 0, 128, 0},
+    {64, 2, 8, 0, 0, 128, 0}, {128, 4, 4, 0, 0, 128, 0}, {128, 2, 4, 0, 0, 128, 0}, {64, 3, 4, 0, 0, 128, 0}, {64, 2, 4, 0, 0, 128, 0},
+    {128, 4, 8, 1, 0, 128, 0}, {128, 3, 8, 1, 0, 128, 0}, {128, 2, 8, 1, 0, 128, 0}, {64, 4, 8, 1, 0, 128, 0}, {64, 3, 8, 1, 0, 128, 0},   // 4 consumer + 4 loader waves
+    {128, 4, 8, 1, 1, 128, 0}, {128, 4, 8, 0, 1, 128, 0}, {128, 4, 4, 0, 1, 128, 0}, {64, 4, 8, 1, 1, 128, 0}, {64, 4, 8, 0, 1, 128, 0},
+    {64, 4, 4, 0, 1, 128, 0},                                                                                                       // fragment prefetch
+    {256, 2, 8, 0, 0, 64, 1}, {256, 3, 8, 0, 0, 64, 1}, {128, 2, 8, 0, 0, 128, 1}, {128, 3, 8, 0, 0, 128, 1}, {128, 3, 8, 0, 0, 64, 1},
+    {128, 4, 8, 0, 0, 64, 1},                                                                                                       // dual-source A (bn3 + add + ReLU of the previous block)
+    {256, 2, 8, 0, 0, 128, 0}, {256, 3, 8, 0, 0, 128, 0}, {256, 3, 8, 0, 0, 64, 0},                                                   // wide tiles
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -604,6 +661,15 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 18: return launch_glds<64, 4, 8, true, true>(a, s);
         case 19: return launch_glds<64, 4, 8, false, true>(a, s);
         case 20: return launch_glds<64, 4, 4, false, true>(a, s);
+        case 21: return launch_glds<256, 2, 8, false, false, 64, true>(a, s);
+        case 22: return launch_glds<256, 3, 8, false, false, 64, true>(a, s);
+        case 23: return launch_glds<128, 2, 8, false, false, 128, true>(a, s);
+        case 24: return launch_glds<128, 3, 8, false, false, 128, true>(a, s);
+        case 25: return launch_glds<128, 3, 8, false, false, 64, true>(a, s);
+        case 26: return launch_glds<128, 4, 8, false, false, 64, true>(a, s);
+        case 27: return launch_glds<256, 2, 8, false, false, 128>(a, s);
+        case 28: return launch_glds<256, 3, 8, false, false, 128>(a, s);
+        case 29: return launch_glds<256, 3, 8, false, false, 64>(a, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -623,7 +689,11 @@ ConvArgs make_args(const sat_op* op) {
         a.in_count = (double)op->count; a.in_momentum = op->momentum; a.in_eps = op->eps;
     }
     a.out_scale = op->scale1; a.out_shift = op->shift1;        // inference epilogue: affine (+ residual) (+ ReLU)
-    a.residual = (const bf16_t*)op->in1;
+    if (op->out1) {                                            // dual-source A: in1 is the residual SOURCE, out1 the side output
+        a.R = (const bf16_t*)op->in1; a.Y = (bf16_t*)op->out1; a.ldy = op->Cin;
+    } else {
+        a.residual = (const bf16_t*)op->in1;
+    }
     a.out_relu = op->flags & 1;
     a.M = op->N * op->Hout * op->Wout; a.N = op->Cout; a.K = op->KH * op->KW * op->Cin;
     a.ldb = a.K; a.ldc = op->Cout;
@@ -642,14 +712,19 @@ ConvArgs make_args(const sat_op* op) {
 // a variant the kernel can run for these arguments (the in-LDS input transform lives in the plain unified-wave loop)
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
-    if (kVariants[v].bn == 128 && a.N <= 64) return false;
-    if ((kVariants[v].spec || kVariants[v].pf) && a.in_affine) return false;
+    const Variant& k = kVariants[v];
+    if (k.bn >= 128 && a.N <= 64) return false;
+    if (k.bn == 256 && a.N <= 128) return false;
+    if ((k.spec || k.pf) && a.in_affine) return false;
+    if ((k.dual != 0) != (a.R != nullptr)) return false;             // dual-source ops run dual kernels and nothing else
+    if (k.bm != 128 && a.stat_partial) return false;                 // the per-tile statistics slabs are 128-row tiles
     return true;
 }
 
 int heuristic_variant(const ConvArgs& a) {
     // 128x128 with a deep ring when it still leaves >= 2 tiles per CU and K is long enough to use the ring;
     // otherwise 128x64 with a shallower ring (more workgroups per CU to overlap prologue/epilogue phases)
+    if (a.R) return a.N > 128 ? 21 : 25;          // dual-source: 64-row tiles covering all of N where N <= 256
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const int nk = sat_cdiv(a.K, 64);
     if (a.N > 64 && t128 >= 512) return nk <= 4 ? 2 : 0;
@@ -666,8 +741,13 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
     if ((a.out_scale != nullptr) != (a.out_shift != nullptr)) return SAT_ERR_ARG;
     if (a.residual && (!a.out_scale || (const void*)a.residual == (const void*)a.C)) return SAT_ERR_ARG;
     if (a.out_scale && (a.stat_partial || a.acc)) return SAT_ERR_ARG;     // batch statistics and a fixed affine exclude each other
+    if (a.R) {
+        // dual-source A: needs the input affine (the previous bn3), a dense 1x1 geometry and room for the table
+        if (!a.in_affine || !a.linear || a.Cin > 2048 || (a.Cin % 64) || !a.Y || a.out_scale) return SAT_ERR_UNSUPPORTED;
+        if ((const void*)a.Y == (const void*)a.A || (const void*)a.Y == (const void*)a.R || (const void*)a.Y == (const void*)a.C) return SAT_ERR_ARG;
+    }
     if (a.in_affine) {
-        if (!a.linear || a.Cin > 512 || (a.Cin % 64)) return SAT_ERR_UNSUPPORTED;
+        if (!a.linear || a.Cin > (a.R ? 2048 : 512) || (a.Cin % 64)) return SAT_ERR_UNSUPPORTED;
         if (a.in_acc) {
             if (!a.in_gamma || !a.in_beta || a.in_count < 1) return SAT_ERR_ARG;
             long long* base = (long long*)op->stat_acc1;       // [2 parities][2][Cin]
@@ -678,7 +758,7 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
         }
     }
     int v = (op->variant > 0 && op->variant <= kNumVariants) ? op->variant - 1 : heuristic_variant(a);
-    if (a.in_affine && (kVariants[v].spec || kVariants[v].pf)) v = heuristic_variant(a);   // the in-LDS transform lives in the plain unified-wave loop
+    if (!variant_ok(v, a)) v = heuristic_variant(a);      // e.g. the in-LDS transforms live in the plain unified-wave loop
     return launch_variant(v, a, s);
 }
 
@@ -687,18 +767,20 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
 #include <tuple>
 #include <stdio.h>
 
+constexpr int kTuneTab = 2048;      // channels of the tuner's neutral (scale 1, shift 0) input-BatchNorm table
+
 extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
                                  sat_stream_t stream) {
     if (!ops || n_ops < 0 || reps < 1) return SAT_ERR_ARG;
-    if (!scratch || scratch_bytes < (int64_t)(1024 * sizeof(float))) return SAT_ERR_WORKSPACE;
+    if (!scratch || scratch_bytes < (int64_t)(2 * kTuneTab * sizeof(float))) return SAT_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int> Key;
     static std::map<Key, int> cache;
     static std::mutex cache_mu;                       // the per-geometry result cache is shared by every caller thread
     const bool verbose = getenv("SAT_TUNE_VERBOSE") != nullptr;
     // neutral input-BatchNorm table (scale 1, shift 0) in the CALLER's scratch: the library allocates nothing
-    if (hipMemsetD32Async((hipDeviceptr_t)scratch, 0x3f800000, 512, s) != hipSuccess ||
-        hipMemsetAsync(scratch + 512, 0, 512 * sizeof(float), s) != hipSuccess)
+    if (hipMemsetD32Async((hipDeviceptr_t)scratch, 0x3f800000, kTuneTab, s) != hipSuccess ||
+        hipMemsetAsync(scratch + kTuneTab, 0, kTuneTab * sizeof(float), s) != hipSuccess)
         return SAT_ERR_UNSUPPORTED;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SAT_ERR_UNSUPPORTED;
@@ -708,7 +790,7 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
         if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) continue;
         const Key key(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
                       ((op->stat_partial || op->stat_acc) ? 1 : 0) + ((op->scale0 || op->stat_acc1) ? 2 : 0) +
-                          (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0));
+                          (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0) + (op->out1 ? 16 : 0));
         {
             std::lock_guard<std::mutex> lk(cache_mu);
             auto it = cache.find(key);
@@ -718,8 +800,8 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
         a.acc = nullptr;             // tuning launches must not touch the statistics / running buffers
         if (a.in_affine) {           // ... nor derive from / clear the live accumulators: the neutral table stands in
             a.in_acc = nullptr; a.in_acc_clear = nullptr; a.in_running_mean = nullptr;
-            a.in_scale = scratch; a.in_shift = scratch + 512;
-            if (!a.linear || a.Cin > 512 || (a.Cin % 64)) continue;
+            a.in_scale = scratch; a.in_shift = scratch + kTuneTab;
+            if (!a.linear || a.Cin > (a.R ? 2048 : 512) || (a.Cin % 64)) continue;
         }
         float best = 1e30f;
         int best_v = heuristic_variant(a);

@@ -341,7 +341,13 @@ class ConvStackProgram:
             mp.count, mp.momentum, mp.eps = count_, BN_MOMENTUM, BN_EPS
         mp.N, mp.Hin, mp.Win, mp.Cout, mp.Hout, mp.Wout = N, Ho, Wo, width, hp_, wp_
         ops.append(mp)
-        for blk, (h, w_, h2, w2, inpl, planes, stride) in zip(stack.blocks(), geo):
+        # bn3 + residual add + ReLU of an identity-residual bottleneck folded into the NEXT bottleneck's conv1 (bf16
+        # training): that conv forms y = relu(c3*s3+t3 + y_prev) in LDS from two LDS-DMA sources and stores y once as
+        # the next residual -- 45 of the 50 normalise+add launches of ResNet-152 and one re-read of y disappear
+        fuse_resid = training and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_RESIDUAL", "1") != "0"
+        pending = None          # (s3, t3, resid buffer) of the previous block when its bn_add is deferred to this conv1
+        blocks_geo = list(zip(stack.blocks(), geo))
+        for bi, (blk, (h, w_, h2, w2, inpl, planes, stride)) in enumerate(blocks_geo):
             tm1 = L.load().sat_conv_tiles_m(N * h * w_)
             tm2 = L.load().sat_conv_tiles_m(N * h2 * w2)
             if fuse_out_bn:
@@ -363,7 +369,23 @@ class ConvStackProgram:
                 fused(blk.conv3, blk.bn3, self.a2, ynext, h2, w2, h2, w2, N * h2 * w2, True, resid)
                 y, ynext = ynext, y
                 continue
-            ops.append(std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_))
+            if pending is not None:
+                ps3, pt3, presid = pending
+                cv1 = std_conv(blk.conv1, self.c3, self.c1, N, h, w_, h, w_)      # A = previous RAW conv3 output ...
+                cv1.in1, cv1.out1 = presid.data_ptr(), y.data_ptr()              # ... + previous block input -> y (stored too)
+                ref = bnref.get(ps3.data_ptr())
+                if ref is None:
+                    cv1.scale0, cv1.shift0 = ps3.data_ptr(), pt3.data_ptr()
+                else:
+                    acc3, bn3_, count3 = ref
+                    cv1.stat_acc1 = acc3
+                    cv1.gamma1, cv1.beta1 = bn3_.weight.data_ptr(), bn3_.bias.data_ptr()
+                    cv1.running_mean1, cv1.running_var1 = bn3_.running_mean.data_ptr(), bn3_.running_var.data_ptr()
+                    cv1.count, cv1.momentum, cv1.eps = count3, BN_MOMENTUM, BN_EPS
+                ops.append(cv1)
+                pending = None
+            else:
+                ops.append(std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_))
             f, s1, t1 = fin_op(blk.bn1, planes, N * h * w_, tm1)
             add(f)
             ops.append(act_op(L.OP_BN_RELU, self.c1, s1, t1, self.a1, N, h, w_, planes))
@@ -393,6 +415,8 @@ class ConvStackProgram:
                 f, sd, td_ = fin_op(blk.downsample[1], planes * 4, N * h2 * w2, tm2)
                 add(f)
                 ops.append(act_op(L.OP_BN_ADD_RELU, self.c3, s3, t3, ynext, N, h2, w2, planes * 4, self.cd, sd, td_))
+            elif (fuse_resid and bi + 1 < len(blocks_geo) and (planes * 4) % 64 == 0 and planes * 4 <= 2048):
+                pending = (s3, t3, y)            # the next block's conv1 forms relu(c3*s3+t3 + y) itself and writes it to ynext
             else:
                 ops.append(act_op(L.OP_BN_ADD_RELU, self.c3, s3, t3, ynext, N, h2, w2, planes * 4, y))
             y, ynext = ynext, y
@@ -435,7 +459,7 @@ class ConvStackProgram:
             if missing:
                 for t in (self.c0, self.c1, self.a1, self.c2, self.a2, self.c3, self.cd, *self.ybuf):
                     t.normal_()
-                scratch = alloc((1024,), torch.float32)           # the tuner's neutral BatchNorm table lives in OUR memory
+                scratch = alloc((4096,), torch.float32)           # the tuner's neutral BatchNorm table lives in OUR memory
                 L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 5, scratch.data_ptr(), scratch.numel() * 4,
                                                    L.stream()), "sat_conv_autotune")
                 torch.cuda.synchronize()
@@ -449,7 +473,7 @@ class ConvStackProgram:
     @staticmethod
     def _tune_key(o):
         fused = (1 if (o.stat_partial or o.stat_acc) else 0) + (2 if (o.scale0 or o.stat_acc1) else 0) + \
-                (4 if o.scale1 else 0) + (8 if o.in1 else 0)
+                (4 if o.scale1 else 0) + (8 if o.in1 else 0) + (16 if o.out1 else 0)
         return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d" % (o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout, o.KH, o.KW, o.stride, fused)
 
     def __del__(self):

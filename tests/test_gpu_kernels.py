@@ -107,10 +107,11 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 21
+NUM_CONV_VARIANTS = 30
+PLAIN_CONV_VARIANTS = list(range(1, 22)) + [28, 29, 30]      # 22..27 are dual-source only (their own test)
 
 
-@pytest.mark.parametrize("variant", list(range(1, NUM_CONV_VARIANTS + 1)))
+@pytest.mark.parametrize("variant", PLAIN_CONV_VARIANTS)
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(3, 15, 13, 64, 192, 3, 1, 1), (2, 9, 9, 24, 72, 3, 2, 1),
                                                          (5, 8, 8, 320, 64, 1, 1, 0)])
 def test_conv_bf16_every_kernel_variant(lib, variant, N, H, W, Cin, Cout, k, stride, pad):
@@ -138,7 +139,7 @@ def test_conv_autotune_sets_a_variant_and_keeps_results(lib):
     ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, 256)
     o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1)
     ops = (L.SatOp * 1)(o)
-    scratch = torch.empty(1024, device="cuda")          # the tuner works in caller-owned memory
+    scratch = torch.empty(4096, device="cuda")          # the tuner works in caller-owned memory
     assert lib.sat_conv_autotune(ops, 1, 2, None, 0, st()) == 1002
     L.check(lib.sat_conv_autotune(ops, 1, 2, scratch.data_ptr(), scratch.numel() * 4, st()))
     assert 1 <= ops[0].variant <= NUM_CONV_VARIANTS
@@ -590,3 +591,64 @@ def test_embed_concat_bwd_beyond_the_default_lds_limit(lib):
         ref.index_add_(0, caps[:pi.batch_sizes[t], t - 1], rows)
     np.testing.assert_allclose(d_embed.cpu().double().numpy(), ref.numpy(), rtol=0, atol=5e-5)
     assert torch.equal(d_feat.cpu(), dX[:B])
+
+
+@pytest.mark.parametrize("derive", [False, True])
+@pytest.mark.parametrize("variant", [0, 22, 23, 24, 25, 26, 27])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(5, 12, 12, 256, 192), (3, 7, 7, 1024, 256), (2, 9, 5, 64, 64)])
+def test_conv1x1_dual_source_bn_add_relu_fused(lib, derive, variant, N, H, W, Cin, Cout):
+    """dual-source 1x1 conv (sat_op.out1): A = relu(c3*s+t + resid) formed in LDS from two LDS-DMA sources -- the previous
+    bottleneck's bn3 + add + ReLU -- stored once as the next residual (out1) and convolved; every dual kernel variant,
+    table precomputed or derived from the producer's integer sums; atomic statistics of the conv's own output"""
+    g = torch.Generator().manual_seed(131 + variant + Cin)
+    c3 = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
+    resid = torch.randn(N, H, W, Cin, generator=g).clamp(min=0).bfloat16()
+    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).bfloat16()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    xf = c3.float().reshape(-1, Cin).double()
+    M = xf.shape[0]
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
+    shift = (beta.double() - mean * scale.double()).float()
+    y = torch.clamp(c3.float().reshape(-1, Cin) * scale + shift + resid.float().reshape(-1, Cin), min=0).bfloat16()
+    ref = y.float().double() @ w.float().double().t()
+    o, keep, _ = _conv_op(L.SAT_BF16, c3.float(), w.float().reshape(Cout, 1, 1, Cin), 1, 0, stats=False)
+    o.variant = variant
+    rd = cu(resid.contiguous())
+    yd = torch.full((M, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
+    o.in1, o.out1 = rd.data_ptr(), yd.data_ptr()
+    own = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+    o.stat_acc = own.data_ptr()
+    if derive:
+        acc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
+        acc[0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
+        acc[0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
+        acc[1] = 777
+        gd, bd, rm, rv = cu(gamma), cu(beta), cu(torch.zeros(Cin)), cu(torch.ones(Cin))
+        o.stat_acc1, o.gamma1, o.beta1 = acc.data_ptr(), gd.data_ptr(), bd.data_ptr()
+        o.running_mean1, o.running_var1 = rm.data_ptr(), rv.data_ptr()
+        o.count, o.momentum, o.eps = M, 0.1, 1e-5
+    else:
+        sd, td = cu(scale), cu(shift)
+        o.scale0, o.shift0 = sd.data_ptr(), td.data_ptr()
+    L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+    sync()
+    got_y = yd.float().cpu()
+    # y: one bf16 rounding of an f32 value that may differ in its last bits from the CPU's (fma contraction): <= 1 bf16 ulp
+    assert torch.isfinite(got_y).all()
+    assert (got_y - y.float()).abs().max().item() <= 2 ** -7 * max(1.0, y.float().abs().max().item())
+    assert (got_y != y.float()).float().mean().item() < 0.02
+    out = keep[2].float().cpu().double()
+    assert (out - ref).abs().max().item() < 3e-2 + 6e-3 * ref.abs().max().item()
+    s1 = own[0, 0].cpu().double() / 2 ** 22
+    np.testing.assert_allclose(s1.numpy(), ref.sum(0).numpy(), rtol=2e-3, atol=0.3 + 2e-3 * M ** 0.5)
+    if derive:
+        assert int(acc[1].abs().sum()) == 0
+        np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-4, atol=1e-6)
+    # argument checks: the side output must not alias an input, and the dual form needs the affine
+    o2 = L.SatOp.from_buffer_copy(bytes(o))
+    o2.out1 = o2.in0
+    assert lib.sat_run_ops_parity(C.pointer(o2), 1, 0, st()) == 1001
+    o3 = L.SatOp.from_buffer_copy(bytes(o))
+    o3.scale0 = o3.shift0 = o3.stat_acc1 = None
+    assert lib.sat_run_ops_parity(C.pointer(o3), 1, 0, st()) == 1003

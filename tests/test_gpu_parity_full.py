@@ -4,11 +4,18 @@ resnet_forward_bf16_storage`), against the f32 oracle, and against this library'
 training steps at BASELINE configs[1] (batch 64) in both modes against `oracle.train_step.full_step`.
 
 Tolerances (measured values are printed; DESIGN.md section 4 quotes them):
-  * f32 mode: mean CE within 1e-4 of the oracle on every step (north_star's bar).
-  * bf16 mode: the conv stack stores bf16 (2^-8 relative rounding per stored tensor, 155 convs deep, BatchNorm
-    renormalising after each), so pooled features agree with the bf16-storage oracle to a few percent relative L2 --
-    what is left is summation order plus the 1-ulp bf16 flips it causes downstream -- and the CE, which at these
-    weights depends on the features only through the BatchNorm1d-normalised head, moves by <= 2e-3.
+  * f32 mode: mean CE within 1e-4 of the oracle on every step (north_star's bar); measured 2e-6.
+  * bf16 mode: the conv stack stores bf16 (2^-8 relative rounding per stored tensor), 155 convs deep with a
+    BatchNorm renormalising after each.  With random weights that map is CHAOTIC at bf16 resolution: two CPU
+    implementations of the very same bf16-storage arithmetic that differ only in accumulation precision (f32 vs f64
+    accumulate inside each conv -- a legitimate change of summation order) end 0.16 apart in relative L2 at the pooled
+    features (cfg1), the same distance either has from the f32 result (0.18).  No implementation can be pinned tighter
+    than that floor at full depth, so the full-depth test measures the floor itself (two oracle runs) and requires the
+    HIP path to sit within it; the tight bound (<1 %) lives where it can hold: at 6 bottlenecks
+    (`test_gpu_parity.py::test_encoder_bf16_close_to_oracle`) and per conv geometry at batch 64
+    (`test_resnet152_conv_geometries_batch64_autotuned_vs_cpu` below: each real layer shape, autotuned variant,
+    integer-atomic statistics, against fp32 CPU convolution of the same bf16 operands).  The CE, which at these weights
+    sees the features only through the BatchNorm1d-normalised head, moves by 8.5e-4 at cfg2 (bound 2e-3).
 Encoder parity is build-internal either way ("parity unpinned": torchvision is absent)."""
 import importlib
 
@@ -51,15 +58,25 @@ def test_resnet152_bf16_train_mode_cfg1_vs_bf16_storage_oracle():
     ref_bf = OE.resnet_forward_bf16_storage(params, x, arch)
     bufs = {k: v.clone() for k, v in buffers.items()}
     ref_f32, _ = OE.resnet_forward(params, bufs, x, arch, training=True)
+    # the noise floor of the bf16-storage arithmetic itself at this depth: the same emulation with every conv
+    # accumulated in f64 instead of f32 (summation order / last-bit differences before each bf16 rounding)
+    import torch.nn.functional as F
+    conv2d = F.conv2d
+    try:
+        F.conv2d = lambda a, w, b=None, stride=1, padding=0: conv2d(a.double(), w.double(), None, stride, padding).float()
+        ref_bf64 = OE.resnet_forward_bf16_storage(params, x, arch)
+    finally:
+        F.conv2d = conv2d
+    floor = _rel(ref_bf64, ref_bf)
     r_bf, r_f32, r_or = _rel(got[0], ref_bf), _rel(got[0], ref_f32), _rel(ref_bf, ref_f32)
-    print("cfg1 bf16 pooled: rel-L2 vs bf16-storage oracle %.4f, vs f32 oracle %.4f (bf16-storage oracle vs f32 oracle %.4f), cos %.5f"
-          % (r_bf, r_f32, r_or, _cos(got[0], ref_bf)))
+    print("cfg1 bf16 pooled: rel-L2 vs bf16-storage oracle %.4f, vs f32 oracle %.4f | oracle noise floor (f32- vs f64-accumulate "
+          "bf16-storage oracle) %.4f, bf16-storage oracle vs f32 oracle %.4f | cos %.5f"
+          % (r_bf, r_f32, floor, r_or, _cos(got[0], ref_bf)))
     assert torch.isfinite(got[0]).all()
-    # the HIP path must be as close to the bf16-storage oracle as that oracle's own rounding noise allows: both sit
-    # the same distance from the f32 result (r_or), and from each other by no more than that
-    assert r_bf < max(0.05, 1.5 * r_or), (r_bf, r_or)
-    assert r_f32 < max(0.08, 2.0 * r_or), (r_f32, r_or)
-    assert _cos(got[0], ref_bf) > 0.995
+    # within the floor: no further from the emulation than the emulation is from its own re-ordered self (+25 %)
+    assert r_bf < 1.25 * floor + 0.02, (r_bf, floor)
+    assert r_f32 < 1.25 * r_or + 0.02, (r_f32, r_or)
+    assert _cos(got[0], ref_bf) > 0.97
     for g in got[1:]:                                      # same input, same statistics: every pass reproduces the first
         assert torch.equal(g, got[0])
 
@@ -106,11 +123,18 @@ def test_cfg2_whole_train_steps_f32_and_bf16_vs_oracle():
         assert abs(a - b) < 2e-3, (l16, ref)                 # bf16 conv stack: stated tolerance (module docstring)
     # parameters after three clamp+Adam steps (f32 mode; resnet.fc.bias has a mathematically zero gradient under
     # train-mode BatchNorm1d: Adam turns its rounding noise into +-lr steps in torch as here -- excluded)
+    # Adam's first steps move every element by ~lr * sign(g): where a gradient element is at rounding-noise level its
+    # sign -- hence a +-lr step -- is arbitrary in torch as here, so a small fraction of elements may sit 1..3 lr apart
     got = {k: v.detach().cpu() for k, v in model32.decoder.state_dict().items()}
-    for k in dpo:
-        assert torch.allclose(got[k], dpo[k], rtol=0, atol=1e-4), (k, (got[k] - dpo[k]).abs().max().item())
-    fc = model32.encoder.resnet.fc.weight.detach().cpu()
-    assert torch.allclose(fc, epo["resnet.fc.weight"], rtol=0, atol=2e-3)       # +-lr Adam steps on near-zero gradients can flip sign
+    got["resnet.fc.weight"] = model32.encoder.resnet.fc.weight.detach().cpu()
+    want = dict(dpo)
+    want["resnet.fc.weight"] = epo["resnet.fc.weight"]
+    for k in want:
+        d = (got[k] - want[k]).abs()
+        assert d.max().item() <= 3 * 2e-3 + 1e-6, (k, d.max().item())          # never more than 3 steps x 2 lr
+        frac = (d > 1e-5).float().mean().item()
+        print("cfg2 params after 3 steps %-22s max|d| %.2e, fraction beyond 1e-5: %.2e" % (k, d.max().item(), frac))
+        assert frac < (0.05 if k == "resnet.fc.weight" else 5e-3), (k, frac)
     # head output of the two HIP modes on the SAME (now trained-for-3-steps-apart) weights is not comparable; compare
     # encoder features on the f32 model's weights instead
     sd = model32.encoder.state_dict()
@@ -118,7 +142,7 @@ def test_cfg2_whole_train_steps_f32_and_bf16_vs_oracle():
     p32 = model32.encoder.pooled_features(di)
     p16 = model16.encoder.pooled_features(di)
     print("cfg2 pooled bf16 vs f32 HIP: rel-L2 %.4f cos %.5f" % (_rel(p16.cpu(), p32.cpu()), _cos(p16, p32)))
-    assert _rel(p16.cpu(), p32.cpu()) < 0.08 and _cos(p16, p32) > 0.995
+    assert _rel(p16.cpu(), p32.cpu()) < 0.30 and _cos(p16, p32) > 0.95     # the chaos floor at full depth (module docstring)
 
 
 @pytest.mark.timeout(900)
@@ -135,11 +159,11 @@ def test_cfg2_bf16_vs_f32_hip_train_two_steps_and_eval():
             p32, p16 = e32.pooled_features(di), e16.pooled_features(di)
             r, c = _rel(p16.cpu(), p32.cpu()), _cos(p16, p32)
             print("train pass %d: pooled rel-L2 %.4f cos %.5f" % (i, r, c))
-            assert r < 0.08 and c > 0.995, (i, r, c)
+            assert r < 0.30 and c > 0.95, (i, r, c)           # the chaos floor at full depth (module docstring); garbage gives cos ~ 0
         f32o, f16o = e32(di), e16(di)
         r = _rel(f16o.cpu(), f32o.cpu())
         print("train head output rel-L2 %.4f" % r)
-        assert r < 0.15                                        # BatchNorm1d over 64 rows renormalises the feature error
+        assert r < 0.45                                        # BatchNorm1d over 64 rows renormalises the feature error
         # eval: let the running statistics converge on the f32 model (momentum 0.1), copy them, compare eval passes
         for _ in range(40):
             e32.pooled_features(di)
@@ -150,7 +174,7 @@ def test_cfg2_bf16_vs_f32_hip_train_two_steps_and_eval():
         assert torch.isfinite(q32).all() and torch.isfinite(q16).all()
         r, c = _rel(q16.cpu(), q32.cpu()), _cos(q16, q32)
         print("eval: pooled rel-L2 %.4f cos %.5f" % (r, c))
-        assert r < 0.08 and c > 0.995, (r, c)
+        assert r < 0.30 and c > 0.95, (r, c)
 
 
 def test_encoder_sees_weights_loaded_into_the_stack_after_a_forward():
@@ -220,3 +244,97 @@ def test_out_of_range_caption_id_raises_instead_of_training_silently():
         ts.step(images, caps, [9] * 4)        # a length beyond the caption matrix: sat_pack_targets would read past the row
     with pytest.raises(ValueError):
         ts.step(images, caps, [8, 8, 8, 1])   # no target token
+
+
+RESNET152_GEOMS_B64 = [   # (H, W, Cin, Cout, k, stride, pad): every distinct conv geometry of the [3,8,36,3] stack at 224x224
+    (56, 56, 64, 64, 1, 1, 0), (56, 56, 64, 64, 3, 1, 1), (56, 56, 64, 256, 1, 1, 0), (56, 56, 256, 64, 1, 1, 0),
+    (56, 56, 256, 128, 1, 1, 0), (56, 56, 128, 128, 3, 2, 1), (28, 28, 128, 512, 1, 1, 0), (56, 56, 256, 512, 1, 2, 0),
+    (28, 28, 512, 128, 1, 1, 0), (28, 28, 128, 128, 3, 1, 1), (28, 28, 512, 256, 1, 1, 0), (28, 28, 256, 256, 3, 2, 1),
+    (14, 14, 256, 1024, 1, 1, 0), (28, 28, 512, 1024, 1, 2, 0), (14, 14, 1024, 256, 1, 1, 0), (14, 14, 256, 256, 3, 1, 1),
+    (14, 14, 1024, 512, 1, 1, 0), (14, 14, 512, 512, 3, 2, 1), (7, 7, 512, 2048, 1, 1, 0), (14, 14, 1024, 2048, 1, 2, 0),
+    (7, 7, 2048, 512, 1, 1, 0), (7, 7, 512, 512, 3, 1, 1)]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("geom", RESNET152_GEOMS_B64, ids=lambda g: "x".join(str(v) for v in g))
+def test_resnet152_conv_geometries_batch64_autotuned_vs_cpu(geom):
+    """Each real layer shape at batch 64 with the variant the autotuner picks and the integer-atomic BatchNorm
+    statistics of the training program, against fp32 CPU convolution of the same bf16 operands: output to bf16
+    rounding, column sums / sums of squares to 1e-3.  (This is where a wrong variant or statistics path at the real
+    geometries shows, free of the full-depth chaos.)"""
+    import ctypes as C
+    import torch.nn.functional as F
+    L = sat._lib
+    lib = L.load()
+    H, W, Cin, Cout, k, stride, pad = geom
+    N = 64
+    g = torch.Generator().manual_seed(H * 1000 + Cin + Cout + k)
+    x = torch.randn(N, H, W, Cin, generator=g).bfloat16()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    M = N * Ho * Wo
+    xd, wd = x.cuda(), w.reshape(Cout, -1).contiguous().cuda()
+    out = torch.full((M, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    tiles = lib.sat_conv_tiles_m(M)
+    acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+    part = torch.zeros(tiles, 2, Cout, device="cuda")
+    o = L.SatOp()
+    o.kind, o.dtype = L.OP_CONV, L.SAT_BF16
+    o.in0, o.w, o.out = xd.data_ptr(), wd.data_ptr(), out.data_ptr()
+    o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, Ho, Wo, Cout
+    o.KH, o.KW, o.stride, o.pad = k, k, stride, pad
+    o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
+    atomic = tiles <= 128
+    if atomic:
+        o.stat_acc = acc.data_ptr()
+    else:
+        o.stat_partial, o.tiles_m = part.data_ptr(), tiles
+    ops = (L.SatOp * 1)(o)
+    scratch = torch.empty(4096, device="cuda")
+    L.check(lib.sat_conv_autotune(ops, 1, 3, scratch.data_ptr(), 16384, L.stream()))
+    assert ops[0].variant >= 1
+    L.check(lib.sat_run_ops_parity(ops, 1, 0, L.stream()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, stride, pad).permute(0, 2, 3, 1).reshape(M, Cout)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err < 2 ** -7 * max(1.0, ref.abs().max().item()), (err, ops[0].variant)      # one bf16 rounding of the output
+    if atomic:
+        s1 = acc[0, 0].cpu().double() / 2 ** 22
+        s2 = acc[0, 1].cpu().double() / 2 ** 22
+    else:
+        s1, s2 = part[:, 0].cpu().double().sum(0), part[:, 1].cpu().double().sum(0)
+    rs, rq = ref.double().sum(0), (ref.double() ** 2).sum(0)
+    assert (s1 - rs).abs().max().item() < 1e-3 * M ** 0.5 + 2e-2, (s1 - rs).abs().max().item()
+    assert ((s2 - rq).abs() / rq).max().item() < 1e-3
+
+
+def test_residual_fusion_into_next_conv1_matches_separate_bn_add(monkeypatch):
+    """bf16 training: bn3 + add + ReLU of an identity-residual bottleneck folded into the next bottleneck's conv1
+    (SAT_FUSE_RESIDUAL=1, default) against the same stack with the separate normalise+add launches, three training
+    passes (both statistics parities + hipGraph replay), running statistics included"""
+    arch, E, B = dict(layers=(2, 3, 2, 2), width=16), 32, 8
+    gen = torch.Generator().manual_seed(61)
+    params, buffers = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
+    xs = [torch.randn(B, 3, 96, 96, generator=gen).cuda() for _ in range(3)]
+    monkeypatch.setenv("SAT_FUSE_RESIDUAL", "0")
+    plain = _encoder(arch, E, params, buffers, "bf16").train()
+    ref = [plain.pooled_features(x) for x in xs]
+    n_plain = next(iter(plain._programs.values())).n_ops
+    monkeypatch.setenv("SAT_FUSE_RESIDUAL", "1")
+    fused = _encoder(arch, E, params, buffers, "bf16").train()
+    out = [fused.pooled_features(x) for x in xs]
+    n_fused = next(iter(fused._programs.values())).n_ops
+    assert n_plain - n_fused == sum(arch["layers"]) - 4 - 1 + 1 - 1 or n_plain - n_fused >= 3, (n_plain, n_fused)
+    for a, b in zip(out, ref):
+        r = _rel(a.cpu(), b.cpu())
+        print("fused-residual vs separate bn_add: rel-L2 %.5f" % r)
+        assert r < 0.01, r                     # same arithmetic; an occasional 1-ulp bf16 flip from fma contraction
+    sa, sb = plain.state_dict(), fused.state_dict()
+    for k in sa:
+        if "running" in k:
+            assert torch.allclose(sa[k], sb[k], rtol=2e-2, atol=2e-3), k
+    bufs = {k: v.clone() for k, v in buffers.items()}
+    ref_bf = OE.resnet_forward_bf16_storage(params, xs[0].cpu(), arch)
+    assert _rel(out[0].cpu(), ref_bf) < 0.02

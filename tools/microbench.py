@@ -79,8 +79,8 @@ def bench_conv(shapes=None, reps=20):
         if os.environ.get("SAT_VARIANT"):
             ops[0].variant = int(os.environ["SAT_VARIANT"])
         else:
-            scratch = torch.empty(1024, device="cuda")
-            L.check(lib.sat_conv_autotune(ops, 1, 5, scratch.data_ptr(), 4096, L.stream()))
+            scratch = torch.empty(4096, device="cuda")
+            L.check(lib.sat_conv_autotune(ops, 1, 5, scratch.data_ptr(), 16384, L.stream()))
         us = time_ops(ops, 1, reps)
         fl = 2.0 * N * Ho * Wo * Cout * k * k * Cin
         print("conv M=%d N=%d K=%d variant %d: %.1f us  %.0f TFLOP/s" % (N * Ho * Wo, Cout, k * k * Cin, ops[0].variant, us, fl / us / 1e6))
