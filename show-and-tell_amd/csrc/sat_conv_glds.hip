@@ -116,7 +116,10 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     constexpr int BK = 64, NT = NW * 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES + (DUAL ? A_BYTES : 0);
     constexpr int R_OFF = A_BYTES + B_BYTES;               // DUAL: the residual source's half of a stage
-    constexpr int LW = SPEC ? NW / 2 : NW;                // waves that issue the LDS-DMA
+    // DUAL: waves 0..NW/2-1 issue ALL the LDS-DMA and own the counted vmcnt; waves NW/2.. issue the global stores of y --
+    // a wave's memory counter is in order, so a store acknowledgement (~1-2 us under load) must never sit in front of the
+    // prefetch a wave is waiting for.  Every wave transforms and computes.
+    constexpr int LW = (SPEC || DUAL) ? NW / 2 : NW;      // waves that issue the LDS-DMA
     constexpr int CW = SPEC ? NW / 2 : NW;                // waves that own accumulators
     // consumer wave grid: 4 waves: 2x2;  8 waves: 4(M)x2(N) for the 128x64 tile, 2(M)x4(N) otherwise
     constexpr int WGM = (CW == 4) ? 2 : ((BM == 128 && BN == 64) ? 4 : 2);
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_loader = SPEC ? (wave >= CW) : true;
+    const bool is_loader = SPEC ? (wave >= CW) : (DUAL ? wave < LW : true);
     const bool is_consumer = SPEC ? (wave < CW) : true;
-    const int lw = SPEC ? (is_loader ? wave - CW : 0) : wave;      // loader index
+    const int lw = SPEC ? (is_loader ? wave - CW : 0) : (DUAL ? (is_loader ? wave : 0) : wave);      // loader index
     const int cw = is_consumer ? wave : 0;                          // consumer index
     const int wm = cw / WGN, wn = cw % WGN;
     const int r = lane & 31, h = lane >> 5;
@@ -393,6 +396,56 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         asm volatile("" ::: "memory");
     };
 
+    // DUAL, software pipelined: the transform of stage kt+1 is split around the MFMAs of stage kt -- its LDS reads go out
+    // first, the arithmetic / LDS write / global store of y follow the matrix work -- so the only per-K-step barrier is
+    // the ring's own and a wave's VALU pass overlaps its SIMD partner's MFMAs
+    constexpr int NCH = DUAL ? BM * 8 / NT : 1;
+    bf16x8 dv[NCH], dz[NCH];
+    auto dual_load = [&](int buf) {
+        const char* sA = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int q = tid + j * NT;
+            const int row = q >> 3, pos = q & 7;
+            dv[j] = *(const bf16x8*)(sA + row * 128 + pos * 16);
+            dz[j] = *(const bf16x8*)(sA + R_OFF + row * 128 + pos * 16);
+        }
+    };
+    auto dual_finish = [&](int buf, int kt) {
+        char* sA = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int q = tid + j * NT;
+            const int row = q >> 3, pos = q & 7;
+            if (m0 + row < p.M) {
+                const int c0 = kt * BK + ((pos ^ ((row >> 1) & 7)) << 3);
+                const f32x4 s0 = *(const f32x4*)(in_tab + c0), s1 = *(const f32x4*)(in_tab + c0 + 4);
+                const f32x4 t0 = *(const f32x4*)(in_tab + p.Cin + c0), t1 = *(const f32x4*)(in_tab + p.Cin + c0 + 4);
+                bf16x8 v = dv[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e] + (float)dz[j][e], 0.0f);
+                    v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e] + (float)dz[j][e + 4], 0.0f);
+                }
+                *(bf16x8*)(sA + row * 128 + pos * 16) = v;
+            }
+        }
+    };
+    // y (the next block's residual) leaves through the store waves: they re-read the finished A half of the stage
+    auto dual_store_y = [&](int buf, int kt) {
+        const char* sA = smem + buf * STAGE;
+        constexpr int NSW = NT - LW * 64;                  // threads in the store waves
+#pragma unroll
+        for (int j = 0; j < BM * 8 / NSW; ++j) {
+            const int q = (tid - LW * 64) + j * NSW;
+            const int row = q >> 3, pos = q & 7;
+            if (m0 + row < p.M) {
+                const int c0 = kt * BK + ((pos ^ ((row >> 1) & 7)) << 3);
+                *(u32x4*)(p.Y + (long)(m0 + row) * p.ldy + c0) = *(const u32x4*)(sA + row * 128 + pos * 16);
+            }
+        }
+    };
+
     auto compute = [&](int buf) {
         const char* st = smem + buf * STAGE;
 #pragma unroll
@@ -470,6 +523,35 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 }
                 buf = (buf + 1 == S) ? 0 : buf + 1;
             }
+        }
+    } else if constexpr (DUAL) {
+        static_assert(S >= 3, "the pipelined dual transform needs a landed stage ahead of the one being computed");
+        constexpr int WAITD = LPW * (D - 2);     // pieces that may still be in flight once stage kt+1 must have landed
+        if (is_loader) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) issue(s);
+            wait_vmcnt<LPW*(D - 1)>();           // stage 0 (mine) ...
+        }
+        __builtin_amdgcn_s_barrier();            // ... and everybody's
+        asm volatile("" ::: "memory");
+        dual_load(0);
+        dual_finish(0, 0);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my transform writes of stage kt (and LDS reads) are done
+            if (is_loader) wait_vmcnt<WAITD>();                    // my pieces of stage kt+1 have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int nbuf = buf + D;
+            if (nbuf >= S) nbuf -= S;
+            if (is_loader) issue(nbuf);                            // stage kt+D -> the slot stage kt-1 occupied
+            const int tbuf = (buf + 1 == S) ? 0 : buf + 1;
+            const bool more = kt + 1 < nk;
+            if (more) dual_load(tbuf);
+            if (!is_loader && tile_n == 0) dual_store_y(buf, kt);  // stage kt is final: y goes out under the MFMAs
+            if (!(p.dbg & 2)) compute(buf);
+            if (more) dual_finish(tbuf, kt + 1);
+            buf = tbuf;
         }
     } else {
 #pragma unroll
@@ -632,9 +714,10 @@ constexpr Variant kVariants[] = {
     {128, 4, 8, 1, 0, 128, 0}, {128, 3, 8, 1, 0, 128, 0}, {128, 2, 8, 1, 0, 128, 0}, {64, 4, 8, 1, 0, 128, 0}, {64, 3, 8, 1, 0, 128, 0},   // 4 consumer + 4 loader waves
     {128, 4, 8, 1, 1, 128, 0}, {128, 4, 8, 0, 1, 128, 0}, {128, 4, 4, 0, 1, 128, 0}, {64, 4, 8, 1, 1, 128, 0}, {64, 4, 8, 0, 1, 128, 0},
     {64, 4, 4, 0, 1, 128, 0},                                                                                                       // fragment prefetch
-    {256, 2, 8, 0, 0, 64, 1}, {256, 3, 8, 0, 0, 64, 1}, {128, 2, 8, 0, 0, 128, 1}, {128, 3, 8, 0, 0, 128, 1}, {128, 3, 8, 0, 0, 64, 1},
+    {256, 3, 8, 0, 0, 64, 1}, {256, 3, 8, 0, 0, 64, 1}, {128, 3, 8, 0, 0, 128, 1}, {128, 3, 8, 0, 0, 128, 1}, {128, 3, 8, 0, 0, 64, 1},
     {128, 4, 8, 0, 0, 64, 1},                                                                                                       // dual-source A (bn3 + add + ReLU of the previous block)
     {256, 2, 8, 0, 0, 128, 0}, {256, 3, 8, 0, 0, 128, 0}, {256, 3, 8, 0, 0, 64, 0},                                                   // wide tiles
+    {128, 3, 8, 0, 0, 64, 0}, {128, 2, 8, 0, 0, 64, 0},                                                                             // 64-row tiles: 2 workgroups per CU on the N = 256 layers
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -661,15 +744,17 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 18: return launch_glds<64, 4, 8, true, true>(a, s);
         case 19: return launch_glds<64, 4, 8, false, true>(a, s);
         case 20: return launch_glds<64, 4, 4, false, true>(a, s);
-        case 21: return launch_glds<256, 2, 8, false, false, 64, true>(a, s);
+        case 21: return launch_glds<256, 3, 8, false, false, 64, true>(a, s);
         case 22: return launch_glds<256, 3, 8, false, false, 64, true>(a, s);
-        case 23: return launch_glds<128, 2, 8, false, false, 128, true>(a, s);
+        case 23: return launch_glds<128, 3, 8, false, false, 128, true>(a, s);
         case 24: return launch_glds<128, 3, 8, false, false, 128, true>(a, s);
         case 25: return launch_glds<128, 3, 8, false, false, 64, true>(a, s);
         case 26: return launch_glds<128, 4, 8, false, false, 64, true>(a, s);
         case 27: return launch_glds<256, 2, 8, false, false, 128>(a, s);
         case 28: return launch_glds<256, 3, 8, false, false, 128>(a, s);
         case 29: return launch_glds<256, 3, 8, false, false, 64>(a, s);
+        case 30: return launch_glds<128, 3, 8, false, false, 64>(a, s);
+        case 31: return launch_glds<128, 2, 8, false, false, 64>(a, s);
         default: return SAT_ERR_ARG;
     }
 }

@@ -343,8 +343,11 @@ class ConvStackProgram:
         ops.append(mp)
         # bn3 + residual add + ReLU of an identity-residual bottleneck folded into the NEXT bottleneck's conv1 (bf16
         # training): that conv forms y = relu(c3*s3+t3 + y_prev) in LDS from two LDS-DMA sources and stores y once as
-        # the next residual -- 45 of the 50 normalise+add launches of ResNet-152 and one re-read of y disappear
-        fuse_resid = training and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_RESIDUAL", "1") != "0"
+        # the next residual -- 45 of the 50 normalise+add launches of ResNet-152 and one re-read of y disappear.
+        # OPT-IN (SAT_FUSE_RESIDUAL=1): measured at cfg 2 it is a wash (6.83 vs 6.81 ms/step): the 77 MB the
+        # separate kernel streams at 5.5 TB/s from 2048 workgroups then has to come through 196 workgroups' LDS rings
+        # (2.6 TB/s: bytes in flight per CU), which costs the conv what the removed launch saved.
+        fuse_resid = training and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_RESIDUAL", "0") == "1"
         pending = None          # (s3, t3, resid buffer) of the previous block when its bn_add is deferred to this conv1
         blocks_geo = list(zip(stack.blocks(), geo))
         for bi, (blk, (h, w_, h2, w2, inpl, planes, stride)) in enumerate(blocks_geo):

@@ -107,8 +107,8 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 30
-PLAIN_CONV_VARIANTS = list(range(1, 22)) + [28, 29, 30]      # 22..27 are dual-source only (their own test)
+NUM_CONV_VARIANTS = 32
+PLAIN_CONV_VARIANTS = list(range(1, 22)) + [28, 29, 30, 31, 32]      # 22..27 are dual-source only (their own test)
 
 
 @pytest.mark.parametrize("variant", PLAIN_CONV_VARIANTS)
@@ -652,3 +652,4 @@ def test_conv1x1_dual_source_bn_add_relu_fused(lib, derive, variant, N, H, W, Ci
     o3 = L.SatOp.from_buffer_copy(bytes(o))
     o3.scale0 = o3.shift0 = o3.stat_acc1 = None
     assert lib.sat_run_ops_parity(C.pointer(o3), 1, 0, st()) == 1003
+

@@ -312,7 +312,7 @@ def test_resnet152_conv_geometries_batch64_autotuned_vs_cpu(geom):
 
 def test_residual_fusion_into_next_conv1_matches_separate_bn_add(monkeypatch):
     """bf16 training: bn3 + add + ReLU of an identity-residual bottleneck folded into the next bottleneck's conv1
-    (SAT_FUSE_RESIDUAL=1, default) against the same stack with the separate normalise+add launches, three training
+    (SAT_FUSE_RESIDUAL=1, opt-in) against the same stack with the separate normalise+add launches, three training
     passes (both statistics parities + hipGraph replay), running statistics included"""
     arch, E, B = dict(layers=(2, 3, 2, 2), width=16), 32, 8
     gen = torch.Generator().manual_seed(61)

@@ -1,10 +1,13 @@
 #!/bin/bash
-# helper for gpurun: A/B one environment variable on the same box.  usage: run_gpu_ab.sh VAR v1 v2 ...
-var=$1; shift
-mkdir -p gpurun_out
-for v in "$@"; do
-  for rep in 1 2; do
-    r=$(env $var=$v timeout -k 10 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")
-    echo "$var=$v run$rep: $r"
-  done
+# helper for gpurun: A/B one environment switch on the bench (no CPU baseline, no f32 leg): `bash tools/run_gpu_ab.sh VAR`
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd $R; mkdir -p gpurun_out
+V=${1:-SAT_FUSE_RESIDUAL}
+for val in 0 1; do
+  env $V=$val timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-f32-mode > gpurun_out/ab_$val.json 2> gpurun_out/ab_$val.err || { echo "bench failed ($V=$val)"; tail -n 20 gpurun_out/ab_$val.err; exit 1; }
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/ab_$val.json"))
+print("$V=$val", d["value"], "img/s", d["ms_per_step"], "ms/step; conv", d["roofline"]["ms_per_step_in_kernel"], "ms", d["roofline"]["frac"])
+PY
 done
