@@ -197,7 +197,11 @@ int sat_pack_targets(const int64_t* captions /*[B][cap_stride]*/, int64_t cap_st
 int sat_lstm_fwd(const float* X /*[N,In]*/, const float* w_ih /*[4H,In]*/, const float* w_hh /*[4H,H]*/,
                  const float* b_ih, const float* b_hh, const int32_t* batch_sizes /*[T] host*/, int T,
                  int In, int H, float* GA, float* CS, float* HS, float* HP, float* c_state,
-                 sat_stream_t stream);
+                 void* workspace, int64_t ws_bytes, sat_stream_t stream);
+/* workspace of the persistent recurrence (hidden-state exchange granules + an error word).  With it (and H in
+ * {32,64,96,128,256,512}, T <= 64, ceil(B/8) * H/16 <= CUs) all T steps run in ONE launch with W_hh register-resident;
+ * workspace NULL / too small, or a shape outside that envelope, falls back to one launch per step (same results). */
+int64_t sat_lstm_fwd_ws_bytes(int B, int H);
 int64_t sat_lstm_bwd_ws_bytes(int B, int H);          /* minimum */
 /* size that also lets the batched dW_ih / dX GEMMs run split-K when they would leave most CUs idle (N = packed rows) */
 int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H);

@@ -65,7 +65,8 @@ SIGNATURES = {
     "sat_embed_concat_fwd": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sat_embed_concat_bwd": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sat_pack_targets": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
-    "sat_lstm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sat_lstm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sat_lstm_fwd_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_bwd_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_bwd_ws_bytes_full": (_i64, [_i, _i, _i, _i]),
     "sat_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i,

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     // y (the next block's residual) leaves through the store waves: they re-read the finished A half of the stage
     auto dual_store_y = [&](int buf, int kt) {
         const char* sA = smem + buf * STAGE;
-        constexpr int NSW = NT - LW * 64;                  // threads in the store waves
+        constexpr int NSW = DUAL ? NT - LW * 64 : NT;      // threads in the store waves
 #pragma unroll
         for (int j = 0; j < BM * 8 / NSW; ++j) {
             const int q = (tid - LW * 64) + j * NSW;

@@ -4,6 +4,7 @@
 // so a whole training step can be captured into one hipGraph by the caller.
 #include "sat_internal.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 extern "C" int sat_version(void) { return SAT_ABI_VERSION; }
 
@@ -184,9 +185,24 @@ extern "C" int sat_fc_bn1d_bwd(const float* dy, const float* pooled, const float
 
 // ------------------------------------------------------------------------------------------------------
 // LSTM layer over a packed batch
+bool sat_lstm_persist_ok(int B, int H, int T, int n_cu);          // sat_lstm_persist.hip
+int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, float* HP, const int32_t* batch_sizes, int T,
+                            int H, void* workspace, int64_t ws_bytes, hipStream_t s);
+
+static int device_cu_count() {
+    static int n = -1;
+    if (n < 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n = v;
+        else n = 0;
+    }
+    return n;
+}
+
 extern "C" int sat_lstm_fwd(const float* X, const float* w_ih, const float* w_hh, const float* b_ih,
                             const float* b_hh, const int32_t* batch_sizes, int T, int In, int H, float* GA,
-                            float* CS, float* HS, float* HP, float* c_state, sat_stream_t stream) {
+                            float* CS, float* HS, float* HP, float* c_state, void* workspace, int64_t ws_bytes,
+                            sat_stream_t stream) {
     if (!X || !w_ih || !w_hh || !b_ih || !b_hh || !batch_sizes || !GA || !CS || !HS || !HP || !c_state || T < 1)
         return SAT_ERR_ARG;
     if ((In & 3) || (H & 3)) return SAT_ERR_UNSUPPORTED;
@@ -199,9 +215,14 @@ extern "C" int sat_lstm_fwd(const float* X, const float* w_ih, const float* w_hh
     }
     // x-gates for every packed row in one batched MFMA GEMM: GA = X * W_ih^T + b_ih + b_hh
     SAT_TRY(sat_gemm_f32(0, 0, X, In, w_ih, In, GA, 4L * H, b_ih, b_hh, (int)N, 4 * H, In, stream));
-    hipError_t e = hipMemsetAsync(c_state, 0, (size_t)B * H * sizeof(float), s);
+    hipError_t e = hipMemsetAsync(HP, 0, (size_t)B * H * sizeof(float), s);   // h_{-1} = 0 for the rows of step 0
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(HP, 0, (size_t)B * H * sizeof(float), s);   // h_{-1} = 0 for the rows of step 0
+    // the recurrence: ONE persistent launch (W_hh in registers, per-group hidden-state exchange) when every workgroup
+    // can be resident and the caller brought the exchange workspace; otherwise one launch per step
+    static const int persist_env = getenv("SAT_LSTM_PERSIST") ? atoi(getenv("SAT_LSTM_PERSIST")) : 1;
+    if (persist_env && workspace && ws_bytes >= sat_lstm_fwd_ws_bytes(B, H) && sat_lstm_persist_ok(B, H, T, device_cu_count()))
+        return sat_lstm_persist_launch(GA, w_hh, CS, HS, HP, batch_sizes, T, H, workspace, ws_bytes, s);
+    e = hipMemsetAsync(c_state, 0, (size_t)B * H * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
     long off = 0;
     for (int t = 0; t < T; ++t) {

@@ -1,0 +1,239 @@
+// Persistent LSTM recurrence (models.py:52 `self.lstm(packed)`, the serial part): ALL time steps of one layer in ONE
+// launch, W_hh resident in registers, the per-step hidden-state exchange through data-tagged granules.
+//
+// The recurrence h_t = f(x-gates_t + h_{t-1} W_hh^T) is independent per batch row, and its weight matrix is the
+// same every step.  So the batch is cut into GROUPS of 8 rows and the 4H gate columns of one group are cut over
+// MEMBER workgroups of 16 hidden units (64 gate columns) each:
+//   * a member loads its W_hh slice [64 columns x H] ONCE into registers in MFMA B-operand layout (128 VGPRs at
+//     H = 512) -- the per-step kernels re-read 4 MB of weights from L2 every step;
+//   * per step it needs only its group's h_{t-1} (8 rows x H, 16 KB), not the whole batch: each member publishes its
+//     8 x 16 slice as 8-byte {step tag, value} granules (one relaxed agent-scope = write-through store per value: the
+//     data IS the flag, no fence, no counter -- cdna_hip_programming.md Guideline 16, R2) and sweeps the other
+//     members' granules with agent-scope loads until every tag shows the step; two parity buffers, since a member
+//     can run at most one step ahead of the slowest member of its group;
+//   * groups never talk to each other: there is no grid-wide barrier, and a group whose rows have all ended
+//     (packed sequences: batch_sizes[t] shrinks) simply leaves;
+//   * gates = v_mfma_f32_16x16x4_f32 (exact f32: same K permutation on both operands), gate math fused, c_t in a
+//     register for the whole sequence; tapes (activated gates, c, h, h_prev) are written for the backward.
+// Every spin is bounded: on a timeout the kernel raises a sticky error word and every workgroup drains.
+//
+// Needs groups * members <= CUs (all workgroups co-resident); the host falls back to one launch per step otherwise.
+#include "sat_internal.h"
+#include <hip/hip_ext.h>
+
+namespace {
+
+constexpr int kMaxT = 64;
+constexpr int kRows = 8;          // batch rows per group
+constexpr int kUnits = 16;        // hidden units per member workgroup (4 waves x 4 units)
+constexpr unsigned kSpinLimit = 1u << 22;
+
+struct PersistArgs {
+    float* GA;            // [N][4H] in: x-gates (+ both biases); out: activated gates i,f,g,o
+    const float* W;       // [4H][H]
+    float* CS;            // [N][H]
+    float* HS;            // [N][H]
+    float* HP;            // [N][H]  (rows of step 0 pre-zeroed by the host)
+    unsigned long long* xch;   // [2 parities][groups][members][8 rows][16 units] granules, zeroed per call
+    unsigned* err;        // sticky timeout word (zeroed per call)
+    int H, T, B, members;
+    int prefix[kMaxT + 1];
+};
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int NKB>      // H = 16 * NKB, NKB even
+__global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) {
+    constexpr int H = 16 * NKB;
+    constexpr int HROW = H + 4;                       // LDS row stride in floats: rows land 16 B apart in the bank row
+    __shared__ __attribute__((aligned(16))) float h_lds[kRows * HROW];
+    __shared__ __attribute__((aligned(16))) float c_lds[4][kRows][16];
+    __shared__ int s_abort;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = blockIdx.x / p.members, member = blockIdx.x - group * p.members;
+    const int row0 = group * kRows;                   // first batch row of this group
+    const int n16 = lane & 15, kg = lane >> 4;
+    const int u0 = member * kUnits + wave * 4;        // this wave's 4 hidden units
+    const long wrow = (long)(n16 >> 2) * H + u0 + (n16 & 3);     // weight row feeding MFMA column n16: gate n16>>2, unit n16&3
+
+    // ---- W_hh slice -> registers, once: lane (n16, kg) holds W[wrow][16 kb + 4 kg .. +3] ----
+    f32x4 wreg[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) wreg[kb] = *(const f32x4*)(p.W + wrow * H + kb * 16 + kg * 4);
+
+    for (int i = tid; i < kRows * HROW; i += 256) h_lds[i] = 0.0f;      // h_{-1} = 0
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+
+    // epilogue ownership: lanes 0..31 of each wave own (row = lane>>2, unit = u0 + (lane&3)); c lives in a register
+    const int erow = lane >> 2, eu = u0 + (lane & 3);
+    float c_reg = 0.0f;
+    gu64* xch = (gu64*)p.xch;
+    const long slab = (long)p.members * kRows * kUnits;                  // granules per (parity, group)
+    const int groups = gridDim.x / p.members;
+
+    for (int t = 0; t < p.T; ++t) {
+        const int bs = p.prefix[t + 1] - p.prefix[t];
+        const int active = bs - row0;                                     // rows of this group still running
+        if (active <= 0) break;                                           // batch_sizes never grow: nothing left for this group
+        const int bs_next = (t + 1 < p.T) ? p.prefix[t + 2] - p.prefix[t + 1] : 0;
+
+        // ---- h_{t-1} of my group: sweep every member's granules of step t-1 (tag = t) ----
+        if (t > 0) {
+            const gu64* src = xch + ((long)((t - 1) & 1) * groups + group) * slab;
+            const int n = (int)slab;                                      // members * 128 granules
+            unsigned spins = 0;
+            bool fail = false;
+            for (;;) {
+                bool ok = true;
+                // 16 granules per lane in flight per round trip (a load that is tested at once would serialise 16 L2 trips)
+                for (int base = 0; base < n; base += 256 * 16) {
+                    unsigned long long x[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int i = base + tid + k * 256;
+                        x[k] = i < n ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : ((unsigned long long)(unsigned)t << 32);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int i = base + tid + k * 256;
+                        if ((unsigned)(x[k] >> 32) == (unsigned)t) {
+                            if (i < n) {
+                                const int mem = i >> 7, r = (i >> 4) & 7, u = i & 15;
+                                h_lds[r * HROW + mem * kUnits + u] = __uint_as_float((unsigned)x[k]);
+                            }
+                        } else {
+                            ok = false;
+                        }
+                    }
+                }
+                if (__syncthreads_and(ok ? 1 : 0)) break;
+                if ((++spins & 63u) == 0) {            // every 64 sweeps: bounded spin + another workgroup's verdict
+                    if (tid == 0 && (spins > kSpinLimit ||
+                                     __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
+                        s_abort = 1;
+                    __syncthreads();
+                    if (s_abort) { fail = true; break; }
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (fail) {
+                if (tid == 0) __hip_atomic_store((gu32*)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+
+        // ---- the epilogue's own operands, fetched under the MFMAs: x-gates of (row, unit) ----
+        float xg[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool own = lane < 32 && erow < active;
+        const long prow = (long)p.prefix[t] + row0 + erow;               // packed row of (t, batch row)
+        if (own) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xg[g] = p.GA[prow * 4 * H + (long)g * H + eu];
+        }
+
+        // ---- gates += h_{t-1} W_hh^T : 16 rows (8 real) x 16 columns per wave, K = H ----
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const bool arow = n16 < kRows;                                    // rows 8..15 of the MFMA tile are padding
+        const float* hsrc = h_lds + n16 * HROW + kg * 4;
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb += 2) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            if (arow) {
+                a0 = *(const f32x4*)(hsrc + kb * 16);
+                a1 = *(const f32x4*)(hsrc + kb * 16 + 16);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], wreg[kb][e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], wreg[kb + 1][e], acc1, 0, 0, 0);
+            }
+        }
+        // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg -> rows 0..7 sit in lanes with kg < 2
+        if (kg < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c_lds[wave][kg * 4 + e][n16] = acc0[e] + acc1[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // wave-local hand-off through LDS
+        __builtin_amdgcn_wave_barrier();
+
+        if (lane < 32) {
+            float g4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) g4[g] = c_lds[wave][erow][g * 4 + (lane & 3)] + xg[g];
+            const float gi = sigm(g4[0]), gf = sigm(g4[1]), gg = tanhf(g4[2]), go = sigm(g4[3]);
+            const float c_new = gf * c_reg + gi * gg;
+            const float h_new = go * tanhf(c_new);
+            c_reg = c_new;
+            if (own) {
+                float* ga = p.GA + prow * 4 * H;
+                ga[eu] = gi; ga[H + eu] = gf; ga[2 * H + eu] = gg; ga[3 * H + eu] = go;
+                p.CS[prow * H + eu] = c_new;
+                p.HS[prow * H + eu] = h_new;
+                if (row0 + erow < bs_next) p.HP[((long)p.prefix[t + 1] + row0 + erow) * H + eu] = h_new;
+            }
+            // publish h_t of (row, unit) for the group: tag = t + 1 (never 0), parity t & 1
+            if (t + 1 < p.T) {
+                gu64* dst = xch + ((long)(t & 1) * groups + group) * slab +
+                            ((long)member * kRows + erow) * kUnits + wave * 4 + (lane & 3);
+                __hip_atomic_store(dst, ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(h_new),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();         // c_lds / h_lds are rewritten by the next step
+    }
+}
+
+}  // namespace
+
+bool sat_lstm_persist_has(int H);
+
+// workspace: the granule exchange (2 parities) + the error word, in one block that is zeroed per call
+extern "C" int64_t sat_lstm_fwd_ws_bytes(int B, int H) {
+    if (H < 16 || (H % 16)) return 0;
+    const int64_t groups = (B + kRows - 1) / kRows, members = H / kUnits;
+    return 2 * groups * members * kRows * kUnits * 8 + 64;
+}
+
+// can the persistent kernel run this layer?  (all workgroups must be co-resident: one per CU)
+bool sat_lstm_persist_ok(int B, int H, int T, int n_cu) {
+    if (!sat_lstm_persist_has(H) || T > kMaxT || T < 1) return false;
+    const int groups = (B + kRows - 1) / kRows, members = H / kUnits;
+    return groups * members <= n_cu;
+}
+
+int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, float* HP, const int32_t* batch_sizes, int T,
+                            int H, void* workspace, int64_t ws_bytes, hipStream_t s) {
+    const int B = batch_sizes[0];
+    const int groups = (B + kRows - 1) / kRows, members = H / kUnits;
+    const int64_t need = sat_lstm_fwd_ws_bytes(B, H);
+    if (!workspace || ws_bytes < need) return SAT_ERR_WORKSPACE;
+    PersistArgs a = {};
+    a.GA = GA; a.W = W; a.CS = CS; a.HS = HS; a.HP = HP;
+    a.xch = (unsigned long long*)workspace;
+    a.err = (unsigned*)((char*)workspace + (need - 64));
+    a.H = H; a.T = T; a.B = B; a.members = members;
+    a.prefix[0] = 0;
+    for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)need, s);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid(groups * members), block(256);
+    switch (H / 16) {
+#define SAT_PERSIST_CASE(n) case n: hipLaunchKernelGGL((lstm_persist_kernel<n>), grid, block, 0, s, a); break;
+        SAT_PERSIST_CASE(2) SAT_PERSIST_CASE(4) SAT_PERSIST_CASE(6) SAT_PERSIST_CASE(8) SAT_PERSIST_CASE(16) SAT_PERSIST_CASE(32)
+#undef SAT_PERSIST_CASE
+        default: return SAT_ERR_UNSUPPORTED;
+    }
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+bool sat_lstm_persist_has(int H) {
+    switch (H / 16) { case 2: case 4: case 6: case 8: case 16: case 32: return (H % 16) == 0; default: return false; }
+}

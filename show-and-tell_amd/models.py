@@ -258,8 +258,10 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
         HS = torch.empty(N, H, device=dev)
         HP = torch.empty(N, H, device=dev)
         cst = torch.empty(B, H, device=dev)
+        wsb = lib.sat_lstm_fwd_ws_bytes(B, H)            # hidden-state exchange of the persistent recurrence
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         L.check(lib.sat_lstm_fwd(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), pi.bs_c, T, In, H,
-                                 L.ptr(GA), L.ptr(CS), L.ptr(HS), L.ptr(HP), L.ptr(cst), st), "sat_lstm_fwd")
+                                 L.ptr(GA), L.ptr(CS), L.ptr(HS), L.ptr(HP), L.ptr(cst), L.ptr(ws), wsb, st), "sat_lstm_fwd")
         tapes["layers"].append((GA, CS, HP))
         tapes["X"].append(HS)
         inp = HS

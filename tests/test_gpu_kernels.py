@@ -653,3 +653,53 @@ def test_conv1x1_dual_source_bn_add_relu_fused(lib, derive, variant, N, H, W, Ci
     o3.scale0 = o3.shift0 = o3.stat_acc1 = None
     assert lib.sat_run_ops_parity(C.pointer(o3), 1, 0, st()) == 1003
 
+
+
+@pytest.mark.parametrize("B,T,In,H,ragged", [(64, 19, 256, 512, False), (64, 19, 64, 512, True), (13, 7, 32, 64, True),
+                                             (8, 5, 32, 32, False), (40, 12, 96, 256, True), (3, 9, 32, 128, True)])
+def test_lstm_fwd_persistent_equals_per_step_launches(lib, B, T, In, H, ragged, monkeypatch):
+    """sat_lstm_fwd with the exchange workspace (ONE persistent launch: W_hh in registers, granule hand-off per group)
+    against the same entry point without it (one launch per step): every tape bit-identical (same MFMA, same K order per
+    output element is NOT guaranteed -- the per-step kernel splits K over 8 waves -- so: 1e-6), and against fp64"""
+    g = torch.Generator().manual_seed(B * 7 + T + H)
+    lengths = sorted([int(x) for x in torch.randint(1, T + 1, (B,), generator=g)], reverse=True) if ragged else [T] * B
+    lengths[0] = T
+    pi = sat.PackInfo.get(lengths, "cuda")
+    N = pi.N
+    k = 1.0 / H ** 0.5
+    X = torch.randn(N, In, generator=g)
+    w_ih = torch.empty(4 * H, In).uniform_(-k, k, generator=g)
+    w_hh = torch.empty(4 * H, H).uniform_(-k, k, generator=g)
+    b_ih = torch.empty(4 * H).uniform_(-k, k, generator=g)
+    b_hh = torch.empty(4 * H).uniform_(-k, k, generator=g)
+    d = [cu(t) for t in (X, w_ih, w_hh, b_ih, b_hh)]
+
+    def run(with_ws):
+        GA, CS = torch.full((N, 4 * H), float("nan"), device="cuda"), torch.full((N, H), float("nan"), device="cuda")
+        HS, HP = torch.full((N, H), float("nan"), device="cuda"), torch.full((N, H), float("nan"), device="cuda")
+        cst = torch.empty(B, H, device="cuda")
+        wsb = lib.sat_lstm_fwd_ws_bytes(B, H) if with_ws else 0
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+        L.check(lib.sat_lstm_fwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), pi.bs_c, pi.T, In, H,
+                                 GA.data_ptr(), CS.data_ptr(), HS.data_ptr(), HP.data_ptr(), cst.data_ptr(),
+                                 ws.data_ptr() if with_ws else None, wsb, st()))
+        sync()
+        err = int(ws[wsb - 64:wsb - 60].view(torch.int32).item()) if with_ws and wsb else 0
+        return GA.cpu(), CS.cpu(), HS.cpu(), HP.cpu(), err
+
+    assert lib.sat_lstm_fwd_ws_bytes(B, H) > 0
+    pers = run(True)
+    step = run(False)
+    assert pers[4] == 0, "persistent recurrence timed out"
+    for a, b, name in zip(pers[:4], step[:4], ("GA", "CS", "HS", "HP")):
+        assert torch.isfinite(a).all(), name
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=2e-6, err_msg=name)
+    # fp64 reference of the recurrence
+    Xg = X.double() @ w_ih.double().t() + b_ih.double() + b_hh.double()
+    h, c = torch.zeros(B, H, dtype=torch.float64), torch.zeros(B, H, dtype=torch.float64)
+    for t, n in enumerate(pi.batch_sizes):
+        gts = Xg[pi.prefix[t]:pi.prefix[t] + n] + h[:n] @ w_hh.double().t()
+        i, f, gg, o = gts[:, :H].sigmoid(), gts[:, H:2 * H].sigmoid(), gts[:, 2 * H:3 * H].tanh(), gts[:, 3 * H:].sigmoid()
+        c = torch.cat([f * c[:n] + i * gg, c[n:]])
+        h = torch.cat([o * c[:n].tanh(), h[n:]])
+        np.testing.assert_allclose(pers[2][pi.prefix[t]:pi.prefix[t] + n].double().numpy(), h[:n].numpy(), rtol=0, atol=5e-6)
