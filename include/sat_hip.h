@@ -51,7 +51,8 @@ int sat_gemm_f32(int amode, int bmode, const float* A, int64_t lda, const float*
  * as an array of sat_op and one call launches all of it.  Activations are NHWC, dtype f32 or bf16.
  */
 enum {
-    SAT_OP_IMAGE_PREP = 1, /* NCHW f32 image -> zero-padded NHWC4 (in0 -> out); H/W = Hin/Win, pad = border */
+    SAT_OP_IMAGE_PREP = 1, /* NCHW f32 image -> zero-padded NHWC4 (in0 -> out); H/W = Hin/Win, pad = border; Cout = 8 (bf16):
+                            * NHWC8 instead, one 16-byte chunk per pixel (3x3 stems: VGG conv1_1, model2.py:15) */
     SAT_OP_CONV = 2,       /* implicit-GEMM conv: in0 (NHWC) * w [Cout][KH*KW*Cin] -> out [M][Cout] (+ stat_partial) */
     SAT_OP_BN_FINALIZE = 3,/* partials -> scale/shift (+ running stats update); with stat_acc set ("acc mode"):
                             * partials -> the fixed-point integer accumulators stat_acc (parity half), consumers derive */
@@ -59,6 +60,7 @@ enum {
     SAT_OP_BN_ADD_RELU = 5,/* out = relu(in0*scale0+shift0 + (in1*scale1+shift1 | in1)) */
     SAT_OP_BN_RELU_MAXPOOL = 6, /* out = maxpool3x3/2(relu(in0*scale0+shift0)) */
     SAT_OP_AVGPOOL = 7,    /* out f32 [N][C] = mean over Hin*Win of in0 */
+    SAT_OP_MAXPOOL2 = 9,   /* out = maxpool 2x2 / stride 2 of in0 (NHWC; Hin, Win even; Cout channels): VGG16, model2.py:15-16 */
     SAT_OP_BN_EVAL_BATCH = 8 /* eval mode: in0 = DEVICE array of `count` sat_bn_eval_item; every item's (scale, shift)
                               * from its running statistics in ONE launch (replaces one BN_FINALIZE per layer); eps */
 };
@@ -245,6 +247,45 @@ int sat_lstm_step(const float* x, const float* h_in, float* c, const float* w_ih
 /* rows of an embedding table: out[b] = embed[ids[b*ids_stride]] */
 int sat_embed_rows(const float* embed, const int64_t* ids, int64_t ids_stride, int B, int E, int V,
                    float* out, sat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Show-Attend-Tell decoder (model2.py:38-111: the model train.py:37 constructs).  f32, rows = batch rows of one step.
+ * sat_attention_fwd: `attention_layer` (model2.py:73-78) for `rows` batch rows:
+ *   h_att = tanh(ctx_enc[b] + proj[b][None,:]); alpha[b] = softmax_p(h_att . w_att); context[b] = mean_p(alpha[b,p] feats[b,p,:])
+ *   ctx_enc, feats: [rows][P][C] (context_encode / features, model2.py:45-46); proj = weight_hh(hidden) [rows][ld_proj];
+ *   alpha [rows][P] (nullable); context [rows][ld_ctx] (ld_ctx lets it land inside the LSTMCell input row).
+ * sat_attention_bwd: its backward given d_context (h_att recomputed): d_ctx_enc[rows][P][C] += ..., d_proj [rows][C],
+ *   d_watt_part [rows][C] (sum over rows = d weight_att; kept per row for a fixed-order reduction).
+ * sat_lstmcell_fwd: one nn.LSTMCell step (model2.py:58), c in place, optional tapes (activated gates, new c).
+ * sat_rows_copy: out[r] = in[idx ? idx[r*idx_stride] : r] (embedding rows into a strided destination, state slices).
+ * sat_rows_sum: out[c] (+)= sum_r in[r][c] in fixed order.
+ */
+int sat_attention_fwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
+                      int rows, int P, int C, float* alpha, float* context, int64_t ld_ctx, sat_stream_t stream);
+int sat_attention_bwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
+                      const float* alpha, const float* d_ctx, int64_t ld_dctx, int rows, int P, int C,
+                      float* d_ctx_enc, float* d_proj, float* d_watt_part, sat_stream_t stream);
+int sat_lstmcell_fwd(const float* x /*[B,In]*/, const float* h_in /*[B,H]*/, float* c /*[B,H] in place*/, const float* w_ih,
+                     const float* w_hh, const float* b_ih, const float* b_hh, int B, int In, int H, float* h_out,
+                     float* gates /*[B,4H] or NULL*/, float* c_tape /*[B,H] or NULL*/, sat_stream_t stream);
+int sat_rows_copy(const float* in, int64_t ldi, const int64_t* idx, int64_t idx_stride, int64_t nrows_in, int rows, int cols,
+                  float* out, int64_t ldo, sat_stream_t stream);
+int sat_rows_sum(const float* in, int64_t ld, int rows, int cols, float* out, int accumulate, sat_stream_t stream);
+/* out[r] = a[r] + b[r] over `cols` columns of strided rows */
+int sat_rows_add(const float* a, int64_t lda, const float* b, int64_t ldb, int rows, int cols, float* out, int64_t ldo,
+                 sat_stream_t stream);
+/* packed token ids out[row(t,b)] = captions[b][t + col0] (prefix/T/N as for sat_pack_targets: the embedding rows a step uses) */
+int sat_pack_tokens(const int64_t* captions, int64_t cap_stride, const int32_t* prefix /*device*/, int T, int N, int col0,
+                    int64_t* out, sat_stream_t stream);
+/* dense embedding gradient (nn.Embedding, sparse=False; model2.py:28): table[V,E] = 0, then table[ids[n]] += rows[n] with a
+ * fixed summation order (first occurrence sums its duplicates in row order) */
+int sat_scatter_rows_add(const float* rows /*[N,E]*/, const int64_t* ids /*[N]*/, int N, int E, int V, float* table,
+                         sat_stream_t stream);
+/* pointwise backward of one nn.LSTMCell step: dh = dh_out (+ dh_carry for rows < n_carry), dc from dc_state (rows < n_carry);
+ * DG[n,4H] = d(pre-activation gates); dc_state = d c_prev.  gates/c: the step's tapes; c_prev NULL = zeros. */
+int sat_lstmcell_bwd_point(const float* dh_out /*[n,H]*/, const float* dh_carry /*[>=n_carry,H] or NULL*/, int n_carry,
+                           const float* gates /*[n,4H]*/, const float* c /*[n,H]*/, const float* c_prev /*[n,H] or NULL*/,
+                           float* dc_state /*[n,H]*/, float* DG /*[n,4H]*/, int n, int H, sat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Beam decode (the reference has only a stub, model2.py:113-114, next to the greedy loop

@@ -14,6 +14,7 @@ SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
 OP_BN_EVAL_BATCH = 8
+OP_MAXPOOL2 = 9
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -82,6 +83,15 @@ SIGNATURES = {
     "sat_vocab_argmax_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_embed_rows": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "sat_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
+    "sat_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sat_lstmcell_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sat_rows_copy": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _vp, _i64, _vp]),
+    "sat_rows_sum": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp]),
+    "sat_rows_add": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _i64, _vp]),
+    "sat_pack_tokens": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp, _vp]),
+    "sat_scatter_rows_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sat_lstmcell_bwd_point": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sat_beam_step": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_beam_step_ws_bytes": (_i64, [_i, _i]),
     "sat_beam_gather_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

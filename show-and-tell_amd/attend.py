@@ -1,0 +1,400 @@
+"""Show-Attend-Tell behind the same boundary: `ShowAttendTellModel` with the reference's constructor,
+`forward(images, captions, lengths)` and `sample(images, states)` (`/root/reference/model2.py:9-111`, the model
+`train.py:37` constructs), every tensor op a libsat_hip.so kernel.
+
+    encoder  : VGG16 `features[:-3]` (model2.py:15-16), frozen (model2.py:17, 87-89) -- the conv op program of the ResNet
+               path (implicit-GEMM conv with the bias + ReLU riding in the bf16 conv epilogue, SAT_OP_MAXPOOL2)
+    decoder  : context_encode = features @ image_att_w (sat_gemm_f32); init_lstm; per packed step: weight_hh projection,
+               sat_attention_fwd (tanh / softmax / weighted mean, model2.py:73-78), sat_lstmcell_fwd (model2.py:58);
+               output_layer batched over all packed rows after the loop (model2.py:80-85)
+    backward : hand-written (sat_attention_bwd, LSTMCell BPTT, batched weight-gradient GEMMs) behind torch.autograd, so
+               `loss.backward()` (train.py:144) works unchanged; `finetune(allow=True)` (conv backward) is not built.
+
+state_dict keys equal the reference's: `encoder.{0,2,5,...}.weight/bias`, `image_att_w`, `init_hidden.*`, `init_memory.*`,
+`weight_hh.*`, `weight_att`, `embedding.weight`, `lstmcell.{weight_ih,weight_hh,bias_ih,bias_hh}`, `context2out.*`,
+`hidden2tout.*`, `classifier.*`.  GPU only: there is no CPU fallback.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .models import IdGuard
+from .pack import PackInfo
+
+VGG16_FEATURES = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512]    # vgg16.features[:-3]
+
+
+class _ConvB(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        w = torch.empty(cout, cin, 3, 3)
+        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")          # torchvision vgg init
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class VggFeatures(nn.Module):
+    """`nn.Sequential(*list(vgg16.features)[:-3])` as a parameter tree with the same child names ("0", "2", "5", ...)."""
+
+    def __init__(self, cfg=VGG16_FEATURES):
+        super().__init__()
+        self.cfg = list(cfg)
+        i, c = 0, 3
+        self.conv_names = []
+        for v in self.cfg:
+            if v == "M":
+                i += 1
+            else:
+                self.add_module(str(i), _ConvB(c, v))
+                self.conv_names.append(str(i))
+                c, i = v, i + 2
+        self.out_channels = c
+
+    def convs(self):
+        return [getattr(self, n) for n in self.conv_names]
+
+
+class VggProgram:
+    """Device buffers + sat_op array of the frozen VGG stack for one (batch, H, W, dtype): images f32 NCHW ->
+    features f32 [N, P, C] (model2.py:44-45's view + transpose is the NHWC flattening) and their mean over P."""
+
+    def __init__(self, stack, N, H, W, dtype, device):
+        self.N, self.H, self.W, self.dtype = N, H, W, dtype
+        td = torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
+        ch = 8 if dtype == L.SAT_BF16 else 4
+        self.keep, ops = [], []
+
+        def alloc(shape, dt=td, zero=False):
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dt, device=device)
+            self.keep.append(t)
+            return t
+
+        # 3-channel input: zero-bordered NHWC image with the channels padded to one 16-byte chunk per pixel
+        cpad = ch
+        self.img_pad = alloc((N, H + 2, W + 2, cpad), zero=True)
+        o = L.SatOp()
+        o.kind, o.dtype = L.OP_IMAGE_PREP, dtype
+        o.out = self.img_pad.data_ptr()
+        o.N, o.Hin, o.Win, o.Hout, o.Wout, o.pad, o.Cout = N, H, W, H + 2, W + 2, 1, cpad
+        ops.append(o)
+        x, h, w, c = self.img_pad, H, W, cpad
+        first = True
+        ones = {}
+        convs = iter(stack.convs())
+        for v in stack.cfg:
+            if v == "M":
+                out = alloc((N, h // 2, w // 2, c))
+                o = L.SatOp()
+                o.kind, o.dtype = L.OP_MAXPOOL2, dtype
+                o.in0, o.out = x.data_ptr(), out.data_ptr()
+                o.N, o.Hin, o.Win, o.Cout = N, h, w, c
+                ops.append(o)
+                x, h, w = out, h // 2, w // 2
+                continue
+            conv = next(convs)
+            wt = conv.weight.detach().to(device=device, dtype=torch.float32)
+            if first:                                    # pad Cin 3 -> chunk width with zero weights
+                wp = torch.zeros(v, cpad, 3, 3, device=device)
+                wp[:, :3] = wt
+                wt = wp
+            wk = wt.permute(0, 2, 3, 1).contiguous().to(td).reshape(v, -1)
+            bias = conv.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+            self.keep += [wk, bias]
+            out = alloc((N, h, w, v))
+            o = L.SatOp()
+            o.kind, o.dtype = L.OP_CONV, dtype
+            o.in0, o.w, o.out = x.data_ptr(), wk.data_ptr(), out.data_ptr()
+            cin = c
+            o.N, o.Cin, o.Hout, o.Wout, o.Cout, o.KH, o.KW, o.stride = N, cin, h, w, v, 3, 3, 1
+            if first:                                    # the border is in the image: no padding arithmetic in the kernel
+                o.Hin, o.Win, o.pad = h + 2, w + 2, 0
+                o.sN, o.sH, o.sW = (h + 2) * (w + 2) * cin, (w + 2) * cin, cin
+            else:
+                o.Hin, o.Win, o.pad = h, w, 1
+                o.sN, o.sH, o.sW = h * w * cin, w * cin, cin
+            if v not in ones:
+                ones[v] = alloc((v,), torch.float32)
+                ones[v].fill_(1.0)
+            if dtype == L.SAT_BF16:                      # bias + ReLU ride in the conv epilogue (out = relu(acc*1 + bias))
+                o.scale1, o.shift1, o.flags = ones[v].data_ptr(), bias.data_ptr(), 1
+                ops.append(o)
+            else:                                        # f32 parity mode: conv, then the elementwise affine + ReLU kernel
+                raw = alloc((N, h, w, v))
+                o.out = raw.data_ptr()
+                ops.append(o)
+                a = L.SatOp()
+                a.kind, a.dtype = L.OP_BN_RELU, dtype
+                a.in0, a.out, a.scale0, a.shift0 = raw.data_ptr(), out.data_ptr(), ones[v].data_ptr(), bias.data_ptr()
+                a.N, a.Hout, a.Wout, a.Cout = N, h, w, v
+                ops.append(a)
+            x, c, first = out, v, False
+        self.P, self.C = h * w, c
+        self.fmap = x
+        self.fmean = alloc((N, c), torch.float32)
+        ap = L.SatOp()
+        ap.kind, ap.dtype = L.OP_AVGPOOL, dtype
+        ap.in0, ap.out = x.data_ptr(), self.fmean.data_ptr()
+        ap.N, ap.Hin, ap.Win, ap.Cout = N, h, w, c
+        ops.append(ap)
+        self.features = self.fmap.view(N, self.P, c) if dtype == L.SAT_F32 else alloc((N, self.P, c), torch.float32)
+        self.ops = (L.SatOp * len(ops))(*ops)
+        self.n_ops = len(ops)
+        if dtype == L.SAT_BF16 and os.environ.get("SAT_AUTOTUNE", "1") != "0":
+            scratch = alloc((4096,), torch.float32)
+            L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 3, scratch.data_ptr(), scratch.numel() * 4, L.stream()),
+                    "sat_conv_autotune")
+            torch.cuda.synchronize()
+
+    def run(self, images):
+        L.require_gpu(images, "images")
+        if images.dtype != torch.float32 or tuple(images.shape) != (self.N, 3, self.H, self.W):
+            raise ValueError("images must be float32 [%d,3,%d,%d]" % (self.N, self.H, self.W))
+        images = images.contiguous()
+        lib = L.load()
+        self.ops[0].in0 = images.data_ptr()
+        L.check(lib.sat_run_ops(self.ops, self.n_ops, L.stream()), "sat_run_ops")
+        if self.dtype == L.SAT_BF16:
+            L.check(lib.sat_cast_bf16_f32(self.fmap.data_ptr(), self.features.data_ptr(), self.features.numel(), L.stream()),
+                    "sat_cast_bf16_f32")
+        return self.features, self.fmean
+
+
+class _Lin(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        k = 1.0 / math.sqrt(fin)
+        self.weight = nn.Parameter(torch.empty(fout, fin).uniform_(-k, k))         # nn.Linear default init
+        self.bias = nn.Parameter(torch.empty(fout).uniform_(-k, k))
+
+
+class _Emb(nn.Module):
+    def __init__(self, v, e):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(v, e).normal_(0, 1))                # nn.Embedding default init
+
+
+class _Cell(nn.Module):
+    def __init__(self, fin, h):
+        super().__init__()
+        k = 1.0 / math.sqrt(h)
+        self.weight_ih = nn.Parameter(torch.empty(4 * h, fin).uniform_(-k, k))     # nn.LSTMCell default init
+        self.weight_hh = nn.Parameter(torch.empty(4 * h, h).uniform_(-k, k))
+        self.bias_ih = nn.Parameter(torch.empty(4 * h).uniform_(-k, k))
+        self.bias_hh = nn.Parameter(torch.empty(4 * h).uniform_(-k, k))
+
+
+def _gemm(lib, amode, bmode, A, lda, B, ldb, Cout, ldc, M, N, K, bias=None, bias2=None):
+    L.check(lib.sat_gemm_f32(amode, bmode, L.ptr(A) if torch.is_tensor(A) else A, lda, L.ptr(B) if torch.is_tensor(B) else B, ldb,
+                             L.ptr(Cout) if torch.is_tensor(Cout) else Cout, ldc, L.ptr(bias), L.ptr(bias2), M, N, K, L.stream()),
+            "sat_gemm_f32")
+
+
+def _p(t, row0=0):
+    """device pointer of row `row0` of a 2-D contiguous f32 tensor"""
+    return t.data_ptr() + row0 * t.shape[1] * 4
+
+
+class _AttendFn(torch.autograd.Function):
+    """decoder half of model2.py:38-65 given the encoder features (the conv stack is frozen, model2.py:17)."""
+
+    @staticmethod
+    def forward(ctx, model, features, fmean, captions, pi, *params):
+        lib = L.load()
+        m = model
+        dev = features.device
+        st = L.stream()
+        B, P, C = features.shape
+        E, H, V, Hin = m.embed_size, m.hidden_size, m.vocab_size, m.hidden_size
+        N, T = pi.N, pi.T
+        f2 = features.view(B * P, C)
+        ctx_enc = torch.empty(B * P, C, device=dev)
+        _gemm(lib, 0, 1, f2, C, m.image_att_w, C, ctx_enc, C, B * P, C, C)                      # model2.py:46
+        h0, c0 = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+        _gemm(lib, 0, 0, fmean, C, m.init_hidden.weight, C, h0, H, B, H, C, m.init_hidden.bias)  # model2.py:67-71
+        _gemm(lib, 0, 0, fmean, C, m.init_memory.weight, C, c0, H, B, H, C, m.init_memory.bias)
+        c = c0.clone()
+        CTX, HS = torch.empty(N, C, device=dev), torch.empty(N, H, device=dev)
+        X, GATES = torch.empty(N, Hin, device=dev), torch.empty(N, 4 * H, device=dev)
+        CS, ALPHA = torch.empty(N, H, device=dev), torch.empty(N, P, device=dev)
+        proj = torch.empty(B, C, device=dev)
+        watt = m.weight_att.view(-1)
+        for t, bs in enumerate(pi.batch_sizes):                                                  # model2.py:54-62
+            r0 = pi.prefix[t]
+            hprev = h0.data_ptr() if t == 0 else _p(HS, pi.prefix[t - 1])
+            _gemm(lib, 0, 0, hprev, H, m.weight_hh.weight, H, proj, C, bs, C, H, m.weight_hh.bias)
+            L.check(lib.sat_attention_fwd(L.ptr(ctx_enc), L.ptr(f2), L.ptr(proj), C, L.ptr(watt), bs, P, C, _p(ALPHA, r0),
+                                          _p(CTX, r0), C, st), "sat_attention_fwd")
+            L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, captions.data_ptr() + t * 8, captions.stride(0), V, bs, E,
+                                      _p(X, r0), Hin, st), "sat_rows_copy")
+            L.check(lib.sat_rows_copy(_p(CTX, r0), C, None, 0, bs, bs, C, _p(X, r0) + E * 4, Hin, st), "sat_rows_copy")
+            L.check(lib.sat_lstmcell_fwd(_p(X, r0), hprev, L.ptr(c), L.ptr(m.lstmcell.weight_ih), L.ptr(m.lstmcell.weight_hh),
+                                         L.ptr(m.lstmcell.bias_ih), L.ptr(m.lstmcell.bias_hh), bs, Hin, H, _p(HS, r0),
+                                         _p(GATES, r0), _p(CS, r0), st), "sat_lstmcell_fwd")
+        # output_layer over all packed rows at once (model2.py:80-85): z = [ctx | h] [W_c2o | W_h2o]^T + b1 + b2
+        Zin, Wz = torch.empty(N, C + H, device=dev), torch.empty(E, C + H, device=dev)
+        L.check(lib.sat_rows_copy(L.ptr(CTX), C, None, 0, N, N, C, L.ptr(Zin), C + H, st), "sat_rows_copy")
+        L.check(lib.sat_rows_copy(L.ptr(HS), H, None, 0, N, N, H, Zin.data_ptr() + C * 4, C + H, st), "sat_rows_copy")
+        L.check(lib.sat_rows_copy(L.ptr(m.context2out.weight), C, None, 0, E, E, C, L.ptr(Wz), C + H, st), "sat_rows_copy")
+        L.check(lib.sat_rows_copy(L.ptr(m.hidden2tout.weight), H, None, 0, E, E, H, Wz.data_ptr() + C * 4, C + H, st), "sat_rows_copy")
+        Z = torch.empty(N, E, device=dev)
+        _gemm(lib, 0, 0, Zin, C + H, Wz, C + H, Z, E, N, E, C + H, m.context2out.bias, m.hidden2tout.bias)
+        ldl = (V + 3) // 4 * 4
+        logits = torch.zeros(N, ldl, device=dev) if V % 4 else torch.empty(N, V, device=dev)
+        _gemm(lib, 0, 0, Z, E, m.classifier.weight, E, logits, ldl, N, V, E, m.classifier.bias)
+        ctx.m, ctx.pi, ctx.captions = m, pi, captions
+        ctx.tapes = dict(f2=f2, fmean=fmean, ctx_enc=ctx_enc, h0=h0, c0=c0, CTX=CTX, HS=HS, X=X, GATES=GATES, CS=CS, ALPHA=ALPHA,
+                         Zin=Zin, Wz=Wz, Z=Z)
+        return logits if ldl == V else logits[:, :V]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        from .attend_bwd import attend_backward
+        grads = attend_backward(ctx.m, ctx.pi, ctx.captions, ctx.tapes, dlogits)
+        return (None, None, None, None, None) + tuple(grads)
+
+
+PARAM_ORDER = ("image_att_w", "init_hidden.weight", "init_hidden.bias", "init_memory.weight", "init_memory.bias",
+               "weight_hh.weight", "weight_hh.bias", "weight_att", "embedding.weight", "lstmcell.weight_ih", "lstmcell.weight_hh",
+               "lstmcell.bias_ih", "lstmcell.bias_hh", "context2out.weight", "context2out.bias", "hidden2tout.weight",
+               "hidden2tout.bias", "classifier.weight", "classifier.bias")
+
+
+class ShowAttendTellModel(nn.Module):
+    """model2.py:9-111.  `compute_dtype` ('bf16' conv stack / 'f32' parity) and `vgg_cfg` are build extensions."""
+
+    def __init__(self, hidden_size, context_size, vocab_size, embed_size, opt=None, feature_size=(196, 512),
+                 compute_dtype="bf16", vgg_cfg=VGG16_FEATURES):
+        super().__init__()
+        feat = int(feature_size[1])
+        if embed_size + feat != hidden_size:
+            raise ValueError("the LSTMCell input is cat[embedding, context] (model2.py:57-58): hidden_size must equal "
+                             "embed_size + %d" % feat)
+        if context_size != feat:
+            raise ValueError("weight_hh(hidden) is added to context_encode (model2.py:74): context_size must equal %d" % feat)
+        if feat % 4 or hidden_size % 4 or embed_size % 4:
+            raise ValueError("feature, hidden and embed sizes must be multiples of 4")
+        self.opt = opt
+        self.encoder = VggFeatures(vgg_cfg)                                             # model2.py:15-16
+        if self.encoder.out_channels != feat:
+            raise ValueError("the conv stack ends in %d channels, feature_size says %d" % (self.encoder.out_channels, feat))
+        self.finetune(allow=False)                                                      # model2.py:17
+        self.image_att_w = nn.Parameter(torch.empty(feat, feat).normal_(0, 0.05))       # model2.py:20 (uninitialised there)
+        self.init_hidden, self.init_memory = _Lin(feat, hidden_size), _Lin(feat, hidden_size)
+        self.weight_hh = _Lin(hidden_size, context_size)
+        self.weight_att = nn.Parameter(torch.empty(feat, 1).normal_(0, 0.05))           # model2.py:25 (uninitialised there)
+        self.embedding = _Emb(vocab_size, embed_size)
+        self.lstmcell = _Cell(hidden_size, hidden_size)
+        self.context2out, self.hidden2tout = _Lin(context_size, embed_size), _Lin(hidden_size, embed_size)
+        self.classifier = _Lin(embed_size, vocab_size)
+        self.hidden_size, self.embed_size, self.vocab_size, self.feat = hidden_size, embed_size, vocab_size, feat
+        self.compute_dtype = compute_dtype
+        self._programs, self._guard = {}, None
+        self.register_load_state_dict_post_hook(lambda mod, k: mod._programs.clear())
+        self.encoder.register_load_state_dict_post_hook(lambda mod, k: self._programs.clear())
+
+    def finetune(self, allow=False):
+        """model2.py:87-89.  allow=True needs the conv backward, which is not built."""
+        if allow:
+            raise NotImplementedError("fine-tuning the conv stack (conv backward) is not built; the encoder stays frozen")
+        for p in self.encoder.parameters():
+            p.requires_grad = False
+
+    def _apply(self, fn, *a, **k):
+        self._programs.clear()
+        return super()._apply(fn, *a, **k)
+
+    def _encode(self, images):
+        L.require_gpu(images, "images")
+        N, _, H, W = images.shape
+        dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
+        sig = sum(p._version * 7 + (p.data_ptr() & 0xffffffff) for p in self.encoder.parameters())
+        key = (N, H, W, dt, str(images.device), sig)
+        prog = self._programs.get(key)
+        if prog is None:
+            self._programs.clear()
+            prog = self._programs[key] = VggProgram(self.encoder, N, H, W, dt, images.device)
+        with torch.no_grad():
+            feats, fmean = prog.run(images)
+        if feats.shape[2] != self.feat:
+            raise ValueError("encoder features have %d channels, expected %d" % (feats.shape[2], self.feat))
+        return feats.clone(), fmean.clone()           # the program's buffers are overwritten by the next forward
+
+    def _params(self):
+        d = dict(self.named_parameters())
+        return [d[k] for k in PARAM_ORDER]
+
+    def forward(self, images, captions, lengths):
+        """model2.py:38-65: logits f32 [sum(lengths), V], rows in time-major packed order."""
+        feats, fmean = self._encode(images)
+        return self.decode(feats, fmean, captions, lengths)
+
+    def decode(self, features, fmean, captions, lengths):
+        L.require_gpu(captions, "captions")
+        if len(lengths) != features.shape[0]:
+            raise ValueError("len(lengths) != batch size")
+        pi = PackInfo.get(lengths, features.device)
+        if pi.T > captions.shape[1]:
+            raise ValueError("a length exceeds captions.shape[1]")
+        if captions.dtype != torch.int64 or captions.stride(1) != 1:
+            captions = captions.long().contiguous()
+        if self._guard is None or self._guard.status.device != features.device:
+            self._guard = IdGuard(features.device)
+        self._guard.submit(captions, pi.T, self.vocab_size, "captions")
+        return _AttendFn.apply(self, features, fmean, captions, pi, *self._params())
+
+    @torch.no_grad()
+    def sample(self, images, states=None):
+        """Greedy search, 20 steps (model2.py:91-111; torch-0.1 keepdim semantics): i64 [B,20].  `states`: None = zeros (what
+        eval.py:82-83 passes), a (h, c) pair of [B,H] tensors, or eval.py:89's stacked [2,B,H] tensor."""
+        feats, _ = self._encode(images)
+        return self.sample_features(feats, states)
+
+    @torch.no_grad()
+    def sample_features(self, features, states=None, steps=20, start_id=1):
+        lib = L.load()
+        m, dev, st = self, features.device, L.stream()
+        B, P, C = features.shape
+        E, H, V, Hin = m.embed_size, m.hidden_size, m.vocab_size, m.hidden_size
+        f2 = features.contiguous().view(B * P, C)
+        ctx_enc = torch.empty(B * P, C, device=dev)
+        _gemm(lib, 0, 1, f2, C, m.image_att_w, C, ctx_enc, C, B * P, C, C)
+        if states is None:
+            h, c = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+        else:
+            h, c = states[0].to(dev).float().contiguous().clone(), states[1].to(dev).float().contiguous().clone()
+        h2 = torch.empty(B, H, device=dev)
+        proj, X = torch.empty(B, C, device=dev), torch.empty(B, Hin, device=dev)
+        ctxb, Zin, Z = torch.empty(B, C, device=dev), torch.empty(B, C + H, device=dev), torch.empty(B, E, device=dev)
+        Wz = torch.empty(E, C + H, device=dev)
+        L.check(lib.sat_rows_copy(L.ptr(m.context2out.weight), C, None, 0, E, E, C, L.ptr(Wz), C + H, st), "sat_rows_copy")
+        L.check(lib.sat_rows_copy(L.ptr(m.hidden2tout.weight), H, None, 0, E, E, H, Wz.data_ptr() + C * 4, C + H, st), "sat_rows_copy")
+        ids = torch.full((B, steps), int(start_id), dtype=torch.int64, device=dev)
+        start = torch.full((B,), int(start_id), dtype=torch.int64, device=dev)
+        wsb = lib.sat_vocab_argmax_ws_bytes(B, V)
+        ws = torch.empty(wsb // 4, device=dev)
+        watt = m.weight_att.view(-1)
+        for i in range(steps):
+            _gemm(lib, 0, 0, h, H, m.weight_hh.weight, H, proj, C, B, C, H, m.weight_hh.bias)
+            L.check(lib.sat_attention_fwd(L.ptr(ctx_enc), L.ptr(f2), L.ptr(proj), C, L.ptr(watt), B, P, C, None, L.ptr(ctxb), C, st),
+                    "sat_attention_fwd")
+            if i == 0:                                                               # model2.py:101-102
+                L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, start.data_ptr(), 1, V, B, E, L.ptr(X), Hin, st), "sat_rows_copy")
+                L.check(lib.sat_rows_copy(L.ptr(ctxb), C, None, 0, B, B, C, X.data_ptr() + E * 4, Hin, st), "sat_rows_copy")
+            L.check(lib.sat_lstmcell_fwd(L.ptr(X), L.ptr(h), L.ptr(c), L.ptr(m.lstmcell.weight_ih), L.ptr(m.lstmcell.weight_hh),
+                                         L.ptr(m.lstmcell.bias_ih), L.ptr(m.lstmcell.bias_hh), B, Hin, H, L.ptr(h2), None, None, st),
+                    "sat_lstmcell_fwd")
+            h, h2 = h2, h
+            L.check(lib.sat_rows_copy(L.ptr(ctxb), C, None, 0, B, B, C, L.ptr(Zin), C + H, st), "sat_rows_copy")
+            L.check(lib.sat_rows_copy(L.ptr(h), H, None, 0, B, B, H, Zin.data_ptr() + C * 4, C + H, st), "sat_rows_copy")
+            _gemm(lib, 0, 0, Zin, C + H, Wz, C + H, Z, E, B, E, C + H, m.context2out.bias, m.hidden2tout.bias)
+            col = ids[:, i]
+            L.check(lib.sat_vocab_argmax(L.ptr(Z), L.ptr(m.classifier.weight), L.ptr(m.classifier.bias), B, E, V, col.data_ptr(),
+                                         ids.stride(0), L.ptr(ws), wsb, st), "sat_vocab_argmax")
+            # model2.py:107-108: the NEXT LSTM input = [embedding(predicted), THIS step's context]
+            L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, col.data_ptr(), ids.stride(0), V, B, E, L.ptr(X), Hin, st), "sat_rows_copy")
+            L.check(lib.sat_rows_copy(L.ptr(ctxb), C, None, 0, B, B, C, X.data_ptr() + E * 4, Hin, st), "sat_rows_copy")
+        return ids

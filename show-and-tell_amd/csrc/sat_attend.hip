@@ -1,0 +1,346 @@
+// Show-Attend-Tell decoder kernels (`/root/reference/model2.py:38-111`, the model train.py:37 constructs): the soft
+// attention step (`attention_layer`, model2.py:73-78) forward and backward, a 2x2/2 max-pool for the VGG16
+// `features[:-3]` stack (model2.py:15-16), and small row utilities.  Decoder arithmetic is f32 (ocml tanhf / expf), like
+// the Show-and-Tell decoder; the dense contractions around these kernels go through sat_gemm_f32 / the skinny kernels.
+#include "sat_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.0f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, sh[i]);
+    return r;
+}
+
+// One workgroup per batch row b (model2.py:73-78):
+//   h_att[p,c] = tanh(ctx_enc[b,p,c] + proj[b,c]);  s[p] = sum_c h_att[p,c] * w_att[c];  alpha = softmax_p(s)
+//   context[b,c] = (1/P) * sum_p alpha[p] * feats[b,p,c]            (the reference takes the MEAN of the weighted features)
+// Scores: one wave per position (lanes stride the channels, 16 B per lane), fixed-order wave reduction.
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ ctx_enc, const float* __restrict__ feats,
+                                                            const float* __restrict__ proj, long ld_proj,
+                                                            const float* __restrict__ w_att, int P, int C,
+                                                            float* __restrict__ alpha, float* __restrict__ context, long ld_ctx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [C] proj | [C] w_att | [P] scores | [8] scratch
+    float* s_proj = sm;
+    float* s_w = sm + C;
+    float* s_sc = sm + 2 * C;
+    float* s_red = s_sc + ((P + 3) & ~3);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int c = tid; c < C; c += blockDim.x) {
+        s_proj[c] = proj[(long)b * ld_proj + c];
+        s_w[c] = w_att[c];
+    }
+    __syncthreads();
+    const float* ce = ctx_enc + (long)b * P * C;
+    for (int p = wave; p < P; p += nw) {
+        float acc = 0.0f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 x = *(const f32x4*)(ce + (long)p * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += tanhf(x[e] + s_proj[c + e]) * s_w[c + e];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) s_sc[p] = acc;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int p = tid; p < P; p += blockDim.x) m = fmaxf(m, s_sc[p]);
+    m = block_max(m, s_red);
+    float z = 0.0f;
+    for (int p = tid; p < P; p += blockDim.x) z += expf(s_sc[p] - m);
+    z = block_sum(z, s_red);
+    const float inv = 1.0f / z;
+    for (int p = tid; p < P; p += blockDim.x) {
+        const float a = expf(s_sc[p] - m) * inv;
+        s_sc[p] = a;
+        if (alpha) alpha[(long)b * P + p] = a;
+    }
+    __syncthreads();
+    const float* fb = feats + (long)b * P * C;
+    const float invP = 1.0f / (float)P;
+    for (int c = tid; c < C; c += blockDim.x) {
+        float acc = 0.0f;
+        for (int p = 0; p < P; ++p) acc += s_sc[p] * fb[(long)p * C + c];
+        context[(long)b * ld_ctx + c] = acc * invP;
+    }
+}
+
+// Backward of the step above for one batch row (h_att recomputed, never stored):
+//   d_alpha[p] = (1/P) feats[b,p,:] . d_ctx[b,:]
+//   d_s[p]     = alpha[p] * (d_alpha[p] - sum_q alpha[q] d_alpha[q])
+//   d_pre[p,c] = d_s[p] * w_att[c] * (1 - h_att[p,c]^2)        -> d_ctx_enc[b,p,c] += d_pre   (accumulated over steps)
+//   d_proj[b,c] = sum_p d_pre[p,c];   d_w_att partial[b,c] = sum_p d_s[p] * h_att[p,c]
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ ctx_enc, const float* __restrict__ feats,
+                                                            const float* __restrict__ proj, long ld_proj,
+                                                            const float* __restrict__ w_att, const float* __restrict__ alpha,
+                                                            const float* __restrict__ d_ctx, long ld_dctx, int P, int C,
+                                                            float* __restrict__ d_ctx_enc, float* __restrict__ d_proj,
+                                                            float* __restrict__ d_watt_part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [C] proj | [C] w_att | [C] d_ctx | [P] d_s | [8]
+    float* s_proj = sm;
+    float* s_w = sm + C;
+    float* s_dc = sm + 2 * C;
+    float* s_ds = sm + 3 * C;
+    float* s_red = s_ds + ((P + 3) & ~3);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int c = tid; c < C; c += blockDim.x) {
+        s_proj[c] = proj[(long)b * ld_proj + c];
+        s_w[c] = w_att[c];
+        s_dc[c] = d_ctx[(long)b * ld_dctx + c];
+    }
+    __syncthreads();
+    const float* fb = feats + (long)b * P * C;
+    const float invP = 1.0f / (float)P;
+    for (int p = wave; p < P; p += nw) {
+        float acc = 0.0f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 x = *(const f32x4*)(fb + (long)p * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += x[e] * s_dc[c + e];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) s_ds[p] = acc * invP;                           // d_alpha for now
+    }
+    __syncthreads();
+    float dot = 0.0f;
+    for (int p = tid; p < P; p += blockDim.x) dot += alpha[(long)b * P + p] * s_ds[p];
+    dot = block_sum(dot, s_red);
+    for (int p = tid; p < P; p += blockDim.x) s_ds[p] = alpha[(long)b * P + p] * (s_ds[p] - dot);
+    __syncthreads();
+    const float* ce = ctx_enc + (long)b * P * C;
+    float* dce = d_ctx_enc + (long)b * P * C;
+    for (int c = tid; c < C; c += blockDim.x) {                          // a thread owns a channel: fixed order over p
+        const float pj = s_proj[c], w = s_w[c];
+        float dp = 0.0f, dw = 0.0f;
+        for (int p = 0; p < P; ++p) {
+            const float ha = tanhf(ce[(long)p * C + c] + pj);
+            const float ds = s_ds[p];
+            const float dpre = ds * w * (1.0f - ha * ha);
+            dce[(long)p * C + c] += dpre;
+            dp += dpre;
+            dw += ds * ha;
+        }
+        d_proj[(long)b * C + c] = dp;
+        d_watt_part[(long)b * C + c] = dw;
+    }
+}
+
+// 2x2 / stride 2 max-pool, NHWC, 16 B per lane
+template <typename T>
+__global__ void maxpool2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int Hin, int Win, int C) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int Ho = Hin / 2, Wo = Win / 2, cch = C / V;
+    const long total = (long)N * Ho * Wo * cch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cch);
+        long r = i / cch;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const T* p = in + (((long)n * Hin + 2 * ho) * Win + 2 * wo) * C + cc * V;
+        float best[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) best[k] = -INFINITY;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const T* q = p + ((long)(d >> 1) * Win + (d & 1)) * C;
+            if constexpr (sizeof(T) == 4) {
+                const f32x4 x = *(const f32x4*)q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) best[k] = fmaxf(best[k], x[k]);
+            } else {
+                const bf16x8 x = *(const bf16x8*)q;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) best[k] = fmaxf(best[k], (float)x[k]);
+            }
+        }
+        T* o = out + i * V;
+        if constexpr (sizeof(T) == 4) {
+            *(f32x4*)o = (f32x4){best[0], best[1], best[2], best[3]};
+        } else {
+            bf16x8 y;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = (bf16_t)best[k];
+            *(bf16x8*)o = y;
+        }
+    }
+}
+
+// out[r*ldo + c] = in[idx(r)*ldi + c]: row gather / strided row copy (idx NULL: identity)
+__global__ __launch_bounds__(256) void rows_copy_kernel(const float* __restrict__ in, long ldi, const int64_t* __restrict__ idx,
+                                                        long idx_stride, long nrows_in, int cols, float* __restrict__ out, long ldo) {
+    const int r = blockIdx.x;
+    long src = r;
+    if (idx) {
+        src = idx[(long)r * idx_stride];
+        src = src < 0 ? 0 : (src >= nrows_in ? nrows_in - 1 : src);      // memory safety only (sat_validate_ids reports bad ids)
+    }
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) out[(long)r * ldo + c] = in[src * ldi + c];
+}
+
+// out[c] = sum_r in[r*ld + c] over rows (small r): fixed order
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ in, long ld, int rows, int cols, float* __restrict__ out,
+                                                       int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float acc = accumulate ? out[c] : 0.0f;
+    for (int r = 0; r < rows; ++r) acc += in[(long)r * ld + c];
+    out[c] = acc;
+}
+
+// out[r][c] = a[r][c] + b[r][c] (strided rows)
+__global__ __launch_bounds__(256) void rows_add_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                       int cols, float* __restrict__ out, long ldo) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) out[(long)r * ldo + c] = a[(long)r * lda + c] + b[(long)r * ldb + c];
+}
+
+// packed token ids: out[row(t,b)] = captions[b][t + col0] for b < batch_sizes[t]
+__global__ void pack_tokens_kernel(const int64_t* __restrict__ captions, long cap_stride, const int* __restrict__ prefix, int T,
+                                   int N, int col0, int64_t* __restrict__ out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    int t = 0;
+    while (t + 1 < T && row >= prefix[t + 1]) ++t;
+    out[row] = captions[(long)(row - prefix[t]) * cap_stride + t + col0];
+}
+
+// deterministic scatter-add of rows into a table (dense embedding gradient, nn.Embedding sparse=False): the workgroup of
+// the FIRST row carrying an id sums every row with that id in row order; the table is zeroed by the launcher.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int N,
+                                                           int E, int V, float* __restrict__ table) {
+    extern __shared__ __attribute__((aligned(16))) int tok[];
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const long x = ids[i];
+        tok[i] = (int)(x < 0 ? 0 : (x >= V ? V - 1 : x));            // memory safety only (sat_validate_ids reports bad ids)
+    }
+    __syncthreads();
+    const int v = tok[row];
+    int dup = 0;
+    for (int i = threadIdx.x; i < row; i += blockDim.x) dup |= (tok[i] == v);
+    if (__syncthreads_or(dup)) return;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        float acc = rows[(long)row * E + e];
+        for (int i = row + 1; i < N; ++i)
+            if (tok[i] == v) acc += rows[(long)i * E + e];
+        table[(long)v * E + e] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int sat_rows_add(const float* a, int64_t lda, const float* b, int64_t ldb, int rows, int cols, float* out, int64_t ldo,
+                            sat_stream_t stream) {
+    if (!a || !b || !out || rows < 0 || cols < 1 || lda < cols || ldb < cols || ldo < cols) return SAT_ERR_ARG;
+    if (rows == 0) return SAT_OK;
+    hipLaunchKernelGGL(rows_add_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, (long)lda, b, (long)ldb, cols, out, (long)ldo);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_pack_tokens(const int64_t* captions, int64_t cap_stride, const int32_t* prefix, int T, int N, int col0,
+                               int64_t* out, sat_stream_t stream) {
+    if (!captions || !prefix || !out || T < 1 || N < 1 || col0 < 0) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(pack_tokens_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, captions, (long)cap_stride,
+                       prefix, T, N, col0, out);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_scatter_rows_add(const float* rows, const int64_t* ids, int N, int E, int V, float* table, sat_stream_t stream) {
+    if (!rows || !ids || !table || N < 1 || E < 1 || V < 1) return SAT_ERR_ARG;
+    const size_t dyn = (size_t)N * 4;
+    if (dyn > 150 * 1024) return SAT_ERR_UNSUPPORTED;
+    if (dyn > 48 * 1024) {
+        hipError_t ea = hipFuncSetAttribute((const void*)scatter_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (ea != hipSuccess) return (int)ea;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(table, 0, (size_t)V * E * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(N), dim3(256), dyn, s, rows, ids, N, E, V, table);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_lstmcell_bwd_point(const float* dh_out, const float* dh_carry, int n_carry, const float* gates, const float* c,
+                                      const float* c_prev, float* dc_state, float* DG, int n, int H, sat_stream_t stream) {
+    if (!dh_out || !gates || !c || !dc_state || !DG || n < 1 || H < 1 || (n_carry > 0 && !dh_carry)) return SAT_ERR_ARG;
+    return sat_lstm_bwd_point_launch(dh_out, dh_carry, n_carry > 0 ? 1 : 0, 0, n_carry, gates, c, c_prev, dc_state, DG, n, H,
+                                     (hipStream_t)stream);
+}
+
+int sat_maxpool2_launch(const sat_op* op, hipStream_t s) {
+    if (!op->in0 || !op->out || (op->Hin & 1) || (op->Win & 1)) return SAT_ERR_ARG;
+    const int C = op->Cout;
+    const int V = op->dtype == SAT_BF16 ? 8 : 4;
+    if (C % V) return SAT_ERR_ARG;
+    const long total = (long)op->N * (op->Hin / 2) * (op->Win / 2) * (C / V);
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (op->dtype == SAT_BF16)
+        hipLaunchKernelGGL(maxpool2_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)op->in0, (bf16_t*)op->out, op->N, op->Hin, op->Win, C);
+    else
+        hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)op->in0, (float*)op->out, op->N, op->Hin, op->Win, C);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_attention_fwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
+                                 int rows, int P, int C, float* alpha, float* context, int64_t ld_ctx, sat_stream_t stream) {
+    if (!ctx_enc || !feats || !proj || !w_att || !context || rows < 1 || P < 1 || C < 4 || (C & 3) || ld_proj < C || ld_ctx < C)
+        return SAT_ERR_ARG;
+    const size_t lds = (size_t)(2 * C + ((P + 3) & ~3) + 8) * sizeof(float);
+    if (lds > 60 * 1024) return SAT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, ctx_enc, feats, proj, (long)ld_proj,
+                       w_att, P, C, alpha, context, (long)ld_ctx);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_attention_bwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
+                                 const float* alpha, const float* d_ctx, int64_t ld_dctx, int rows, int P, int C,
+                                 float* d_ctx_enc, float* d_proj, float* d_watt_part, sat_stream_t stream) {
+    if (!ctx_enc || !feats || !proj || !w_att || !alpha || !d_ctx || !d_ctx_enc || !d_proj || !d_watt_part || rows < 1 || P < 1 ||
+        C < 4 || (C & 3) || ld_proj < C || ld_dctx < C)
+        return SAT_ERR_ARG;
+    const size_t lds = (size_t)(3 * C + ((P + 3) & ~3) + 8) * sizeof(float);
+    if (lds > 60 * 1024) return SAT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, ctx_enc, feats, proj, (long)ld_proj,
+                       w_att, alpha, d_ctx, (long)ld_dctx, P, C, d_ctx_enc, d_proj, d_watt_part);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_rows_copy(const float* in, int64_t ldi, const int64_t* idx, int64_t idx_stride, int64_t nrows_in, int rows,
+                             int cols, float* out, int64_t ldo, sat_stream_t stream) {
+    if (!in || !out || rows < 0 || cols < 1 || ldi < cols || ldo < cols) return SAT_ERR_ARG;
+    if (rows == 0) return SAT_OK;
+    hipLaunchKernelGGL(rows_copy_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, in, (long)ldi, idx, (long)idx_stride,
+                       (long)nrows_in, cols, out, (long)ldo);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_rows_sum(const float* in, int64_t ld, int rows, int cols, float* out, int accumulate, sat_stream_t stream) {
+    if (!in || !out || rows < 0 || cols < 1 || ld < cols) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, (long)ld, rows, cols, out,
+                       accumulate);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}

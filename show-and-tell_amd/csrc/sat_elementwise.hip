@@ -60,7 +60,7 @@ template <> __device__ __forceinline__ void store_chunk<bf16_t>(bf16_t* p, const
 // ------------------------------------------------------------------------------------------------------
 // image prep: NCHW f32 -> zero-bordered NHWC4 (channel 3 = 0).  Border/extra pixels are never written:
 // the caller zero-fills the buffer once.
-template <typename T>
+template <typename T, int CH = 4>
 __global__ void image_prep_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int H, int W,
                                   int Hp, int Wp, int pad) {
     const long total = (long)N * H * W;
@@ -71,11 +71,12 @@ __global__ void image_prep_kernel(const float* __restrict__ in, T* __restrict__ 
         const int n = (int)(t / H);
         const long plane = (long)H * W;
         const float* src = in + (long)n * 3 * plane + (long)h * W + w;
-        T* dst = out + (((long)n * Hp + h + pad) * Wp + w + pad) * 4;
+        T* dst = out + (((long)n * Hp + h + pad) * Wp + w + pad) * CH;
         dst[0] = from_f32<T>(src[0]);
         dst[1] = from_f32<T>(src[plane]);
         dst[2] = from_f32<T>(src[2 * plane]);
-        dst[3] = from_f32<T>(0.0f);
+#pragma unroll
+        for (int c = 3; c < CH; ++c) dst[c] = from_f32<T>(0.0f);
     }
 }
 
@@ -843,7 +844,11 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
 int sat_image_prep_launch(const sat_op* op, hipStream_t s) {
     if (!op->in0 || !op->out) return SAT_ERR_ARG;
     const long total = (long)op->N * op->Hin * op->Win;
-    if (op->dtype == SAT_BF16)
+    if (op->Cout != 0 && op->Cout != 4 && !(op->Cout == 8 && op->dtype == SAT_BF16)) return SAT_ERR_ARG;
+    if (op->dtype == SAT_BF16 && op->Cout == 8)       // NHWC8: a 16-byte chunk per pixel for 3x3 stems (VGG conv1_1)
+        hipLaunchKernelGGL((image_prep_kernel<bf16_t, 8>), dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const float*)op->in0,
+                           (bf16_t*)op->out, op->N, op->Hin, op->Win, op->Hout, op->Wout, op->pad);
+    else if (op->dtype == SAT_BF16)
         hipLaunchKernelGGL(image_prep_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const float*)op->in0,
                            (bf16_t*)op->out, op->N, op->Hin, op->Win, op->Hout, op->Wout, op->pad);
     else

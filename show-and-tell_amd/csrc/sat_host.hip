@@ -37,6 +37,7 @@ extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_
             case SAT_OP_BN_RELU_MAXPOOL: rc = sat_bn_relu_maxpool_launch(op, parity, s); break;
             case SAT_OP_AVGPOOL: rc = sat_avgpool_launch(op, s); break;
             case SAT_OP_BN_EVAL_BATCH: rc = sat_bn_eval_batch_launch(op, s); break;
+            case SAT_OP_MAXPOOL2: rc = sat_maxpool2_launch(op, s); break;
             default: rc = SAT_ERR_UNSUPPORTED;
         }
         if (rc != SAT_OK) return rc;

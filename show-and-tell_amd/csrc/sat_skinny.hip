@@ -297,3 +297,13 @@ extern "C" int sat_lstm_step(const float* x, const float* h_in, float* c, const 
     return sat_skinny_lstm(h_in, w_hh, x, w_ih, In, b_ih, b_hh, nullptr, 0, B, H, c, nullptr, 0, nullptr, h_out,
                            nullptr, 0, (hipStream_t)stream);
 }
+
+// one nn.LSTMCell step (model2.py:58 `self.lstmcell(rnn_input, (hidden, c))`): like sat_lstm_step, plus the tapes the
+// backward needs (activated gates i,f,g,o and the new cell state), both optional
+extern "C" int sat_lstmcell_fwd(const float* x, const float* h_in, float* c, const float* w_ih, const float* w_hh,
+                                const float* b_ih, const float* b_hh, int B, int In, int H, float* h_out,
+                                float* gates /*[B,4H] or NULL*/, float* c_tape /*[B,H] or NULL*/, sat_stream_t stream) {
+    if (!x || !h_in || !c || !w_ih || !w_hh || !h_out || B < 1) return SAT_ERR_ARG;
+    return sat_skinny_lstm(h_in, w_hh, x, w_ih, In, b_ih, b_hh, nullptr, 0, B, H, c, gates, 4L * H, c_tape, h_out,
+                           nullptr, 0, (hipStream_t)stream);
+}

@@ -1,0 +1,237 @@
+"""GPU (MI355X): Show-Attend-Tell (`/root/reference/model2.py`, the model train.py:37 constructs) on the HIP path against
+(a) goldens produced by the reference class's own methods (tests/golden/G6, G7), (b) the CPU oracle (`oracle/attend.py`),
+kernel by kernel and end to end."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+sat = importlib.import_module("show-and-tell_amd")
+L = sat._lib
+from oracle import attend as OA  # noqa: E402
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: z[k] for k in z.files}
+
+
+def st():
+    return L.stream()
+
+
+def test_attention_fwd_bwd_kernels_vs_fp64():
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    B, P, C = 5, 196, 512
+    ce, fe = torch.randn(B, P, C, generator=g) * 0.5, torch.randn(B, P, C, generator=g).clamp(min=0)
+    proj, w = torch.randn(B, C, generator=g) * 0.5, torch.randn(C, generator=g) * 0.1
+    dctx = torch.randn(B, C, generator=g)
+    ce64, fe64, pj64, w64 = (t.double().requires_grad_(True) for t in (ce, fe, proj, w))
+    hatt = torch.tanh(ce64 + pj64[:, None, :])
+    alpha = torch.softmax(hatt @ w64, dim=1)
+    ctx = (fe64 * alpha[:, :, None]).mean(1)
+    ctx.backward(dctx.double())
+    d = [t.cuda() for t in (ce, fe, proj, w, dctx)]
+    al, co = torch.empty(B, P, device="cuda"), torch.full((B, C + 8), float("nan"), device="cuda")
+    L.check(lib.sat_attention_fwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), C, d[3].data_ptr(), B, P, C, al.data_ptr(),
+                                  co.data_ptr() + 16, C + 8, st()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(al.cpu().numpy(), alpha.detach().numpy(), rtol=0, atol=2e-7)
+    np.testing.assert_allclose(co[:, 4:4 + C].cpu().numpy(), ctx.detach().numpy(), rtol=0, atol=2e-7)
+    assert torch.isnan(co[:, :4]).all() and torch.isnan(co[:, 4 + C:]).all()          # strided destination: nothing else written
+    dce = torch.ones(B, P, C, device="cuda")                                           # accumulates INTO the buffer
+    dpj, dwp = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+    L.check(lib.sat_attention_bwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), C, d[3].data_ptr(), al.data_ptr(), d[4].data_ptr(), C,
+                                  B, P, C, dce.data_ptr(), dpj.data_ptr(), dwp.data_ptr(), st()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dce.cpu().numpy() - 1.0, ce64.grad.numpy(), rtol=0, atol=3e-7)
+    np.testing.assert_allclose(dpj.cpu().numpy(), pj64.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dwp.sum(0).cpu().numpy(), w64.grad.numpy(), rtol=1e-4, atol=1e-6)
+    assert lib.sat_attention_fwd(None, None, None, C, None, B, P, C, None, None, C, st()) == 1001
+
+
+@pytest.mark.parametrize("dtype", [L.SAT_F32, L.SAT_BF16])
+def test_maxpool2_and_row_utilities(dtype):
+    lib = L.load()
+    td = torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 6, 10, 16, generator=g).to(td)
+    xd, out = x.cuda(), torch.empty(3, 3, 5, 16, device="cuda", dtype=td)
+    o = L.SatOp()
+    o.kind, o.dtype = L.OP_MAXPOOL2, dtype
+    o.in0, o.out = xd.data_ptr(), out.data_ptr()
+    o.N, o.Hin, o.Win, o.Cout = 3, 6, 10, 16
+    import ctypes as C
+    L.check(lib.sat_run_ops(C.pointer(o), 1, st()))
+    ref = F.max_pool2d(x.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(out.float().cpu(), ref)
+    if dtype == L.SAT_BF16:
+        return
+    table, ids = torch.randn(50, 12, generator=g), torch.randint(0, 50, (7, 3), generator=g)
+    td_, idd = table.cuda(), ids.cuda()
+    dst = torch.zeros(7, 20, device="cuda")
+    L.check(lib.sat_rows_copy(td_.data_ptr(), 12, idd.data_ptr() + 8, 3, 50, 7, 12, dst.data_ptr() + 16, 20, st()))
+    assert torch.equal(dst[:, 4:16].cpu(), table[ids[:, 1]]) and float(dst[:, :4].abs().sum()) == 0
+    a, b = torch.randn(7, 12, generator=g), torch.randn(7, 12, generator=g)
+    ad, bd, od = a.cuda(), b.cuda(), torch.empty(7, 12, device="cuda")
+    L.check(lib.sat_rows_add(ad.data_ptr(), 12, bd.data_ptr(), 12, 7, 12, od.data_ptr(), 12, st()))
+    assert torch.equal(od.cpu(), a + b)
+    acc = torch.ones(12, device="cuda")
+    L.check(lib.sat_rows_sum(ad.data_ptr(), 12, 7, 12, acc.data_ptr(), 1, st()))
+    np.testing.assert_allclose(acc.cpu().numpy(), (1 + a.double().sum(0)).numpy(), rtol=1e-6)
+    rows, tok = torch.randn(40, 8, generator=g), torch.randint(0, 9, (40,), generator=g)
+    rd, tkd, tab = rows.cuda(), tok.cuda(), torch.full((9, 8), float("nan"), device="cuda")
+    L.check(lib.sat_scatter_rows_add(rd.data_ptr(), tkd.data_ptr(), 40, 8, 9, tab.data_ptr(), st()))
+    np.testing.assert_allclose(tab.cpu().double().numpy(), torch.zeros(9, 8, dtype=torch.float64).index_add_(0, tok, rows.double()).numpy(), atol=1e-5)
+
+
+def _model_from_golden(g):
+    hidden, context, vocab, embed, B, T, P, feat = [int(x) for x in g["dims"]]
+    params = OA.init_attend_params(hidden, context, vocab, embed, generator=torch.Generator().manual_seed(int(g["seed"])), feat=feat)
+    cfg = [8, "M", feat]                     # a tiny stand-in conv stack ending in `feat` channels (the goldens pin the decoder half)
+    model = sat.ShowAttendTellModel(hidden, context, vocab, embed, None, feature_size=(P, feat), compute_dtype="f32", vgg_cfg=cfg)
+    model.load_state_dict(params, strict=False)
+    return model.cuda(), params, (hidden, context, vocab, embed, B, T, P, feat)
+
+
+@pytest.mark.parametrize("name", ["G6_attend_small.npz", "G7_attend_vgg_dims.npz"])
+def test_attend_decoder_matches_reference_goldens(golden_dir, name):
+    """train.py:134-144 on the decoder half: logits, CE (within 1e-4), every gradient, and the 20-step greedy ids bit-exact"""
+    g = load(golden_dir, name)
+    model, params, (hidden, context, vocab, embed, B, T, P, feat) = _model_from_golden(g)
+    feats = torch.from_numpy(g["features"]).cuda()
+    caps = torch.from_numpy(g["captions"]).cuda()
+    lengths = [int(x) for x in g["lengths"]]
+    targets, l1 = sat.pack_targets(caps, lengths)
+    assert np.array_equal(targets.cpu().numpy(), g["targets"])
+    model.zero_grad()
+    out = model.decode(feats, feats.mean(1), caps[:, :-1], l1)
+    if "argmax" in g:
+        np.testing.assert_allclose(out[:, :64].detach().cpu().numpy(), g["logits"], rtol=0, atol=2e-5)
+        assert np.array_equal(out.argmax(1).cpu().numpy(), g["argmax"])
+    else:
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g["logits"], rtol=0, atol=2e-5)
+    loss = torch.nn.CrossEntropyLoss()(out, targets)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in params:
+        got = named[k].grad.cpu()
+        if "grad." + k in g:
+            np.testing.assert_allclose(got.numpy(), g["grad." + k], rtol=2e-3, atol=2e-7, err_msg=k)
+        else:
+            assert abs(got.double().norm().item() - float(g["gradnorm." + k])) < 2e-3 * float(g["gradnorm." + k]) + 1e-8, k
+            gk = got.flatten()
+            np.testing.assert_allclose(gk[::max(1, gk.numel() // 512)][:512].numpy(), g["gradsample." + k], rtol=2e-3, atol=2e-7, err_msg=k)
+    assert all(p.grad is None for p in model.encoder.parameters())           # frozen (model2.py:17)
+    ids0 = model.sample_features(feats, None)
+    assert np.array_equal(ids0.cpu().numpy(), g["sample_ids_zero_state"])
+    h0, c0 = OA.init_lstm(params, torch.from_numpy(g["features"]))
+    ids1 = model.sample_features(feats, (h0.cuda(), c0.cuda()))
+    assert np.array_equal(ids1.cpu().numpy(), g["sample_ids_init_state"])
+    assert np.array_equal(model.sample_features(feats, torch.stack([h0, c0]).cuda()).cpu().numpy(), g["sample_ids_init_state"])   # eval.py:89
+
+
+SMALL_VGG = [16, 16, "M", 32, "M", 64, 64, "M", 64]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_vgg_stack_vs_oracle(dtype):
+    g = torch.Generator().manual_seed(9)
+    vp = OA.init_vgg_params(g, cfg=SMALL_VGG)
+    model = sat.ShowAttendTellModel(64 + 32, 64, 100, 32, None, feature_size=(16, 64), compute_dtype=dtype, vgg_cfg=SMALL_VGG)
+    model.load_state_dict(vp, strict=False)
+    model.cuda()
+    x = torch.randn(5, 3, 32, 32, generator=g)
+    feats, fmean = model._encode(x.cuda())
+    ref = OA.vgg_forward(vp, x, cfg=SMALL_VGG)
+    assert feats.shape == ref.shape == (5, 16, 64)
+    if dtype == "f32":
+        np.testing.assert_allclose(feats.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    else:
+        ref_bf = OA.vgg_forward(vp, x, cfg=SMALL_VGG, bf16_storage=True)
+        assert ((feats.cpu() - ref_bf).norm() / ref_bf.norm()).item() < 0.01
+        assert ((feats.cpu() - ref).norm() / ref.norm()).item() < 0.03
+    np.testing.assert_allclose(fmean.cpu().numpy(), feats.mean(1).cpu().numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.timeout(900)
+def test_vgg16_full_stack_f32_and_bf16_vs_oracle_224():
+    """the real 12-conv `features[:-3]` at 224x224 (batch 2): [B,196,512] features, f32 MFMA vs the CPU oracle; bf16 vs the
+    bf16-storage oracle"""
+    g = torch.Generator().manual_seed(10)
+    vp = OA.init_vgg_params(g)
+    x = torch.randn(2, 3, 224, 224, generator=g)
+    ref = OA.vgg_forward(vp, x)
+    ref_bf = OA.vgg_forward(vp, x, bf16_storage=True)
+    for dtype in ("f32", "bf16"):
+        model = sat.ShowAttendTellModel(1024, 512, 1000, 512, None, compute_dtype=dtype)
+        model.load_state_dict(vp, strict=False)
+        model.cuda()
+        feats, _ = model._encode(x.cuda())
+        assert feats.shape == (2, 196, 512)
+        if dtype == "f32":
+            assert (feats.cpu() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+        else:
+            r = ((feats.cpu() - ref_bf).norm() / ref_bf.norm()).item()
+            print("VGG16 bf16 vs bf16-storage oracle rel-L2 %.4f (vs f32 oracle %.4f)" % (r, ((feats.cpu() - ref).norm() / ref.norm()).item()))
+            assert r < 0.02
+
+
+def test_full_model_drop_in_training_loop_and_sample():
+    """model(images, captions, lengths) / CE / loss.backward() / clamp / torch Adam exactly as train.py:134-146 drives the model
+    it constructs at train.py:37, then model.sample(images, state) as eval.py:99; f32 mode against the oracle end to end"""
+    g = torch.Generator().manual_seed(12)
+    hidden, embed, vocab, B, T = 64 + 32, 32, 120, 6, 9
+    vp = OA.init_vgg_params(g, cfg=SMALL_VGG)
+    dp = OA.init_attend_params(hidden, 64, vocab, embed, generator=g, feat=64)
+    model = sat.ShowAttendTellModel(hidden, 64, vocab, embed, None, feature_size=(16, 64), compute_dtype="f32", vgg_cfg=SMALL_VGG)
+    sd = dict(vp)
+    sd.update(dp)
+    model.load_state_dict(sd)
+    model.cuda()
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    images = torch.randn(B, 3, 32, 32, generator=g)
+    lengths = [9, 9, 7, 6, 4, 3]
+    caps = torch.zeros(B, T, dtype=torch.long)
+    for b, l in enumerate(lengths):
+        caps[b, 0] = 1
+        caps[b, 1:l - 1] = torch.randint(4, vocab, (l - 2,), generator=g)
+        caps[b, l - 1] = 2
+    feats = OA.vgg_forward(vp, images, cfg=SMALL_VGG)
+    ref_loss, ref_grads, ref_logits = OA.attend_loss_and_grads(dp, feats, caps, lengths)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)      # train.py:55-56
+    assert len(opt.param_groups[0]["params"]) == 19
+    di, dc = images.cuda(), caps.cuda()
+    targets, l1 = sat.pack_targets(dc, lengths)
+    losses = []
+    for it in range(4):
+        model.zero_grad()
+        out = model(di, dc[:, :-1], l1)
+        loss = torch.nn.CrossEntropyLoss()(out, targets)
+        loss.backward()
+        if it == 0:
+            np.testing.assert_allclose(out.detach().cpu().numpy(), ref_logits.numpy(), rtol=0, atol=5e-5)
+            assert abs(loss.item() - ref_loss.item()) < 1e-4
+            named = dict(model.named_parameters())
+            for k in dp:
+                np.testing.assert_allclose(named[k].grad.cpu().numpy(), ref_grads[k].numpy(), rtol=5e-3, atol=5e-7, err_msg=k)
+        for p in opt.param_groups[0]["params"]:
+            p.grad.data.clamp_(-0.1, 0.1)
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    ids = model.eval().sample(di, None)
+    assert ids.shape == (B, 20) and ids.dtype == torch.int64 and int(ids.min()) >= 0 and int(ids.max()) < vocab
+    cur = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith("encoder.")}
+    assert torch.equal(ids.cpu(), OA.attend_sample(cur, feats, None))
+    with pytest.raises(NotImplementedError):
+        model.finetune(allow=True)
+    with pytest.raises(ValueError):
+        sat.ShowAttendTellModel(100, 512, 50, 32)           # hidden != embed + 512
