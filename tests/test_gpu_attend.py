@@ -84,7 +84,7 @@ def test_maxpool2_and_row_utilities(dtype):
     assert torch.equal(od.cpu(), a + b)
     acc = torch.ones(12, device="cuda")
     L.check(lib.sat_rows_sum(ad.data_ptr(), 12, 7, 12, acc.data_ptr(), 1, st()))
-    np.testing.assert_allclose(acc.cpu().numpy(), (1 + a.double().sum(0)).numpy(), rtol=1e-6)
+    np.testing.assert_allclose(acc.cpu().numpy(), (1 + a.double().sum(0)).numpy(), rtol=1e-5, atol=2e-6)
     rows, tok = torch.randn(40, 8, generator=g), torch.randint(0, 9, (40,), generator=g)
     rd, tkd, tab = rows.cuda(), tok.cuda(), torch.full((9, 8), float("nan"), device="cuda")
     L.check(lib.sat_scatter_rows_add(rd.data_ptr(), tkd.data_ptr(), 40, 8, 9, tab.data_ptr(), st()))
