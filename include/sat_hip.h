@@ -288,6 +288,18 @@ int sat_lstmcell_bwd_point(const float* dh_out /*[n,H]*/, const float* dh_carry 
                            float* dc_state /*[n,H]*/, float* DG /*[n,4H]*/, int n, int H, sat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * On-device collate (data_loader.py:48-62 `collate_fn`): the batch arrives in dataset order -- images
+ * [B][3*H*W] f32 and ragged captions (flat ids + offsets[B+1]) already in HBM; `order[r]` [device int32] is the sample that
+ * lands in row r (decreasing caption length, ties in dataset order: the host derives it from the host-side lengths, which
+ * it needs anyway for the packed-sequence bookkeeping).
+ * sat_collate_captions: out[r][t] = t < len(order[r]) ? flat[offsets[order[r]] + t] : 0   (the zero-padded LongTensor)
+ * sat_gather_rows_f32:  out row r = in row order[r]                                          (torch.stack in sorted order)
+ */
+int sat_collate_captions(const int64_t* flat, const int64_t* offsets /*[B+1]*/, const int32_t* order /*[B]*/, int B, int Tmax,
+                         int64_t* out /*[B][Tmax]*/, sat_stream_t stream);
+int sat_gather_rows_f32(const float* in, const int32_t* order, int rows, int64_t cols, float* out, sat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Beam decode (the reference has only a stub, model2.py:113-114, next to the greedy loop
  * models.py:56-67).  Rows are (image b, hypothesis k) = b*K + k, K <= 8.
  * sat_beam_step: candidates (k, v) score scores_in[b,k] + log_softmax(logits[b*K+k])[v]; the best K of the K*V per

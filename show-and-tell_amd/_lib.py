@@ -92,6 +92,8 @@ SIGNATURES = {
     "sat_pack_tokens": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp, _vp]),
     "sat_scatter_rows_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_lstmcell_bwd_point": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "sat_collate_captions": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "sat_gather_rows_f32": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
     "sat_beam_step": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_beam_step_ws_bytes": (_i64, [_i, _i]),
     "sat_beam_gather_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -245,6 +245,48 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 
 }  // namespace
 
+// On-device collate (data_loader.py:48-62 `collate_fn`): captions arrive ragged (one flat id array + per-sample offsets) in
+// dataset order; `order[r]` = the sample that lands in row r (sorted by decreasing length, ties in dataset order -- computed
+// on the host from the host-side lengths).  out[r][t] = t < len(order[r]) ? flat[offset[order[r]] + t] : 0.
+namespace {
+__global__ __launch_bounds__(256) void collate_captions_kernel(const int64_t* __restrict__ flat, const int64_t* __restrict__ offsets,
+                                                               const int32_t* __restrict__ order, int B, int Tmax,
+                                                               int64_t* __restrict__ out) {
+    const int r = blockIdx.x;
+    const int src = order[r];
+    const int64_t o0 = offsets[src], len = offsets[src + 1] - o0;
+    for (int t = threadIdx.x; t < Tmax; t += blockDim.x) out[(long)r * Tmax + t] = t < len ? flat[o0 + t] : 0;
+}
+// out row r = in row order[r]; rows of `cols` floats, 16 B per lane when aligned
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ order, long cols,
+                                                          float* __restrict__ out) {
+    const long r = blockIdx.y;
+    const float* src = in + (long)order[r] * cols;
+    float* dst = out + r * cols;
+    const long n4 = ((cols & 3) == 0 && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0) ? cols / 4 : 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        ((f32x4*)dst)[i] = ((const f32x4*)src)[i];
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < cols; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int sat_collate_captions(const int64_t* flat, const int64_t* offsets, const int32_t* order, int B, int Tmax,
+                                    int64_t* out, sat_stream_t stream) {
+    if (!flat || !offsets || !order || !out || B < 1 || Tmax < 1) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(collate_captions_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, flat, offsets, order, B, Tmax, out);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_gather_rows_f32(const float* in, const int32_t* order, int rows, int64_t cols, float* out, sat_stream_t stream) {
+    if (!in || !order || !out || rows < 1 || cols < 1 || in == out) return SAT_ERR_ARG;
+    const long per = (cols / 4 + 255) / 256;
+    const int gx = (int)(per < 1 ? 1 : (per > 64 ? 64 : per));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, rows), dim3(256), 0, (hipStream_t)stream, in, order, (long)cols, out);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
 extern "C" int sat_rows_add(const float* a, int64_t lda, const float* b, int64_t ldb, int rows, int cols, float* out, int64_t ldo,
                             sat_stream_t stream) {
     if (!a || !b || !out || rows < 0 || cols < 1 || lda < cols || ldb < cols || ldo < cols) return SAT_ERR_ARG;

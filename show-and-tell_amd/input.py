@@ -24,6 +24,44 @@ def collate_batch(samples, pin_memory=False):
     return images, captions, lengths, tuple(s[2] for s in ordered)
 
 
+def collate_on_device(images, flat_captions, lengths, image_ids=None):
+    """`collate_fn` (data_loader.py:48-62) with the data movement on the MI355X: `images` f32 [B,3,H,W] and the ragged
+    captions (`flat_captions` int64, samples back to back, dataset order) are already in HBM -- e.g. staged by
+    `DevicePrefetcher` -- and `lengths` (host ints, dataset order) say where each caption ends.  Returns the reference's
+    batch: images in decreasing-length order (ties keep dataset order), captions zero-padded [B, max_len], lengths list,
+    image ids tuple.  The order itself is host integer work on lengths the host already holds: no device sync."""
+    from . import _lib as L
+    lib = L.load()
+    L.require_gpu(images, "images")
+    L.require_gpu(flat_captions, "flat_captions")
+    lengths = [int(l) for l in lengths]
+    B = len(lengths)
+    if B == 0 or images.shape[0] != B:
+        raise ValueError("one length per image")
+    if min(lengths) < 1 or sum(lengths) != flat_captions.numel():
+        raise ValueError("lengths must be >= 1 and sum to flat_captions.numel()")
+    if images.dtype != torch.float32 or flat_captions.dtype != torch.int64:
+        raise TypeError("images float32, captions int64")
+    order = sorted(range(B), key=lambda i: -lengths[i])                       # stable: ties keep dataset order
+    offs = [0]
+    for l in lengths:
+        offs.append(offs[-1] + l)
+    dev = images.device
+    order_d = torch.tensor(order, dtype=torch.int32, device=dev)
+    offs_d = torch.tensor(offs, dtype=torch.int64, device=dev)
+    tmax = lengths[order[0]]
+    caps = torch.empty(B, tmax, dtype=torch.int64, device=dev)
+    images = images.contiguous()
+    out_im = torch.empty_like(images)
+    st = L.stream()
+    L.check(lib.sat_collate_captions(flat_captions.contiguous().data_ptr(), offs_d.data_ptr(), order_d.data_ptr(), B, tmax,
+                                     caps.data_ptr(), st), "sat_collate_captions")
+    L.check(lib.sat_gather_rows_f32(images.data_ptr(), order_d.data_ptr(), B, images[0].numel(), out_im.data_ptr(), st),
+            "sat_gather_rows_f32")
+    ids = tuple(image_ids[i] for i in order) if image_ids is not None else tuple(order)
+    return out_im, caps, [lengths[i] for i in order], ids
+
+
 class DevicePrefetcher:
     """Wraps an iterable of (images, captions, lengths, ...) host batches: yields the same tuples with the two tensors
     resident on `device`; the copy of the next batch runs on a side HIP stream while the caller works on the current

@@ -235,3 +235,19 @@ def test_full_model_drop_in_training_loop_and_sample():
         model.finetune(allow=True)
     with pytest.raises(ValueError):
         sat.ShowAttendTellModel(100, 512, 50, 32)           # hidden != embed + 512
+
+
+def test_collate_on_device_equals_the_reference_collate_contract():
+    """data_loader.py:48-62: sort by caption length (longest first, ties in dataset order), stack, zero-pad -- with the
+    permute / pad done by HIP kernels on tensors already in HBM; must equal the host `collate_batch`"""
+    g = torch.Generator().manual_seed(21)
+    lens = [5, 9, 3, 9, 1, 7, 5]
+    samples = [(torch.randn(3, 8, 10, generator=g), torch.randint(1, 50, (l,), generator=g), "img%d" % i) for i, l in enumerate(lens)]
+    ref_im, ref_caps, ref_len, ref_ids = sat.collate_batch(samples)
+    images = torch.stack([s[0] for s in samples]).cuda()
+    flat = torch.cat([s[1] for s in samples]).cuda()
+    im, caps, ln, ids = sat.collate_on_device(images, flat, lens, [s[2] for s in samples])
+    assert ln == ref_len and ids == ref_ids
+    assert torch.equal(caps.cpu(), ref_caps) and torch.equal(im.cpu(), ref_im)
+    with pytest.raises(ValueError):
+        sat.collate_on_device(images, flat, lens[:-1] + [2])
