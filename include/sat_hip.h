@@ -223,10 +223,22 @@ int sat_vocab_logits_fwd(const float* Hs /*[N,H]*/, const float* w /*[V,H]*/, co
  * d(loss)/d(logits) = (softmax - onehot) * inv_denom. */
 int sat_ce_rows(float* logits /*[N,ldl]*/, int64_t ldl, const int64_t* targets /*[N]*/, int N, int V, float inv_denom,
                 int write_grad, float* row_loss /*[N]*/, float* loss_out /*[1]*/, sat_stream_t stream);
-/* fused: logits + CE (+ in-place grad) */
-int sat_vocab_ce_fwd(const float* Hs, const float* w, const float* b, const int64_t* targets,
-                     int N, int H, int V, float inv_denom, int write_grad,
-                     float* logits, int64_t ldl, float* row_loss, float* loss_out, sat_stream_t stream);
+/* FUSED vocab projection + cross entropy (models.py:53 + train.py:53,143): the projection GEMM's epilogue emits per-row
+ * (max, sum exp) partials next to the logits, a small combine kernel turns them into lse[n] and row_loss[n] = lse - logit[target]
+ * (it reads ONE logit per row), loss_out[0] = inv_denom * sum(row_loss).  The logits are written once and never re-read by
+ * the loss.  Pad columns [V, ldl) are not written (zero-fill the buffer once when ldl > V, as for sat_vocab_logits_fwd). */
+int sat_vocab_ce_fwd(const float* Hs /*[N,H]*/, const float* w /*[V,H]*/, const float* b /*[V]*/, const int64_t* targets /*[N]*/,
+                     int N, int H, int V, float inv_denom, float* logits /*[N,ldl]*/, int64_t ldl, float* lse /*[N] out*/,
+                     float* row_loss /*[N]*/, float* loss_out /*[1] or NULL*/, float* workspace, int64_t ws_bytes, sat_stream_t stream);
+int64_t sat_vocab_ce_fwd_ws_bytes(int N, int V);
+/* ... and its backward (train.py:144) WITHOUT materialising d(loss)/d(logits): both gradient GEMMs form
+ * (softmax - onehot) * inv_denom from the stored logits + lse + targets while loading their operand, and the weight-gradient
+ * GEMM accumulates the bias gradient on the way: the logits make 1 write + 2 reads per step instead of 2 writes + 4 reads.
+ * ldl % 4 == 0, pad columns hold anything (they are masked). */
+int sat_vocab_ce_bwd_fused(const float* logits, int64_t ldl, const float* lse, const int64_t* targets, float inv_denom,
+                           const float* Hs, const float* w, int N, int H, int V, float* dw /*[V,H]*/, float* db /*[V]*/,
+                           float* dHs /*[N,H]*/, float* workspace, int64_t ws_bytes, sat_stream_t stream);
+int64_t sat_vocab_ce_bwd_fused_ws_bytes(int N, int H, int V);
 /* backward of the projection given dlogits: dW[V,H], db[V], dHs[N,H] */
 int sat_vocab_ce_bwd(const float* dlogits /*[N,ldl]*/, int64_t ldl, const float* Hs, const float* w, int N, int H, int V,
                      float* dw, float* db, float* dHs, float* workspace, int64_t ws_bytes, sat_stream_t stream);

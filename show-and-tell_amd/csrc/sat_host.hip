@@ -334,13 +334,6 @@ extern "C" int sat_vocab_logits_fwd(const float* Hs, const float* w, const float
     return sat_gemm_f32(0, 0, Hs, H, w, H, logits, ldl, b, nullptr, N, V, H, stream);
 }
 
-extern "C" int sat_vocab_ce_fwd(const float* Hs, const float* w, const float* b, const int64_t* targets, int N,
-                                int H, int V, float inv_denom, int write_grad, float* logits, int64_t ldl,
-                                float* row_loss, float* loss_out, sat_stream_t stream) {
-    SAT_TRY(sat_vocab_logits_fwd(Hs, w, b, N, H, V, logits, ldl, stream));
-    return sat_ce_rows(logits, ldl, targets, N, V, inv_denom, write_grad, row_loss, loss_out, stream);
-}
-
 static int vocab_bwd_split(int N, int H, int V) {
     // dHs[N,H] = dlogits[N,V] * W[V,H]: K = V is long and M*N small -> deal K over enough slices to fill the chip
     const long tiles = (long)sat_cdiv(N, 64) * sat_cdiv(H, 64);

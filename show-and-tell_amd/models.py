@@ -231,8 +231,10 @@ class _Weight(nn.Module):
             self.bias = nn.Parameter(torch.zeros(bias))
 
 
-def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, captions, pi, logits=None):
-    """embed+cat+pack -> L x LSTM -> vocab logits (models.py:49-53).  Returns (logits, tapes)."""
+def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, captions, pi, logits=None, ce=None):
+    """embed+cat+pack -> L x LSTM -> vocab logits (models.py:49-53).  Returns (logits, tapes).
+    `ce` = dict(targets, inv_denom, lse, row_loss, loss_out, ws): the projection and the cross entropy (train.py:143) run as
+    ONE fused op (`sat_vocab_ce_fwd`: the loss never re-reads the logits)."""
     dev = features.device
     E = embed_w.shape[1]
     V = lin_w.shape[0]
@@ -267,12 +269,17 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
         inp = HS
     if logits is None:
         logits = torch.zeros(N, (V + 3) // 4 * 4, device=dev) if V % 4 else torch.empty(N, V, device=dev)
+    if ce is not None:
+        L.check(lib.sat_vocab_ce_fwd(L.ptr(inp), L.ptr(lin_w), L.ptr(lin_b), L.ptr(ce["targets"]), N, lin_w.shape[1], V,
+                                     float(ce["inv_denom"]), L.ptr(logits), logits.stride(0), L.ptr(ce["lse"]), L.ptr(ce["row_loss"]),
+                                     L.ptr(ce["loss_out"]), L.ptr(ce["ws"]), ce["ws"].numel() * 4, st), "sat_vocab_ce_fwd")
+        return logits, tapes
     L.check(lib.sat_vocab_logits_fwd(L.ptr(inp), L.ptr(lin_w), L.ptr(lin_b), N, lin_w.shape[1], V, L.ptr(logits),
                                      logits.stride(0), st), "sat_vocab_logits_fwd")
     return logits, tapes
 
 
-def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi, grads_out, on_stage=None):
+def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi, grads_out, on_stage=None, ce=None):
     """Backward of decoder_forward_tapes.  `dlogits`: f32 [N, ld] with ld = V rounded up to 4 and zero pad columns.  grads_out: dict name -> preallocated f32 tensor to fill:
     'embed', ('w_ih',l), ('w_hh',l), ('b_ih',l), ('b_hh',l), 'lin_w', 'lin_b', 'features'.
     on_stage(i) is called when gradient group i is final (0 vocab projection, 1 LSTM) -- the data-parallel
@@ -283,10 +290,18 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
     V, Hl = lin_w.shape
     Xtop = tapes["X"][-1]
     dH = torch.empty(N, Hl, device=dev)
-    vwsb = lib.sat_vocab_ce_bwd_ws_bytes(N, Hl, V)
-    vws = torch.empty(max(vwsb // 4, 4), device=dev)
-    L.check(lib.sat_vocab_ce_bwd(L.ptr(dlogits), dlogits.stride(0), L.ptr(Xtop), L.ptr(lin_w), N, Hl, V, L.ptr(grads_out["lin_w"]),
-                                 L.ptr(grads_out["lin_b"]), L.ptr(dH), L.ptr(vws), vwsb, st), "sat_vocab_ce_bwd")
+    if ce is not None:
+        # `dlogits` holds the LOGITS: d(loss)/d(logits) is formed inside the two gradient GEMMs' operand loads (never stored)
+        vwsb = lib.sat_vocab_ce_bwd_fused_ws_bytes(N, Hl, V)
+        vws = torch.empty(max(vwsb // 4, 4), device=dev)
+        L.check(lib.sat_vocab_ce_bwd_fused(L.ptr(dlogits), dlogits.stride(0), L.ptr(ce["lse"]), L.ptr(ce["targets"]), float(ce["inv_denom"]),
+                                           L.ptr(Xtop), L.ptr(lin_w), N, Hl, V, L.ptr(grads_out["lin_w"]), L.ptr(grads_out["lin_b"]),
+                                           L.ptr(dH), L.ptr(vws), vwsb, st), "sat_vocab_ce_bwd_fused")
+    else:
+        vwsb = lib.sat_vocab_ce_bwd_ws_bytes(N, Hl, V)
+        vws = torch.empty(max(vwsb // 4, 4), device=dev)
+        L.check(lib.sat_vocab_ce_bwd(L.ptr(dlogits), dlogits.stride(0), L.ptr(Xtop), L.ptr(lin_w), N, Hl, V, L.ptr(grads_out["lin_w"]),
+                                     L.ptr(grads_out["lin_b"]), L.ptr(dH), L.ptr(vws), vwsb, st), "sat_vocab_ce_bwd")
     if on_stage is not None:
         on_stage(0)
     for l in reversed(range(len(lstm_layers))):

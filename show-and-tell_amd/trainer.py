@@ -20,6 +20,16 @@ from .models import BN1D_MOMENTUM, BN_EPS, ShowAndTell, decoder_backward_tapes, 
 from .pack import PackInfo
 
 
+import os as _os
+
+# SAT_FUSED_CE=1: projection + CE as ONE op (sat_vocab_ce_fwd: the loss never re-reads the logits) and a backward that never
+# materialises d(loss)/d(logits) (sat_vocab_ce_bwd_fused).  Built, parity-tested and measured -- and OFF by default: at cfg 2
+# the 48.6 MB of logits live in the 256 MB Infinity Cache, so the passes the fusion removes cost ~10 us each (ce_rows 23 us,
+# colsum 15 us), while exp() in the epilogue / operand path costs the three GEMMs +65 / +113 / +49 us (6.94 vs 6.70 ms/step,
+# profiles/r02_fused_ce_ab.txt).  Default: logits -> sat_ce_rows (gradient in place) -> sat_vocab_ce_bwd.
+_FUSED_CE = _os.environ.get("SAT_FUSED_CE", "0") == "1"
+
+
 def lr_for_epoch(epoch, learning_rate=1e-3, decay_start=1, decay_every=3, decay_rate=0.8):
     """Epoch step decay of the reference trainer (train.py:101-107; defaults config.py:38-46)."""
     if epoch > decay_start and decay_start >= 1:
@@ -124,7 +134,8 @@ class TrainStep:
             wsb = lib.sat_fc_bn1d_ws_bytes(B, F, E)
             bufs = self._bufs[key] = dict(
                 targets=torch.empty(N, dtype=torch.int64, device=dev), logits=torch.zeros(N, (V + 3) // 4 * 4, device=dev),
-                row_loss=torch.empty(N, device=dev), feats=torch.empty(B, E, device=dev),
+                row_loss=torch.empty(N, device=dev), lse=torch.empty(N, device=dev),
+                ce_ws=torch.empty(max(lib.sat_vocab_ce_fwd_ws_bytes(N, V) // 4, 4), device=dev), feats=torch.empty(B, E, device=dev),
                 xhat=torch.empty(B, E, device=dev), rstd=torch.empty(E, device=dev),
                 head_ws=torch.empty(max(wsb // 4, B * E), device=dev), d_feat=torch.empty(B, E, device=dev))
         # targets = pack(captions[:,1:], lengths-1)                           train.py:135
@@ -146,12 +157,17 @@ class TrainStep:
             bn.num_batches_tracked += 1
             feats_in = bufs["feats"]
         layers = [dec.lstm.layer(l) for l in range(dec.num_layers)]
-        logits, tapes = decoder_forward_tapes(lib, feats_in, dec.embed.weight, layers, dec.linear.weight,
-                                              dec.linear.bias, captions[:, :-1], pi, logits=bufs["logits"])
-        # ---- loss + d(loss)/d(logits) in place (train.py:143) ----
         loss_slot = flat.grads[flat.loss_slot:flat.loss_slot + 1]
-        L.check(lib.sat_ce_rows(L.ptr(logits), logits.stride(0), L.ptr(bufs["targets"]), N, V, float(inv_denom), 1,
-                                L.ptr(bufs["row_loss"]), L.ptr(loss_slot), st), "sat_ce_rows")
+        ce = None
+        if _FUSED_CE:          # projection + CE as one op; the backward forms d(loss)/d(logits) inside its GEMMs
+            ce = dict(targets=bufs["targets"], inv_denom=inv_denom, lse=bufs["lse"], row_loss=bufs["row_loss"], loss_out=loss_slot,
+                      ws=bufs["ce_ws"])
+        logits, tapes = decoder_forward_tapes(lib, feats_in, dec.embed.weight, layers, dec.linear.weight,
+                                              dec.linear.bias, captions[:, :-1], pi, logits=bufs["logits"], ce=ce)
+        if ce is None:
+            # ---- loss + d(loss)/d(logits) in place (train.py:143) ----
+            L.check(lib.sat_ce_rows(L.ptr(logits), logits.stride(0), L.ptr(bufs["targets"]), N, V, float(inv_denom), 1,
+                                    L.ptr(bufs["row_loss"]), L.ptr(loss_slot), st), "sat_ce_rows")
         # ---- backward (train.py:144): gradients land directly in the flat buffer ----
         g = {"embed": flat.grad("decoder.embed.weight"), "lin_w": flat.grad("decoder.linear.weight"),
              "lin_b": flat.grad("decoder.linear.bias"), "features": bufs["d_feat"]}
@@ -159,7 +175,7 @@ class TrainStep:
             for short, n in (("w_ih", "weight_ih"), ("w_hh", "weight_hh"), ("b_ih", "bias_ih"), ("b_hh", "bias_hh")):
                 g[(short, l)] = flat.grad("decoder.lstm.%s_l%d" % (n, l))
         decoder_backward_tapes(lib, logits, tapes, dec.embed.weight, layers, dec.linear.weight, pi, g,
-                               on_stage=on_bucket_ready)
+                               on_stage=on_bucket_ready, ce=ce)
         if not cached_features:
             fc, bn = enc.resnet.fc, enc.bn
             L.check(lib.sat_fc_bn1d_bwd(L.ptr(bufs["d_feat"]), L.ptr(pooled), L.ptr(bufs["xhat"]), L.ptr(bufs["rstd"]),

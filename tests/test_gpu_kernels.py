@@ -703,3 +703,49 @@ def test_lstm_fwd_persistent_equals_per_step_launches(lib, B, T, In, H, ragged, 
         c = torch.cat([f * c[:n] + i * gg, c[n:]])
         h = torch.cat([o * c[:n].tanh(), h[n:]])
         np.testing.assert_allclose(pers[2][pi.prefix[t]:pi.prefix[t] + n].double().numpy(), h[:n].numpy(), rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("N,H,V", [(1216, 512, 10000), (76, 64, 500), (33, 32, 1003), (200, 128, 130)])
+def test_fused_vocab_ce_fwd_and_bwd_vs_fp64(lib, N, H, V):
+    """sat_vocab_ce_fwd (GEMM epilogue emits per-row max / sum-exp partials, combine kernel -> lse, loss) and
+    sat_vocab_ce_bwd_fused (softmax gradient formed in the GEMMs' operand loads; bias gradient accumulated in the dW GEMM)
+    against fp64 softmax cross entropy and its gradients; V not a multiple of 4 / of the tile, N below one tile"""
+    g = torch.Generator().manual_seed(N + V)
+    Hs = torch.randn(N, H, generator=g) * 0.5
+    W = torch.empty(V, H).uniform_(-0.1, 0.1, generator=g)
+    b = torch.randn(V, generator=g) * 0.1
+    tg = torch.randint(0, V, (N,), generator=g)
+    inv = 1.0 / N
+    Hd, Wd, bd, tgd = cu(Hs), cu(W), cu(b), cu(tg)
+    ldl = (V + 3) // 4 * 4
+    logits = torch.zeros(N, ldl, device="cuda")
+    lse, rl, lo = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(1, device="cuda")
+    wsb = lib.sat_vocab_ce_fwd_ws_bytes(N, V)
+    ws = torch.empty(wsb // 4, device="cuda")
+    assert lib.sat_vocab_ce_fwd(L.ptr(Hd), L.ptr(Wd), L.ptr(bd), L.ptr(tgd), N, H, V, inv, L.ptr(logits), ldl, L.ptr(lse), L.ptr(rl),
+                                L.ptr(lo), L.ptr(ws), 16, st()) == 1002
+    L.check(lib.sat_vocab_ce_fwd(L.ptr(Hd), L.ptr(Wd), L.ptr(bd), L.ptr(tgd), N, H, V, inv, L.ptr(logits), ldl, L.ptr(lse), L.ptr(rl),
+                                 L.ptr(lo), L.ptr(ws), wsb, st()))
+    sync()
+    Hq, Wq = Hs.double().requires_grad_(True), W.double().requires_grad_(True)
+    bq = b.double().requires_grad_(True)
+    ref_logits = Hq @ Wq.t() + bq
+    ref_lse = torch.logsumexp(ref_logits, 1)
+    ref_rows = ref_lse - ref_logits[torch.arange(N), tg]
+    loss = ref_rows.sum() * inv
+    loss.backward()
+    np.testing.assert_allclose(logits[:, :V].cpu().numpy(), ref_logits.detach().numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(lse.cpu().numpy(), ref_lse.detach().numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(rl.cpu().numpy(), ref_rows.detach().numpy(), rtol=0, atol=1e-5)
+    assert abs(lo.item() - loss.item()) < 2e-6
+    if ldl > V:
+        assert float(logits[:, V:].abs().sum()) == 0.0
+    dw, db, dH = torch.full((V, H), float("nan"), device="cuda"), torch.full((V,), float("nan"), device="cuda"), torch.full((N, H), float("nan"), device="cuda")
+    bwsb = lib.sat_vocab_ce_bwd_fused_ws_bytes(N, H, V)
+    bws = torch.empty(max(bwsb // 4, 4), device="cuda")
+    L.check(lib.sat_vocab_ce_bwd_fused(L.ptr(logits), ldl, L.ptr(lse), L.ptr(tgd), inv, L.ptr(Hd), L.ptr(Wd), N, H, V, L.ptr(dw), L.ptr(db),
+                                       L.ptr(dH), L.ptr(bws), bwsb, st()))
+    sync()
+    np.testing.assert_allclose(dw.cpu().numpy(), Wq.grad.numpy(), rtol=1e-4, atol=2e-8)
+    np.testing.assert_allclose(db.cpu().numpy(), bq.grad.numpy(), rtol=1e-4, atol=2e-8)
+    np.testing.assert_allclose(dH.cpu().numpy(), Hq.grad.numpy(), rtol=1e-4, atol=2e-8)
