@@ -267,7 +267,8 @@ int sat_embed_rows(const float* embed, const int64_t* ids, int64_t ids_stride, i
  *   ctx_enc, feats: [rows][P][C] (context_encode / features, model2.py:45-46); proj = weight_hh(hidden) [rows][ld_proj];
  *   alpha [rows][P] (nullable); context [rows][ld_ctx] (ld_ctx lets it land inside the LSTMCell input row).
  * sat_attention_bwd: its backward given d_context (h_att recomputed): d_ctx_enc[rows][P][C] += ..., d_proj [rows][C],
- *   d_watt_part [rows][C] (sum over rows = d weight_att; kept per row for a fixed-order reduction).
+ *   d_watt_part [rows][C] (sum over rows = d weight_att; kept per row for a fixed-order reduction); d_feats (fine-tuning only):
+ *   the gradient the weighted mean sends back into the features, accumulated.
  * sat_lstmcell_fwd: one nn.LSTMCell step (model2.py:58), c in place, optional tapes (activated gates, new c).
  * sat_rows_copy: out[r] = in[idx ? idx[r*idx_stride] : r] (embedding rows into a strided destination, state slices).
  * sat_rows_sum: out[c] (+)= sum_r in[r][c] in fixed order.
@@ -276,7 +277,8 @@ int sat_attention_fwd(const float* ctx_enc, const float* feats, const float* pro
                       int rows, int P, int C, float* alpha, float* context, int64_t ld_ctx, sat_stream_t stream);
 int sat_attention_bwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
                       const float* alpha, const float* d_ctx, int64_t ld_dctx, int rows, int P, int C,
-                      float* d_ctx_enc, float* d_proj, float* d_watt_part, sat_stream_t stream);
+                      float* d_ctx_enc, float* d_proj, float* d_watt_part, float* d_feats /*[rows][P][C] += , or NULL*/,
+                      sat_stream_t stream);
 int sat_lstmcell_fwd(const float* x /*[B,In]*/, const float* h_in /*[B,H]*/, float* c /*[B,H] in place*/, const float* w_ih,
                      const float* w_hh, const float* b_ih, const float* b_hh, int B, int In, int H, float* h_out,
                      float* gates /*[B,4H] or NULL*/, float* c_tape /*[B,H] or NULL*/, sat_stream_t stream);
@@ -298,6 +300,22 @@ int sat_scatter_rows_add(const float* rows /*[N,E]*/, const int64_t* ids /*[N]*/
 int sat_lstmcell_bwd_point(const float* dh_out /*[n,H]*/, const float* dh_carry /*[>=n_carry,H] or NULL*/, int n_carry,
                            const float* gates /*[n,4H]*/, const float* c /*[n,H]*/, const float* c_prev /*[n,H] or NULL*/,
                            float* dc_state /*[n,H]*/, float* DG /*[n,4H]*/, int n, int H, sat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conv-stack backward for fine-tuning (model2.py:87-89 `finetune(allow=True)`), f32 NHWC.  A 3x3/s1/p1 conv layer
+ * y = relu(conv(x, W) + b) is differentiated with the kernels the forward already has:
+ *   dZp = sat_pad_nhwc_f32(dY, mask = y)          zero-bordered d(pre-activation)               [N][H+2][W+2][Cout]
+ *   db  = sat_colsum_f32(dZp)                     (the border rows are zeros)
+ *   dW[:, kh, kw, :] = dZp^T . shift(Xp, kh, kw)  nine sat_gemm_f32_splitk (amode 2, bmode 1) over the flat padded pixel index:
+ *                                                 with BOTH operands in the zero-bordered layout a tap is a constant flat offset
+ *   dX  = SAT_OP_CONV(dZp as a pre-padded image, W flipped and transposed)                       (the forward conv kernel)
+ * sat_maxpool2_bwd_f32: gradient of SAT_OP_MAXPOOL2 (first maximum in scan order, torch's tie rule).
+ * sat_bcast_add_f32: out[b][p][:] += scale * v[b][:] (backward of the mean over positions, model2.py:68).
+ */
+int sat_pad_nhwc_f32(const float* in, const float* relu_mask_of /*or NULL*/, int N, int H, int W, int C, int pad, float* out,
+                     sat_stream_t stream);
+int sat_maxpool2_bwd_f32(const float* x, const float* dy, int N, int Hin, int Win, int C, float* dx, sat_stream_t stream);
+int sat_bcast_add_f32(const float* v, int B, int P, int C, float scale, float* out, sat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-device collate (data_loader.py:48-62 `collate_fn`): the batch arrives in dataset order -- images

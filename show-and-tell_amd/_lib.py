@@ -87,7 +87,10 @@ SIGNATURES = {
     "sat_lstm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_embed_rows": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "sat_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
-    "sat_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sat_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sat_pad_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sat_maxpool2_bwd_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sat_bcast_add_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "sat_lstmcell_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "sat_rows_copy": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _vp, _i64, _vp]),
     "sat_rows_sum": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp]),

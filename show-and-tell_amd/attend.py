@@ -8,7 +8,9 @@
                sat_attention_fwd (tanh / softmax / weighted mean, model2.py:73-78), sat_lstmcell_fwd (model2.py:58);
                output_layer batched over all packed rows after the loop (model2.py:80-85)
     backward : hand-written (sat_attention_bwd, LSTMCell BPTT, batched weight-gradient GEMMs) behind torch.autograd, so
-               `loss.backward()` (train.py:144) works unchanged; `finetune(allow=True)` (conv backward) is not built.
+               `loss.backward()` (train.py:144) works unchanged; `finetune(allow=True)` (model2.py:87-89) adds the conv-stack
+               backward (f32 mode): dgrad = the forward conv kernel on flipped weights, wgrad = split-K GEMMs over the flat
+               zero-bordered pixel index, ReLU mask / max-pool routing kernels.
 
 state_dict keys equal the reference's: `encoder.{0,2,5,...}.weight/bias`, `image_att_w`, `init_hidden.*`, `init_memory.*`,
 `weight_hh.*`, `weight_att`, `embedding.weight`, `lstmcell.{weight_ih,weight_hh,bias_ih,bias_hh}`, `context2out.*`,
@@ -63,7 +65,7 @@ class VggProgram:
     features f32 [N, P, C] (model2.py:44-45's view + transpose is the NHWC flattening) and their mean over P."""
 
     def __init__(self, stack, N, H, W, dtype, device):
-        self.N, self.H, self.W, self.dtype = N, H, W, dtype
+        self.N, self.H, self.W, self.dtype, self.stack = N, H, W, dtype, stack
         td = torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
         ch = 8 if dtype == L.SAT_BF16 else 4
         self.keep, ops = [], []
@@ -83,6 +85,7 @@ class VggProgram:
         ops.append(o)
         x, h, w, c = self.img_pad, H, W, cpad
         first = True
+        self.layers, self.run_id = [], 0            # (kind, ...) in forward order: the tapes of the backward
         ones = {}
         convs = iter(stack.convs())
         for v in stack.cfg:
@@ -93,6 +96,7 @@ class VggProgram:
                 o.in0, o.out = x.data_ptr(), out.data_ptr()
                 o.N, o.Hin, o.Win, o.Cout = N, h, w, c
                 ops.append(o)
+                self.layers.append(("pool", x, out, h, w, c))
                 x, h, w = out, h // 2, w // 2
                 continue
             conv = next(convs)
@@ -131,6 +135,7 @@ class VggProgram:
                 a.in0, a.out, a.scale0, a.shift0 = raw.data_ptr(), out.data_ptr(), ones[v].data_ptr(), bias.data_ptr()
                 a.N, a.Hout, a.Wout, a.Cout = N, h, w, v
                 ops.append(a)
+            self.layers.append(("conv", conv, x, out, h, w, cin, v, first))
             x, c, first = out, v, False
         self.P, self.C = h * w, c
         self.fmap = x
@@ -157,10 +162,86 @@ class VggProgram:
         lib = L.load()
         self.ops[0].in0 = images.data_ptr()
         L.check(lib.sat_run_ops(self.ops, self.n_ops, L.stream()), "sat_run_ops")
+        self.run_id += 1
         if self.dtype == L.SAT_BF16:
             L.check(lib.sat_cast_bf16_f32(self.fmap.data_ptr(), self.features.data_ptr(), self.features.numel(), L.stream()),
                     "sat_cast_bf16_f32")
         return self.features, self.fmean
+
+
+def _vgg_backward(self, d_feats, d_fmean):
+    """Gradient of the conv stack (f32 NHWC): per 3x3 conv layer the zero-bordered d(pre-activation) (`sat_pad_nhwc_f32` with the
+    ReLU mask), the bias gradient (`sat_colsum_f32`), nine split-K GEMMs over the flat padded pixel index for the weight
+    gradient, and the forward conv kernel on flipped weights for the input gradient; `sat_maxpool2_bwd_f32` for the pools.
+    Returns [dW, db] per conv in forward order (parameter layout)."""
+    if self.dtype != L.SAT_F32:
+        raise NotImplementedError("fine-tuning the conv stack runs in the f32 parity mode (compute_dtype='f32')")
+    lib, st = L.load(), L.stream()
+    N = self.N
+    dev = d_feats.device
+    dY = d_feats.contiguous().clone()                     # [N, P, C] == NHWC of the last map
+    if d_fmean is not None:                               # fmean = mean over positions (model2.py:68)
+        L.check(lib.sat_bcast_add_f32(d_fmean.contiguous().data_ptr(), N, self.P, self.C, 1.0 / self.P, dY.data_ptr(), st), "sat_bcast_add_f32")
+    grads = {}
+    for layer in reversed(self.layers):
+        if layer[0] == "pool":
+            _, x, out, h, w, c = layer
+            dX = torch.empty_like(x)
+            L.check(lib.sat_maxpool2_bwd_f32(x.data_ptr(), dY.data_ptr(), N, h, w, c, dX.data_ptr(), st), "sat_maxpool2_bwd_f32")
+            dY = dX
+            continue
+        _, conv, x, out, h, w, cin, cout, first = layer
+        hp, wp = h + 2, w + 2
+        npix = N * hp * wp
+        dZp = torch.empty(npix, cout, device=dev)
+        L.check(lib.sat_pad_nhwc_f32(dY.data_ptr(), out.data_ptr(), N, h, w, cout, 1, dZp.data_ptr(), st), "sat_pad_nhwc_f32")
+        db = torch.empty(cout, device=dev)
+        L.check(lib.sat_colsum_f32(dZp.data_ptr(), cout, npix, cout, db.data_ptr(), st), "sat_colsum_f32")
+        # zero-bordered input with a margin of one padded row (+1 pixel) at both ends: a tap is a constant flat offset
+        margin = wp + 1
+        Xp = torch.zeros(npix + 2 * margin, cin, device=dev)
+        inner = Xp.data_ptr() + margin * cin * 4
+        if first:                                         # the stem's input is the already padded image
+            L.check(lib.sat_rows_copy(x.data_ptr(), cin, None, 0, npix, npix, cin, inner, cin, st), "sat_rows_copy")
+        else:
+            L.check(lib.sat_pad_nhwc_f32(x.data_ptr(), None, N, h, w, cin, 1, inner, st), "sat_pad_nhwc_f32")
+        tiles = ((cout + 63) // 64) * ((cin + 63) // 64)
+        ks = max(1, min(64, 512 // tiles, npix // 256))
+        slab = cout * cin
+        wsl = torch.empty(ks * slab, device=dev)
+        tap_out = torch.empty(cout, cin, device=dev)
+        dWk = torch.empty(cout, 9 * cin, device=dev)
+        for kh in range(3):
+            for kw in range(3):
+                shift = (kh - 1) * wp + (kw - 1)
+                L.check(lib.sat_gemm_f32_splitk(2, 1, dZp.data_ptr(), cout, inner + shift * cin * 4, cin, wsl.data_ptr(), cin, None, None,
+                                                cout, cin, npix, ks, slab, st), "sat_gemm_f32_splitk")
+                L.check(lib.sat_sum_slabs_f32(wsl.data_ptr(), ks, slab, slab, tap_out.data_ptr(), st), "sat_sum_slabs_f32")
+                L.check(lib.sat_rows_copy(tap_out.data_ptr(), cin, None, 0, cout, cout, cin, dWk.data_ptr() + (kh * 3 + kw) * cin * 4,
+                                          9 * cin, st), "sat_rows_copy")
+        dW = dWk.view(cout, 3, 3, cin)[..., :conv.cin].permute(0, 3, 1, 2).contiguous()       # kernel layout -> [Cout, Cin, 3, 3]
+        grads[conv] = (dW, db)
+        if first:
+            break
+        # input gradient = conv of the zero-bordered d(pre-activation) with the flipped, transposed weights (forward kernel)
+        wflip = conv.weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous().view(cin, 9 * cout)
+        dX = torch.empty(N, h, w, cin, device=dev)
+        o = L.SatOp()
+        o.kind, o.dtype = L.OP_CONV, L.SAT_F32
+        o.in0, o.w, o.out = dZp.data_ptr(), wflip.data_ptr(), dX.data_ptr()
+        o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, hp, wp, cout, h, w, cin
+        o.KH, o.KW, o.stride, o.pad = 3, 3, 1, 0
+        o.sN, o.sH, o.sW = hp * wp * cout, wp * cout, cout
+        ops = (L.SatOp * 1)(o)
+        L.check(lib.sat_run_ops(ops, 1, st), "sat_run_ops")
+        dY = dX
+    out = []
+    for conv in self.stack.convs():
+        out += list(grads[conv])
+    return out
+
+
+VggProgram.backward = _vgg_backward
 
 
 class _Lin(nn.Module):
@@ -253,8 +334,27 @@ class _AttendFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         from .attend_bwd import attend_backward
-        grads = attend_backward(ctx.m, ctx.pi, ctx.captions, ctx.tapes, dlogits)
-        return (None, None, None, None, None) + tuple(grads)
+        want = ctx.needs_input_grad[1]                     # features carry a graph only when the conv stack is fine-tuned
+        grads, d_feats, d_fmean = attend_backward(ctx.m, ctx.pi, ctx.captions, ctx.tapes, dlogits, want_dfeat=want)
+        return (None, d_feats, d_fmean if ctx.needs_input_grad[2] else None, None, None) + tuple(grads)
+
+
+class _VggFn(torch.autograd.Function):
+    """the conv stack WITH a backward (fine-tuning, model2.py:87-89 `finetune(allow=True)`): f32 parity mode only"""
+
+    @staticmethod
+    def forward(ctx, prog, images, *params):
+        feats, fmean = prog.run(images)
+        ctx.prog, ctx.run_id = prog, prog.run_id
+        return feats.clone(), fmean.clone()
+
+    @staticmethod
+    def backward(ctx, d_feats, d_fmean):
+        prog = ctx.prog
+        if prog.run_id != ctx.run_id:
+            raise RuntimeError("the conv stack ran again before this backward: its activation tapes were overwritten "
+                               "(fine-tuning keeps one forward per backward)")
+        return (None, None) + tuple(prog.backward(d_feats, d_fmean))
 
 
 PARAM_ORDER = ("image_att_w", "init_hidden.weight", "init_hidden.bias", "init_memory.weight", "init_memory.bias",
@@ -281,6 +381,7 @@ class ShowAttendTellModel(nn.Module):
         self.encoder = VggFeatures(vgg_cfg)                                             # model2.py:15-16
         if self.encoder.out_channels != feat:
             raise ValueError("the conv stack ends in %d channels, feature_size says %d" % (self.encoder.out_channels, feat))
+        self.compute_dtype = compute_dtype
         self.finetune(allow=False)                                                      # model2.py:17
         self.image_att_w = nn.Parameter(torch.empty(feat, feat).normal_(0, 0.05))       # model2.py:20 (uninitialised there)
         self.init_hidden, self.init_memory = _Lin(feat, hidden_size), _Lin(feat, hidden_size)
@@ -297,11 +398,12 @@ class ShowAttendTellModel(nn.Module):
         self.encoder.register_load_state_dict_post_hook(lambda mod, k: self._programs.clear())
 
     def finetune(self, allow=False):
-        """model2.py:87-89.  allow=True needs the conv backward, which is not built."""
-        if allow:
-            raise NotImplementedError("fine-tuning the conv stack (conv backward) is not built; the encoder stays frozen")
+        """model2.py:87-89: (un)freeze the conv stack.  Fine-tuning runs the stack with a hand-written backward (dgrad through
+        the forward conv kernel on flipped weights, wgrad as split-K GEMMs, ReLU / max-pool routing) in the f32 parity mode."""
+        if allow and getattr(self, "compute_dtype", "f32") != "f32":
+            raise NotImplementedError("fine-tuning the conv stack needs compute_dtype='f32' (the bf16 stack keeps no f32 master weights)")
         for p in self.encoder.parameters():
-            p.requires_grad = False
+            p.requires_grad = True if allow else False
 
     def _apply(self, fn, *a, **k):
         self._programs.clear()
@@ -317,11 +419,21 @@ class ShowAttendTellModel(nn.Module):
         if prog is None:
             self._programs.clear()
             prog = self._programs[key] = VggProgram(self.encoder, N, H, W, dt, images.device)
-        with torch.no_grad():
-            feats, fmean = prog.run(images)
+        tuned = [p for p in self.encoder.parameters() if p.requires_grad]
+        if tuned and torch.is_grad_enabled():
+            if len(tuned) != 2 * len(self.encoder.conv_names):
+                raise NotImplementedError("fine-tune all of the conv stack or none of it (model2.py:87-89)")
+            params = []
+            for cv in self.encoder.convs():
+                params += [cv.weight, cv.bias]
+            feats, fmean = _VggFn.apply(prog, images, *params)
+        else:
+            with torch.no_grad():
+                feats, fmean = prog.run(images)
+            feats, fmean = feats.clone(), fmean.clone()   # the program's buffers are overwritten by the next forward
         if feats.shape[2] != self.feat:
             raise ValueError("encoder features have %d channels, expected %d" % (feats.shape[2], self.feat))
-        return feats.clone(), fmean.clone()           # the program's buffers are overwritten by the next forward
+        return feats, fmean
 
     def _params(self):
         d = dict(self.named_parameters())

@@ -17,8 +17,9 @@ def _rows(t, r0):
     return t.data_ptr() + r0 * t.shape[1] * 4
 
 
-def attend_backward(m, pi, captions, tp, dlogits):
-    """Returns the gradients in `attend.PARAM_ORDER`."""
+def attend_backward(m, pi, captions, tp, dlogits, want_dfeat=False):
+    """Returns (gradients in `attend.PARAM_ORDER`, d_features [B,P,C] or None, d_fmean [B,C] or None); the last two only when
+    the conv stack is being fine-tuned (model2.py:87-89)."""
     lib, st = L.load(), L.stream()
     dev = dlogits.device
     f2, fmean, ctx_enc = tp["f2"], tp["fmean"], tp["ctx_enc"]
@@ -61,6 +62,7 @@ def attend_backward(m, pi, captions, tp, dlogits):
     dh_carry, dh_a, dh_b = torch.zeros(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
     dc_state = torch.zeros(B, H, device=dev)
     d_ctx_enc = torch.zeros_like(ctx_enc)
+    d_feats = torch.zeros_like(ctx_enc) if want_dfeat else None      # [B*P, C]: what the weighted means send back (per step)
     dwatt_part = torch.empty(B, C, device=dev)
     g["weight_att"] = torch.zeros(C, device=dev)
     proj = torch.empty(B, C, device=dev)
@@ -77,7 +79,8 @@ def attend_backward(m, pi, captions, tp, dlogits):
         L.check(lib.sat_rows_add(DX.data_ptr() + E * 4, Hin, _rows(dZin, r0), C + H, bs, C, dctx.data_ptr(), C, st), "sat_rows_add")
         _gemm(lib, 0, 0, hprev, H, m.weight_hh.weight, H, proj, C, bs, C, H, m.weight_hh.bias)           # recompute the projection
         L.check(lib.sat_attention_bwd(ctx_enc.data_ptr(), f2.data_ptr(), proj.data_ptr(), C, watt.data_ptr(), _rows(ALPHA, r0),
-                                      dctx.data_ptr(), C, bs, P, C, d_ctx_enc.data_ptr(), _rows(DPROJ, r0), dwatt_part.data_ptr(), st),
+                                      dctx.data_ptr(), C, bs, P, C, d_ctx_enc.data_ptr(), _rows(DPROJ, r0), dwatt_part.data_ptr(),
+                                      d_feats.data_ptr() if d_feats is not None else None, st),
                 "sat_attention_bwd")
         L.check(lib.sat_rows_sum(dwatt_part.data_ptr(), C, bs, C, g["weight_att"].data_ptr(), 1, st), "sat_rows_sum")
         _gemm(lib, 0, 1, _rows(DG, r0), 4 * H, m.lstmcell.weight_hh, H, dh_a, H, bs, H, 4 * H)           # dh_{t-1} via the LSTM
@@ -117,5 +120,18 @@ def attend_backward(m, pi, captions, tp, dlogits):
     g["embedding.weight"] = torch.empty(V, E, device=dev)
     L.check(lib.sat_scatter_rows_add(DEMB.data_ptr(), toks.data_ptr(), N, E, V, g["embedding.weight"].data_ptr(), st),
             "sat_scatter_rows_add")
+    d_fmean = None
+    if want_dfeat:
+        # context_encode = features @ W  =>  d features += d_ctx_enc @ W^T
+        tmp = torch.empty_like(ctx_enc)
+        _gemm(lib, 0, 0, d_ctx_enc, C, m.image_att_w, C, tmp, C, f2.shape[0], C, C)
+        L.check(lib.sat_rows_add(d_feats.data_ptr(), C, tmp.data_ptr(), C, f2.shape[0], C, d_feats.data_ptr(), C, st), "sat_rows_add")
+        # init_lstm: h0 = fmean Wh^T + b, c0 = fmean Wc^T + b  =>  d fmean = dh0 Wh + dc0 Wc
+        da, db_ = torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+        _gemm(lib, 0, 1, dh_carry, H, m.init_hidden.weight, C, da, C, B, C, H)
+        _gemm(lib, 0, 1, dc_state, H, m.init_memory.weight, C, db_, C, B, C, H)
+        d_fmean = torch.empty(B, C, device=dev)
+        L.check(lib.sat_rows_add(da.data_ptr(), C, db_.data_ptr(), C, B, C, d_fmean.data_ptr(), C, st), "sat_rows_add")
+        d_feats = d_feats.view(B, P, C)
     from .attend import PARAM_ORDER
-    return [g[k] for k in PARAM_ORDER]
+    return [g[k] for k in PARAM_ORDER], d_feats, d_fmean

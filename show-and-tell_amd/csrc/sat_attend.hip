@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
                                                             const float* __restrict__ w_att, const float* __restrict__ alpha,
                                                             const float* __restrict__ d_ctx, long ld_dctx, int P, int C,
                                                             float* __restrict__ d_ctx_enc, float* __restrict__ d_proj,
-                                                            float* __restrict__ d_watt_part) {
+                                                            float* __restrict__ d_watt_part, float* __restrict__ d_feats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [C] proj | [C] w_att | [C] d_ctx | [P] d_s | [8]
     float* s_proj = sm;
     float* s_w = sm + C;
@@ -124,6 +124,13 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
     __syncthreads();
     const float* ce = ctx_enc + (long)b * P * C;
     float* dce = d_ctx_enc + (long)b * P * C;
+    if (d_feats) {      // fine-tuning: context = mean_p alpha[p] feats[p]  =>  d feats[p,c] += alpha[p] * d_ctx[c] / P
+        float* dfe = d_feats + (long)b * P * C;
+        for (int c = tid; c < C; c += blockDim.x) {
+            const float dc = s_dc[c] * invP;
+            for (int p = 0; p < P; ++p) dfe[(long)p * C + c] += alpha[(long)b * P + p] * dc;
+        }
+    }
     for (int c = tid; c < C; c += blockDim.x) {                          // a thread owns a channel: fixed order over p
         const float pj = s_proj[c], w = s_w[c];
         float dp = 0.0f, dw = 0.0f;
@@ -245,6 +252,95 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 
 }  // namespace
 
+// ---- conv-stack backward helpers (fine-tuning, model2.py:87-89 `finetune(allow=True)`), f32 NHWC ----
+namespace {
+// out = zero-bordered copy of in (border `pad` pixels); with `y` != NULL the ReLU mask is applied on the way:
+// out[n][h+pad][w+pad][c] = y[n][h][w][c] > 0 ? in[n][h][w][c] : 0      (d pre-activation = d post-activation * (y > 0))
+__global__ void pad_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ y, int N, int H, int W, int C, int pad,
+                                float* __restrict__ out) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad, c4 = C / 4;
+    const long total = (long)N * Hp * Wp * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c4);
+        long r = i / c4;
+        const int wp = (int)(r % Wp); r /= Wp;
+        const int hp = (int)(r % Hp);
+        const int n = (int)(r / Hp);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int h = hp - pad, w = wp - pad;
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+            const long src = (((long)n * H + h) * W + w) * C + cc * 4;
+            v = *(const f32x4*)(in + src);
+            if (y) {
+                const f32x4 m = *(const f32x4*)(y + src);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.0f ? v[e] : 0.0f;
+            }
+        }
+        *(f32x4*)(out + i * 4) = v;
+    }
+}
+// backward of the 2x2/2 max-pool: the gradient goes to the FIRST maximum of each window in scan order (torch's rule)
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Hin, int Win, int C,
+                                    float* __restrict__ dx) {
+    const int Ho = Hin / 2, Wo = Win / 2;
+    const long total = (long)N * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const long base = (((long)n * Hin + 2 * ho) * Win + 2 * wo) * C + c;
+        const long off[4] = {0, (long)C, (long)Win * C, (long)Win * C + C};
+        int best = 0;
+        float bv = x[base];
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+            const float v = x[base + off[d]];
+            if (v > bv) { bv = v; best = d; }
+        }
+        const float g = dy[i];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dx[base + off[d]] = d == best ? g : 0.0f;
+    }
+}
+// out[b][p][c] += scale * v[b][c]   (mean over p in the forward)
+__global__ void bcast_add_kernel(const float* __restrict__ v, int B, int P, int C, float scale, float* __restrict__ out) {
+    const long total = (long)B * P * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((long)P * C));
+        out[i] += scale * v[(long)b * C + c];
+    }
+}
+inline int ew_grid2(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
+}  // namespace
+
+extern "C" int sat_pad_nhwc_f32(const float* in, const float* relu_mask_of, int N, int H, int W, int C, int pad, float* out,
+                                sat_stream_t stream) {
+    if (!in || !out || N < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || pad < 0 || in == out) return SAT_ERR_ARG;
+    const long total = (long)N * (H + 2 * pad) * (W + 2 * pad) * (C / 4);
+    hipLaunchKernelGGL(pad_nhwc_kernel, dim3(ew_grid2(total)), dim3(256), 0, (hipStream_t)stream, in, relu_mask_of, N, H, W, C, pad, out);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_maxpool2_bwd_f32(const float* x, const float* dy, int N, int Hin, int Win, int C, float* dx, sat_stream_t stream) {
+    if (!x || !dy || !dx || N < 1 || (Hin & 1) || (Win & 1) || C < 1) return SAT_ERR_ARG;
+    const long total = (long)N * (Hin / 2) * (Win / 2) * C;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid2(total)), dim3(256), 0, (hipStream_t)stream, x, dy, N, Hin, Win, C, dx);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_bcast_add_f32(const float* v, int B, int P, int C, float scale, float* out, sat_stream_t stream) {
+    if (!v || !out || B < 1 || P < 1 || C < 1) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(bcast_add_kernel, dim3(ew_grid2((long)B * P * C)), dim3(256), 0, (hipStream_t)stream, v, B, P, C, scale, out);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
 // On-device collate (data_loader.py:48-62 `collate_fn`): captions arrive ragged (one flat id array + per-sample offsets) in
 // dataset order; `order[r]` = the sample that lands in row r (sorted by decreasing length, ties in dataset order -- computed
 // on the host from the host-side lengths).  out[r][t] = t < len(order[r]) ? flat[offset[order[r]] + t] : 0.
@@ -357,14 +453,14 @@ extern "C" int sat_attention_fwd(const float* ctx_enc, const float* feats, const
 
 extern "C" int sat_attention_bwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
                                  const float* alpha, const float* d_ctx, int64_t ld_dctx, int rows, int P, int C,
-                                 float* d_ctx_enc, float* d_proj, float* d_watt_part, sat_stream_t stream) {
+                                 float* d_ctx_enc, float* d_proj, float* d_watt_part, float* d_feats, sat_stream_t stream) {
     if (!ctx_enc || !feats || !proj || !w_att || !alpha || !d_ctx || !d_ctx_enc || !d_proj || !d_watt_part || rows < 1 || P < 1 ||
         C < 4 || (C & 3) || ld_proj < C || ld_dctx < C)
         return SAT_ERR_ARG;
     const size_t lds = (size_t)(3 * C + ((P + 3) & ~3) + 8) * sizeof(float);
     if (lds > 60 * 1024) return SAT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, ctx_enc, feats, proj, (long)ld_proj,
-                       w_att, alpha, d_ctx, (long)ld_dctx, P, C, d_ctx_enc, d_proj, d_watt_part);
+                       w_att, alpha, d_ctx, (long)ld_dctx, P, C, d_ctx_enc, d_proj, d_watt_part, d_feats);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }

@@ -47,12 +47,14 @@ def test_attention_fwd_bwd_kernels_vs_fp64():
     assert torch.isnan(co[:, :4]).all() and torch.isnan(co[:, 4 + C:]).all()          # strided destination: nothing else written
     dce = torch.ones(B, P, C, device="cuda")                                           # accumulates INTO the buffer
     dpj, dwp = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
+    dfe = torch.zeros(B, P, C, device="cuda")
     L.check(lib.sat_attention_bwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), C, d[3].data_ptr(), al.data_ptr(), d[4].data_ptr(), C,
-                                  B, P, C, dce.data_ptr(), dpj.data_ptr(), dwp.data_ptr(), st()))
+                                  B, P, C, dce.data_ptr(), dpj.data_ptr(), dwp.data_ptr(), dfe.data_ptr(), st()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(dce.cpu().numpy() - 1.0, ce64.grad.numpy(), rtol=0, atol=3e-7)
     np.testing.assert_allclose(dpj.cpu().numpy(), pj64.grad.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(dwp.sum(0).cpu().numpy(), w64.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dfe.cpu().numpy(), fe64.grad.numpy(), rtol=1e-4, atol=1e-8)       # fine-tuning: gradient into the features
     assert lib.sat_attention_fwd(None, None, None, C, None, B, P, C, None, None, C, st()) == 1001
 
 
@@ -231,8 +233,6 @@ def test_full_model_drop_in_training_loop_and_sample():
     assert ids.shape == (B, 20) and ids.dtype == torch.int64 and int(ids.min()) >= 0 and int(ids.max()) < vocab
     cur = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith("encoder.")}
     assert torch.equal(ids.cpu(), OA.attend_sample(cur, feats, None))
-    with pytest.raises(NotImplementedError):
-        model.finetune(allow=True)
     with pytest.raises(ValueError):
         sat.ShowAttendTellModel(100, 512, 50, 32)           # hidden != embed + 512
 
@@ -251,3 +251,57 @@ def test_collate_on_device_equals_the_reference_collate_contract():
     assert torch.equal(caps.cpu(), ref_caps) and torch.equal(im.cpu(), ref_im)
     with pytest.raises(ValueError):
         sat.collate_on_device(images, flat, lens[:-1] + [2])
+
+
+def test_finetune_conv_stack_backward_vs_oracle_autograd():
+    """`finetune(allow=True)` (model2.py:87-89): gradients of every conv weight / bias of the stack (dgrad through the forward conv
+    kernel on flipped weights, wgrad as split-K GEMMs over the flat zero-bordered pixel index, ReLU mask, max-pool routing,
+    the three paths by which the decoder reaches the features) against torch autograd through the CPU oracle"""
+    g = torch.Generator().manual_seed(31)
+    hidden, embed, vocab, B, T = 64 + 32, 32, 90, 5, 8
+    vp = OA.init_vgg_params(g, cfg=SMALL_VGG)
+    dp = OA.init_attend_params(hidden, 64, vocab, embed, generator=g, feat=64)
+    model = sat.ShowAttendTellModel(hidden, 64, vocab, embed, None, feature_size=(16, 64), compute_dtype="f32", vgg_cfg=SMALL_VGG)
+    sd = dict(vp)
+    sd.update(dp)
+    model.load_state_dict(sd)
+    model.cuda()
+    model.finetune(allow=True)
+    assert all(p.requires_grad for p in model.encoder.parameters())
+    images = torch.randn(B, 3, 32, 32, generator=g)
+    lengths = [8, 8, 6, 5, 3]
+    caps = torch.zeros(B, T, dtype=torch.long)
+    for b, l in enumerate(lengths):
+        caps[b, 0] = 1
+        caps[b, 1:l - 1] = torch.randint(4, vocab, (l - 2,), generator=g)
+        caps[b, l - 1] = 2
+    # oracle: autograd through vgg_forward -> attend_forward -> CE
+    from oracle import decoder as OD
+    q = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    l1 = [l - 1 for l in lengths]
+    tg = OD.pack_time_major(caps[:, 1:], l1)
+    ref_logits = OA.attend_forward(q, OA.vgg_forward(q, images, cfg=SMALL_VGG), caps[:, :-1], l1)
+    ref_loss = F.cross_entropy(ref_logits, tg)
+    ref_loss.backward()
+    di, dc = images.cuda(), caps.cuda()
+    targets, _ = sat.pack_targets(dc, lengths)
+    model.zero_grad()
+    out = model(di, dc[:, :-1], l1)
+    loss = torch.nn.CrossEntropyLoss()(out, targets)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in sd:
+        got, ref = named[k].grad.cpu(), q[k].grad
+        scale = ref.abs().max().item() + 1e-12
+        assert (got - ref).abs().max().item() < 3e-3 * scale + 1e-8, (k, (got - ref).abs().max().item(), scale)
+    # a second forward before the backward would overwrite the tapes: refused, not silently wrong
+    out1 = model(di, dc[:, :-1], l1)
+    model(di, dc[:, :-1], l1)
+    with pytest.raises(RuntimeError):
+        out1.sum().backward()
+    model.finetune(allow=False)
+    assert not any(p.requires_grad for p in model.encoder.parameters())
+    bf = sat.ShowAttendTellModel(hidden, 64, vocab, embed, None, feature_size=(16, 64), compute_dtype="bf16", vgg_cfg=SMALL_VGG)
+    with pytest.raises(NotImplementedError):
+        bf.finetune(allow=True)
