@@ -287,12 +287,19 @@ extern "C" int sat_lstm_bwd(const float* dHS, const float* X, const float* w_ih,
     float* dc_state = workspace + nz * slab; // [B][H]
     hipError_t e = hipMemsetAsync(dc_state, 0, (size_t)slab * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
+    static const int fused_step = getenv("SAT_LSTM_BWD_FUSED") ? atoi(getenv("SAT_LSTM_BWD_FUSED")) : 1;
     long off = N;
     for (int t = T - 1; t >= 0; --t) {
         const int n = batch_sizes[t];
         off -= n;
         const int n_next = (t + 1 < T) ? batch_sizes[t + 1] : 0;
         const float* cs_prev = (t > 0) ? CS + (off - batch_sizes[t - 1]) * H : nullptr;
+        if (fused_step) {
+            // ONE launch per step: dh_t = dHS_t + DG_{t+1} W_hh (K = 4H inside the workgroup) and the gate backward of step t
+            SAT_TRY(sat_lstm_bwd_step(dHS + off * H, n_next ? DG + (off + n) * 4 * H : nullptr, n_next, w_hh, GA + off * 4 * H,
+                                      CS + off * H, cs_prev, dc_state, DG + off * 4 * H, n, H, s));
+            continue;
+        }
         SAT_TRY(sat_lstm_bwd_point_launch(dHS + off * H, dh_part, nz, slab, n_next, GA + off * 4 * H, CS + off * H,
                                           cs_prev, dc_state, DG + off * 4 * H, n, H, s));
         if (t > 0)   // dh_{t-1} partial slabs = DG_t * W_hh   (K = 4H split over nz workgroup slices)

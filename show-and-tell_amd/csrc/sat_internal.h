@@ -18,6 +18,8 @@ int sat_skinny_lstm(const float* h_prev, const float* w_hh, const float* x, cons
                     const float* bias, const float* bias2, const float* xg, long ldxg, int M, int H,
                     float* c_state, float* ga, long ldga, float* cs, float* h_out, float* h_out2, int m2,
                     hipStream_t s);
+int sat_lstm_bwd_step(const float* dHS, const float* DG_next, int n_next, const float* w_hh, const float* GA, const float* CS,
+                      const float* CS_prev, float* dc_state, float* DG, int n, int H, hipStream_t s);
 int sat_lstm_bwd_point_launch(const float* dHS, const float* dh_part, int nz, long slab_stride, int n_next,
                               const float* GA, const float* CS, const float* CS_prev, float* dc_state, float* DG,
                               int n, int H, hipStream_t s);

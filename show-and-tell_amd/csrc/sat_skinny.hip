@@ -13,7 +13,7 @@
 
 namespace {
 
-enum { EPI_STORE = 0, EPI_LSTM = 1, EPI_ARGMAX = 2 };
+enum { EPI_STORE = 0, EPI_LSTM = 1, EPI_ARGMAX = 2, EPI_LSTM_BWD = 3 };
 
 struct SkinnyArgs {
     // operand pair 1 (required) and 2 (optional): out += A[M,K] * Wsel[16,K]^T
@@ -34,14 +34,20 @@ struct SkinnyArgs {
     float* h_out2; int m2;                    // second copy for rows < m2 (next step's h_prev rows), nullable
     // EPI_ARGMAX
     float* pmax; int* pidx;                   // [M][gridDim.x]
+    // EPI_LSTM_BWD: out columns are hidden units j; acc = (DG_{t+1} W_hh)[row][j] for rows < m2 (the rows that have a step
+    // t+1); the epilogue is the pointwise LSTM backward of step t for (row, j):
+    //   dh = dhs[row][j] + acc;  dc = dh*o*(1-tanh(c)^2) + dc_state (rows < m2);  DG_t[row][g*H+j];  dc_state = dc*f
+    const float* dhs;                         // [M][H]   d(loss)/d(h_t) from above
+    const float* cs_prev;                     // [M][H] c_{t-1} or NULL (zeros)
+    float* dg;                                // [M][4H] out
 };
 
 constexpr int NWV = 8;   // waves per workgroup: K is split 8 ways (x gridDim.z), partial tiles reduced through LDS
 
-template <bool WKM>
+template <bool WKM, int RT = 4>
 __device__ __forceinline__ void load_operands(const float* __restrict__ A, long lda, const float* __restrict__ W, long ldw,
                                               int K, int M, int row_chunk0, long wrow, bool wrow_ok, int kb, int lane,
-                                              f32x4& b, f32x4 (&a)[4]) {
+                                              f32x4& b, f32x4 (&a)[RT]) {
     const int n16 = lane & 15, kg = lane >> 4;
     const int k = kb * 16 + kg * 4;
     const bool kok = k < K;   // K % 4 == 0
@@ -57,35 +63,77 @@ __device__ __forceinline__ void load_operands(const float* __restrict__ A, long 
         }
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < RT; ++mt) {
         const int row = row_chunk0 + mt * 16 + n16;
         a[mt] = (kok && row < M) ? *(const f32x4*)(A + (long)row * lda + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 
 // software-pipelined: the operands of K-block kb+step are in flight while the MFMAs of K-block kb issue
-template <bool WKM>
+template <bool WKM, int RT = 4>
 __device__ __forceinline__ void accumulate_pair(const float* __restrict__ A, long lda, const float* __restrict__ W,
                                                 long ldw, int K, int M, int row_chunk0, long wrow, bool wrow_ok,
-                                                int kb0, int kbstep, int lane, f32x4 (&acc)[4]) {
+                                                int kb0, int kbstep, int lane, f32x4 (&acc)[RT]) {
     const int nkb = (K + 15) >> 4;
     if (kb0 >= nkb) return;
-    f32x4 b, a[4], bn, an[4];
-    load_operands<WKM>(A, lda, W, ldw, K, M, row_chunk0, wrow, wrow_ok, kb0, lane, b, a);
+    f32x4 b, a[RT], bn, an[RT];
+    load_operands<WKM, RT>(A, lda, W, ldw, K, M, row_chunk0, wrow, wrow_ok, kb0, lane, b, a);
     for (int kb = kb0; kb < nkb; kb += kbstep) {
         const bool more = kb + kbstep < nkb;
-        if (more) load_operands<WKM>(A, lda, W, ldw, K, M, row_chunk0, wrow, wrow_ok, kb + kbstep, lane, bn, an);
+        if (more) load_operands<WKM, RT>(A, lda, W, ldw, K, M, row_chunk0, wrow, wrow_ok, kb + kbstep, lane, bn, an);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < RT; ++mt)
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][e], b[e], acc[mt], 0, 0, 0);
         if (more) {
             b = bn;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a[mt] = an[mt];
+            for (int mt = 0; mt < RT; ++mt) a[mt] = an[mt];
         }
     }
+}
+
+// One step of the LSTM backward chain (train.py:144 through models.py:52) as ONE launch: dh_t = dHS_t + DG_{t+1} W_hh for this
+// workgroup's 16 hidden units x 16 batch rows (K = 4H over the 8 waves, reduced through LDS in a fixed order), then the
+// pointwise gate backward of step t on the reduced tile -- the split-K slabs and the separate pointwise launch of the
+// two-kernel form disappear.  Grid = (H/16, ceil(n/16)): 128 workgroups at H = 512, batch 64.
+__global__ __launch_bounds__(NWV * 64) void lstm_bwd_step_kernel(const SkinnyArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[NWV][16][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = blockIdx.x, rc0 = blockIdx.y * 16;
+    const int n16 = lane & 15;
+    const int H = p.N;
+    const long wrow = (long)cg * 16 + n16;                 // hidden unit fed by MFMA column n16 (W_hh is K-major here)
+    const bool wrow_ok = wrow < H;
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    if (p.A) accumulate_pair<true, 1>(p.A, p.lda, p.W, p.ldw, p.K, p.m2, rc0, wrow, wrow_ok, wave, NWV, lane, acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][(lane >> 4) * 4 + e][n16] = acc[0][e];
+    __syncthreads();
+    if (tid >= 256) return;
+    const int row = tid >> 4, jj = tid & 15;
+    const int grow = rc0 + row, j = cg * 16 + jj;
+    if (grow >= p.M || j >= H) return;
+    float dh = p.dhs[(long)grow * H + j];
+    float dcn = 0.0f;
+    if (grow < p.m2) {
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) dh += red[w][row][jj];
+        dcn = p.c_state[(long)grow * H + j];
+    }
+    const float* ga = p.ga + (long)grow * p.ldga;
+    const float gi = ga[j], gf = ga[H + j], gg = ga[2 * H + j], go = ga[3 * H + j];
+    const float tc = sat_tanh(p.cs[(long)grow * H + j]);
+    const float c_prev = p.cs_prev ? p.cs_prev[(long)grow * H + j] : 0.0f;
+    const float d_o = dh * tc;
+    const float dc = dh * go * (1.0f - tc * tc) + dcn;
+    float* dg = p.dg + (long)grow * 4 * H;
+    dg[j] = dc * gg * gi * (1.0f - gi);
+    dg[H + j] = dc * c_prev * gf * (1.0f - gf);
+    dg[2 * H + j] = dc * gi * (1.0f - gg * gg);
+    dg[3 * H + j] = d_o * go * (1.0f - go);
+    p.c_state[(long)grow * H + j] = dc * gf;
 }
 
 template <int EPI, bool WKM>
@@ -306,4 +354,19 @@ extern "C" int sat_lstmcell_fwd(const float* x, const float* h_in, float* c, con
     if (!x || !h_in || !c || !w_ih || !w_hh || !h_out || B < 1) return SAT_ERR_ARG;
     return sat_skinny_lstm(h_in, w_hh, x, w_ih, In, b_ih, b_hh, nullptr, 0, B, H, c, gates, 4L * H, c_tape, h_out,
                            nullptr, 0, (hipStream_t)stream);
+}
+
+// one fused step of the LSTM backward chain (see lstm_bwd_step_kernel); DG_next NULL / n_next 0 for the last time step
+int sat_lstm_bwd_step(const float* dHS, const float* DG_next, int n_next, const float* w_hh, const float* GA, const float* CS,
+                      const float* CS_prev, float* dc_state, float* DG, int n, int H, hipStream_t s) {
+    if ((H & 3) || n < 1) return SAT_ERR_ARG;
+    SkinnyArgs a = {};
+    a.A = n_next > 0 ? DG_next : nullptr; a.lda = 4L * H; a.W = w_hh; a.ldw = H; a.K = 4 * H;
+    a.M = n; a.N = H; a.m2 = n_next; a.nz = 1;
+    a.dhs = dHS; a.ga = const_cast<float*>(GA); a.ldga = 4L * H; a.cs = const_cast<float*>(CS); a.cs_prev = CS_prev;
+    a.c_state = dc_state; a.dg = DG;
+    dim3 grid(sat_cdiv(H, 16), sat_cdiv(n, 16), 1);
+    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(NWV * 64), 0, s, a);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
 }

@@ -9,7 +9,7 @@ cat gpurun_out/bench.json; tail -n 5 gpurun_out/bench.err
 if [ $rc -ne 0 ]; then echo "bench failed rc=$rc"; exit $rc; fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_run.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-mode > $R/gpurun_out/prof_run.log 2>&1
 rc=$?
 tail -n 3 $R/gpurun_out/prof_run.log
 find $R/gpurun_out/prof -name "*stats*" | head

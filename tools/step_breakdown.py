@@ -13,7 +13,8 @@ def short(n):
         return 'conv<' + m.group(1).replace(' ', '') + '>'
     if 'bn_act_kernel' in n:
         return 'bn_add' if ('_Accum, bool' in n or 'Lb1' in n) else 'bn_relu'
-    for k in ['bn_finalize', 'maxpool', 'avgpool', 'image_prep', 'skinny', 'gemm_kernel', 'lstm_bwd_point', 'ce_rows',
+    for k in ['bn_finalize', 'maxpool', 'avgpool', 'image_prep', 'lstm_persist', 'lstm_bwd_step', 'skinny', 'gemm_kernel', 'lstm_bwd_point', 'ce_rows',
+              'validate_ids', 'bn_slab_to_acc',
               'clamp_adam', 'embed', 'colsum', 'bn1d', 'sum_slabs', 'pack_targets', 'sum_scale', 'beam']:
         if k in n:
             return k
