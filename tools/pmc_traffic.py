@@ -25,11 +25,9 @@ def last_step(d, counter):
     rows = sorted(disp.values(), key=lambda e: e["start"])
     ip = [i for i, e in enumerate(rows) if "image_prep" in e["name"]]
     adam = [i for i, e in enumerate(rows) if "clamp_adam" in e["name"]]
-    s = ip[-1]
-    en = [a for a in adam if a > s]
-    if not en:
-        s = ip[-2]
-        en = [a for a in adam if a > s]
+    last = adam[-1]            # last FULL training step (the roofline passes after it run the encoder without an optimizer step)
+    s = [i for i in ip if i < last][-1]
+    en = [last]
     agg = defaultdict(lambda: [0, 0.0])
     for e in rows[s:en[0] + 1]:
         k = short(e["name"])

@@ -27,11 +27,11 @@ def main():
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     ip = [i for i, r in enumerate(rows) if 'image_prep' in r['Kernel_Name']]
     adam = [i for i, r in enumerate(rows) if 'clamp_adam' in r['Kernel_Name']]
-    s = ip[-1]
-    e = [a for a in adam if a > s]
-    if not e:
-        s = ip[-2]
-        e = [a for a in adam if a > s]
+    # the last FULL training step: the last clamp+Adam launch and the image prep that opened its step (bench.py's
+    # roofline passes run the encoder again afterwards, without an optimizer step)
+    last = adam[-1]
+    s = [i for i in ip if i < last][-1]
+    e = [last]
     step = rows[s:e[0] + 1]
     wall = (int(step[-1]['End_Timestamp']) - int(step[0]['Start_Timestamp'])) / 1e6
     busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in step) / 1e6
