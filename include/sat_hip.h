@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 6
+#define SAT_ABI_VERSION 7
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -124,6 +124,13 @@ typedef struct sat_op {
      * models.py:27 -- formed in LDS, and y is also stored to out1 (shaped like in0: the next block's residual).  Replaces
      * the SAT_OP_BN_ADD_RELU launch between two bottlenecks. */
     void* out1;
+    /* Sharded statistics accumulators: stat_acc is int64 [2 parities][stat_shards][2][C] (0 or 1 = unsharded, else a power of
+     * two <= 8).  A SAT_OP_CONV adds its tile's sums into shard (workgroup id % stat_shards) -- 8x less contention per word,
+     * so layers with up to ~1600 row tiles can use the integer atomics instead of per-tile slabs + a reducer launch -- and
+     * every consumer sums the shards when it derives (scale, shift) (integer sums: still order independent).  stat_shards1
+     * describes stat_acc1 the same way. */
+    int32_t stat_shards;
+    int32_t stat_shards1;
 } sat_op;
 
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -42,6 +42,7 @@ class SatOp(C.Structure):
         ("variant", C.c_int32), ("flags", C.c_int32),
         ("stat_acc", _vp), ("stat_acc1", _vp), ("gamma1", _vp), ("beta1", _vp),
         ("running_mean1", _vp), ("running_var1", _vp), ("out1", _vp),
+        ("stat_shards", C.c_int32), ("stat_shards1", C.c_int32),
     ]
 
 

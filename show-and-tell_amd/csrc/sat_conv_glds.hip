@@ -45,6 +45,8 @@ struct ConvArgs {
     // whatever the arrival order; the consumer kernel (bn_act / maxpool) turns them into scale/shift itself, which
     // removes the separate finalize launch.  Used when there are few M-tiles (<= ~400 adds per word).
     long long* acc;
+    int acc_shards;          // acc is [acc_shards][2][N]: workgroup b adds into shard b % acc_shards
+    int in_shards;           // in_acc / in_acc_clear are [in_shards][2][Cin]: summed when the table is derived
     // Input-side fusion (1x1 convs): the A operand is the RAW output of the previous conv and its BatchNorm + ReLU is
     // applied to each landed LDS stage in place, so the normalised tensor never exists in HBM.  The (scale, shift)
     // table comes precomputed (in_scale/in_shift) or is derived here from the previous conv's integer sums (in_acc).
@@ -337,8 +339,13 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         for (int c = tid; c < p.Cin; c += NT) {
             float sc, sh;
             if (p.in_acc) {
-                const double mean = (double)p.in_acc[c] * inv;
-                double var = (double)p.in_acc[p.Cin + c] * inv - mean * mean;
+                long long s1 = 0, s2 = 0;
+                for (int sh = 0; sh < p.in_shards; ++sh) {           // integer sums: any order gives the same total
+                    s1 += p.in_acc[(long)sh * 2 * p.Cin + c];
+                    s2 += p.in_acc[(long)sh * 2 * p.Cin + p.Cin + c];
+                }
+                const double mean = (double)s1 * inv;
+                double var = (double)s2 * inv - mean * mean;
                 if (var < 0.0) var = 0.0;
                 const float invstd = 1.0f / sqrtf((float)var + p.in_eps);
                 sc = p.in_gamma[c] * invstd;
@@ -349,7 +356,11 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                         p.in_running_mean[c] = (float)((1.0 - p.in_momentum) * p.in_running_mean[c] + p.in_momentum * mean);
                         p.in_running_var[c] = (float)((1.0 - p.in_momentum) * p.in_running_var[c] + p.in_momentum * unbiased);
                     }
-                    if (p.in_acc_clear) { p.in_acc_clear[c] = 0; p.in_acc_clear[p.Cin + c] = 0; }
+                    if (p.in_acc_clear)
+                        for (int sh = 0; sh < p.in_shards; ++sh) {
+                            p.in_acc_clear[(long)sh * 2 * p.Cin + c] = 0;
+                            p.in_acc_clear[(long)sh * 2 * p.Cin + p.Cin + c] = 0;
+                        }
                 }
             } else {
                 sc = p.in_scale[c];
@@ -612,8 +623,9 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                     s += red[(g * 2 + 0) * BN + c];
                     q += red[(g * 2 + 1) * BN + c];
                 }
-                atomicAdd((unsigned long long*)(p.acc + col), (unsigned long long)__double2ll_rn((double)s * kStatScale));
-                atomicAdd((unsigned long long*)(p.acc + p.N + col), (unsigned long long)__double2ll_rn((double)q * kStatScale));
+                long long* dst = p.acc + (long)(bid & (p.acc_shards - 1)) * 2 * p.N;
+                atomicAdd((unsigned long long*)(dst + col), (unsigned long long)__double2ll_rn((double)s * kStatScale));
+                atomicAdd((unsigned long long*)(dst + p.N + col), (unsigned long long)__double2ll_rn((double)q * kStatScale));
             }
         }
     }
@@ -764,6 +776,8 @@ ConvArgs make_args(const sat_op* op) {
     a.A = (const bf16_t*)op->in0; a.B = (const bf16_t*)op->w; a.C = (bf16_t*)op->out;
     a.stat_partial = op->stat_partial;
     a.acc = (long long*)op->stat_acc;
+    a.acc_shards = op->stat_shards > 1 ? op->stat_shards : 1;
+    a.in_shards = op->stat_shards1 > 1 ? op->stat_shards1 : 1;
     a.in_affine = 0;
     if (op->scale0 || op->stat_acc1) {          // BatchNorm + ReLU of the INPUT fused into the A staging (1x1 convs)
         a.in_affine = 1;
@@ -822,7 +836,8 @@ int heuristic_variant(const ConvArgs& a) {
 int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
     if (op->Cout % 8) return SAT_ERR_UNSUPPORTED;
     ConvArgs a = make_args(op);
-    if (a.acc) a.acc += (long)parity * 2 * a.N;          // [2 parities][2][N]
+    if ((a.acc_shards & (a.acc_shards - 1)) || a.acc_shards > 8 || (a.in_shards & (a.in_shards - 1)) || a.in_shards > 8) return SAT_ERR_ARG;
+    if (a.acc) a.acc += (long)parity * a.acc_shards * 2 * a.N;          // [2 parities][shards][2][N]
     if ((a.out_scale != nullptr) != (a.out_shift != nullptr)) return SAT_ERR_ARG;
     if (a.residual && (!a.out_scale || (const void*)a.residual == (const void*)a.C)) return SAT_ERR_ARG;
     if (a.out_scale && (a.stat_partial || a.acc)) return SAT_ERR_ARG;     // batch statistics and a fixed affine exclude each other
@@ -836,8 +851,8 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
         if (a.in_acc) {
             if (!a.in_gamma || !a.in_beta || a.in_count < 1) return SAT_ERR_ARG;
             long long* base = (long long*)op->stat_acc1;       // [2 parities][2][Cin]
-            a.in_acc = base + (long)parity * 2 * a.Cin;
-            a.in_acc_clear = base + (long)(1 - parity) * 2 * a.Cin;
+            a.in_acc = base + (long)parity * a.in_shards * 2 * a.Cin;
+            a.in_acc_clear = base + (long)(1 - parity) * a.in_shards * 2 * a.Cin;
         } else if (!a.in_scale || !a.in_shift) {
             return SAT_ERR_ARG;
         }

@@ -195,8 +195,9 @@ __global__ __launch_bounds__(256) void bn_eval_batch_kernel(const sat_bn_eval_it
 struct BnSrc {
     const float* scale;
     const float* shift;
-    const long long* acc;     // [2][C] (this step's parity)
-    long long* acc_clear;     // [2][C] (other parity) or NULL
+    const long long* acc;     // [shards][2][C] (this step's parity)
+    long long* acc_clear;     // [shards][2][C] (other parity) or NULL
+    int shards;
     const float* gamma;
     const float* beta;
     float* running_mean;
@@ -207,8 +208,13 @@ __device__ __forceinline__ void bn_table_from_acc(const BnSrc& b, int C, double 
                                                   float* sc, float* sh) {
     const double inv = 1.0 / (SAT_STAT_SCALE * count);      // one f64 division per thread, none per channel
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double mean = (double)b.acc[c] * inv;
-        double var = (double)b.acc[C + c] * inv - mean * mean;
+        long long s1 = 0, s2 = 0;
+        for (int sh = 0; sh < b.shards; ++sh) {              // integer sums: order independent
+            s1 += b.acc[(long)sh * 2 * C + c];
+            s2 += b.acc[(long)sh * 2 * C + C + c];
+        }
+        const double mean = (double)s1 * inv;
+        double var = (double)s2 * inv - mean * mean;
         if (var < 0.0) var = 0.0;
         const float invstd = 1.0f / sqrtf((float)var + eps);
         const float s = b.gamma[c] * invstd;
@@ -220,7 +226,8 @@ __device__ __forceinline__ void bn_table_from_acc(const BnSrc& b, int C, double 
                 b.running_mean[c] = (float)((1.0 - momentum) * b.running_mean[c] + momentum * mean);
                 b.running_var[c] = (float)((1.0 - momentum) * b.running_var[c] + momentum * unbiased);
             }
-            if (b.acc_clear) { b.acc_clear[c] = 0; b.acc_clear[C + c] = 0; }
+            if (b.acc_clear)
+                for (int sh = 0; sh < b.shards; ++sh) { b.acc_clear[(long)sh * 2 * C + c] = 0; b.acc_clear[(long)sh * 2 * C + C + c] = 0; }
         }
     }
 }
@@ -871,7 +878,8 @@ int sat_bn_finalize_launch(const sat_op* op, int parity, hipStream_t s) {
         // the same fixed-point integer accumulators the few-tile convs feed directly, and the consuming kernel derives
         // (scale, shift) itself: ~3 us of wide parallel work instead of a 5-11 us latency-bound tail of 2-16 workgroups.
         if (!op->stat_partial || op->tiles_m < 1 || op->Cout < 1) return SAT_ERR_ARG;
-        long long* acc = (long long*)op->stat_acc + (long)parity * 2 * op->Cout;
+        const int sh = op->stat_shards > 1 ? op->stat_shards : 1;      // the reducer adds into shard 0 of this parity's block
+        long long* acc = (long long*)op->stat_acc + (long)parity * sh * 2 * op->Cout;
         hipLaunchKernelGGL(bn_slab_to_acc_kernel, dim3(sat_cdiv(op->Cout, 32), sat_cdiv(op->tiles_m, SLAB_TILES_PER_WG)),
                            dim3(1024), 0, s, op->stat_partial, op->tiles_m, op->Cout, acc);
         SAT_LAUNCH_CHECK();
@@ -901,9 +909,10 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
     size_t lds = 0;
     if (op->stat_acc) {              // statistics arrive as integer sums: derive the table in the kernel
         if (!op->gamma || !op->beta || op->count < 1) return SAT_ERR_ARG;
-        long long* base = (long long*)op->stat_acc;          // [2 parities][2][C]
-        b0.acc = base + (long)parity * 2 * C;
-        b0.acc_clear = base + (long)(1 - parity) * 2 * C;
+        long long* base = (long long*)op->stat_acc;          // [2 parities][shards][2][C]
+        b0.shards = op->stat_shards > 1 ? op->stat_shards : 1;
+        b0.acc = base + (long)parity * b0.shards * 2 * C;
+        b0.acc_clear = base + (long)(1 - parity) * b0.shards * 2 * C;
         b0.gamma = op->gamma; b0.beta = op->beta; b0.running_mean = op->running_mean; b0.running_var = op->running_var;
         lds = (size_t)4 * C * sizeof(float);
     } else if (!op->scale0 || !op->shift0) {
@@ -913,8 +922,9 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
         if (op->stat_acc1) {
             if (!op->gamma1 || !op->beta1 || op->count < 1) return SAT_ERR_ARG;
             long long* base = (long long*)op->stat_acc1;
-            b1.acc = base + (long)parity * 2 * C;
-            b1.acc_clear = base + (long)(1 - parity) * 2 * C;
+            b1.shards = op->stat_shards1 > 1 ? op->stat_shards1 : 1;
+            b1.acc = base + (long)parity * b1.shards * 2 * C;
+            b1.acc_clear = base + (long)(1 - parity) * b1.shards * 2 * C;
             b1.gamma = op->gamma1; b1.beta = op->beta1; b1.running_mean = op->running_mean1; b1.running_var = op->running_var1;
             lds = (size_t)4 * C * sizeof(float);
             has_b1 = 1;
@@ -962,8 +972,9 @@ int sat_bn_relu_maxpool_launch(const sat_op* op, int parity, hipStream_t s) {
     if (op->stat_acc) {
         if (!op->gamma || !op->beta || op->count < 1) return SAT_ERR_ARG;
         long long* base = (long long*)op->stat_acc;
-        b.acc = base + (long)parity * 2 * C;
-        b.acc_clear = base + (long)(1 - parity) * 2 * C;
+        b.shards = op->stat_shards > 1 ? op->stat_shards : 1;
+        b.acc = base + (long)parity * b.shards * 2 * C;
+        b.acc_clear = base + (long)(1 - parity) * b.shards * 2 * C;
         b.gamma = op->gamma; b.beta = op->beta; b.running_mean = op->running_mean; b.running_var = op->running_var;
         lds = (size_t)2 * C * sizeof(float);
         if (lds > 64 * 1024) return SAT_ERR_UNSUPPORTED;

@@ -229,31 +229,36 @@ class ConvStackProgram:
         fuse_in_bn = dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_INPUT_BN", "1") != "0"   # bn2+ReLU inside conv3
         slab_to_acc = os.environ.get("SAT_SLAB_TO_ACC", "1") != "0"
         fuse_out_bn = (not training) and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_EVAL_BN", "1") != "0"
-        if atomic_stats:
-            self.stat_acc = alloc((nbn, 2, 2, cmax), torch.int64, zero=True)
+        # many-tile layers (ATOMIC_MAX_TILES < tiles <= SHARD_MAX_TILES): the same integer atomics into 8 SHARDS of the
+        # accumulator (workgroup id % 8), summed by the consumer: no per-tile slabs, no reducer launch
+        SHARD_MAX_TILES = int(os.environ.get("SAT_SHARDED_BN_MAX_TILES", "1600"))
+        self.stat_accs = []
 
         eval_items = []
 
         def fin_op(bn, c, count, tiles_m, consumer_can_derive=True):
             s, t = new_scale_shift(c)
-            if atomic_stats and consumer_can_derive and tiles_m <= ATOMIC_MAX_TILES:
-                i = bn_idx[0] - 1
+            if atomic_stats and consumer_can_derive and tiles_m <= max(ATOMIC_MAX_TILES, SHARD_MAX_TILES):
+                shards = 1 if tiles_m <= ATOMIC_MAX_TILES else 8
+                acc = alloc((2, shards, 2, c), torch.int64, zero=True)
+                self.stat_accs.append(acc)
                 cv = ops[-1]                       # the conv that produces this BN's input
                 assert cv.kind == L.OP_CONV and cv.Cout == c
                 cv.stat_partial = None
-                cv.stat_acc = self.stat_acc[i].data_ptr()
-                bnref[s.data_ptr()] = (self.stat_acc[i].data_ptr(), bn, count)
+                cv.stat_acc, cv.stat_shards = acc.data_ptr(), shards
+                bnref[s.data_ptr()] = (acc.data_ptr(), bn, count, shards)
                 self.bn_list.append(bn)
                 return None, s, t
             if atomic_stats and consumer_can_derive and slab_to_acc:
-                # many M-tiles: the conv keeps writing per-tile slabs (no contended atomics), a wide reducer launch
-                # folds them into the same integer accumulators, and the consumer derives (scale, shift) as above
-                i = bn_idx[0] - 1
+                # very many M-tiles (the stem): the conv keeps writing per-tile slabs (no contended atomics), a wide reducer
+                # launch folds them into the same integer accumulators, and the consumer derives (scale, shift) as above
+                acc = alloc((2, 1, 2, c), torch.int64, zero=True)
+                self.stat_accs.append(acc)
                 o = L.SatOp()
                 o.kind, o.dtype = L.OP_BN_FINALIZE, dtype
-                o.stat_partial, o.stat_acc = self.partial.data_ptr(), self.stat_acc[i].data_ptr()
+                o.stat_partial, o.stat_acc = self.partial.data_ptr(), acc.data_ptr()
                 o.Cout, o.tiles_m, o.training = c, tiles_m, 1
-                bnref[s.data_ptr()] = (self.stat_acc[i].data_ptr(), bn, count)
+                bnref[s.data_ptr()] = (acc.data_ptr(), bn, count, 1)
                 self.bn_list.append(bn)
                 return o, s, t
             if not training:
@@ -285,8 +290,8 @@ class ConvStackProgram:
             if ref is None:
                 o.scale0, o.shift0 = s.data_ptr(), t.data_ptr()
             else:                                  # derive (scale, shift) from the conv's integer sums
-                acc, bn, count = ref
-                o.stat_acc = acc
+                acc, bn, count, shards = ref
+                o.stat_acc, o.stat_shards = acc, shards
                 o.gamma, o.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
                 o.running_mean, o.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
                 o.count, o.momentum, o.eps = count, BN_MOMENTUM, BN_EPS
@@ -297,8 +302,8 @@ class ConvStackProgram:
                     if ref1 is None:
                         o.scale1, o.shift1 = s1.data_ptr(), t1.data_ptr()
                     else:
-                        acc1, bn1_, count1 = ref1
-                        o.stat_acc1 = acc1
+                        acc1, bn1_, count1, shards1 = ref1
+                        o.stat_acc1, o.stat_shards1 = acc1, shards1
                         o.gamma1, o.beta1 = bn1_.weight.data_ptr(), bn1_.bias.data_ptr()
                         o.running_mean1, o.running_var1 = bn1_.running_mean.data_ptr(), bn1_.running_var.data_ptr()
                         o.count, o.momentum, o.eps = count1, BN_MOMENTUM, BN_EPS
@@ -334,8 +339,8 @@ class ConvStackProgram:
         if ref is None:
             mp.scale0, mp.shift0 = s.data_ptr(), t.data_ptr()
         else:                                      # the pooling kernel derives (scale, shift) from the integer sums
-            acc, bn_, count_ = ref
-            mp.stat_acc = acc
+            acc, bn_, count_, shards_ = ref
+            mp.stat_acc, mp.stat_shards = acc, shards_
             mp.gamma, mp.beta = bn_.weight.data_ptr(), bn_.bias.data_ptr()
             mp.running_mean, mp.running_var = bn_.running_mean.data_ptr(), bn_.running_var.data_ptr()
             mp.count, mp.momentum, mp.eps = count_, BN_MOMENTUM, BN_EPS
@@ -380,8 +385,8 @@ class ConvStackProgram:
                 if ref is None:
                     cv1.scale0, cv1.shift0 = ps3.data_ptr(), pt3.data_ptr()
                 else:
-                    acc3, bn3_, count3 = ref
-                    cv1.stat_acc1 = acc3
+                    acc3, bn3_, count3, shards3 = ref
+                    cv1.stat_acc1, cv1.stat_shards1 = acc3, shards3
                     cv1.gamma1, cv1.beta1 = bn3_.weight.data_ptr(), bn3_.bias.data_ptr()
                     cv1.running_mean1, cv1.running_var1 = bn3_.running_mean.data_ptr(), bn3_.running_var.data_ptr()
                     cv1.count, cv1.momentum, cv1.eps = count3, BN_MOMENTUM, BN_EPS
@@ -402,8 +407,8 @@ class ConvStackProgram:
                 if ref is None:
                     cv3.scale0, cv3.shift0 = s2.data_ptr(), t2.data_ptr()
                 else:
-                    acc2, bn2_, count2 = ref
-                    cv3.stat_acc1 = acc2
+                    acc2, bn2_, count2, shards2 = ref
+                    cv3.stat_acc1, cv3.stat_shards1 = acc2, shards2
                     cv3.gamma1, cv3.beta1 = bn2_.weight.data_ptr(), bn2_.bias.data_ptr()
                     cv3.running_mean1, cv3.running_var1 = bn2_.running_mean.data_ptr(), bn2_.running_var.data_ptr()
                     cv3.count, cv3.momentum, cv3.eps = count2, BN_MOMENTUM, BN_EPS

@@ -355,9 +355,11 @@ def test_fc_bn1d_fwd_bwd(lib):
     assert db.cpu().abs().max().item() < 5e-4 and gr["resnet.fc.bias"].abs().max().item() < 5e-4
 
 
-def test_conv_atomic_stats_then_consumer_derives_affine(lib):
-    """bf16 conv adds fixed-point column sums with integer atomics; BN_RELU / BN_ADD_RELU derive scale/shift from them,
-    update the running statistics once, clear the other parity's accumulators; results are bitwise reproducible"""
+@pytest.mark.parametrize("shards", [1, 8])
+def test_conv_atomic_stats_then_consumer_derives_affine(lib, shards):
+    """bf16 conv adds fixed-point column sums with integer atomics (optionally into 8 shards of the accumulator: workgroup
+    id % 8); BN_RELU / BN_ADD_RELU sum the shards, derive scale/shift, update the running statistics once, clear the other
+    parity's accumulators; results are bitwise reproducible -- and identical for 1 and 8 shards (integer sums)"""
     N, H, W, Cin, Cout = 6, 20, 20, 64, 192
     g = torch.Generator().manual_seed(93)
     x = (torch.randn(N, Cin, H, W, generator=g) + 0.3).bfloat16().float()
@@ -367,9 +369,9 @@ def test_conv_atomic_stats_then_consumer_derives_affine(lib):
     ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cout)
     M = ref.shape[0]
     conv, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1, stats=False)
-    acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+    acc = torch.zeros(2, shards, 2, Cout, dtype=torch.int64, device="cuda")
     acc[1] = 12345                                     # stale other-parity half: must be cleared by the consumer
-    conv.stat_acc = acc.data_ptr()
+    conv.stat_acc, conv.stat_shards = acc.data_ptr(), shards
     gd, bd = cu(gamma), cu(beta)
     rm, rv = cu(torch.zeros(Cout)), cu(torch.ones(Cout))
     idd = cu(idt)
@@ -378,6 +380,7 @@ def test_conv_atomic_stats_then_consumer_derives_affine(lib):
     act.kind, act.dtype = L.OP_BN_ADD_RELU, L.SAT_BF16
     act.in0, act.in1, act.out = keep[2].data_ptr(), idd.data_ptr(), y1.data_ptr()
     act.stat_acc, act.gamma, act.beta = acc.data_ptr(), gd.data_ptr(), bd.data_ptr()
+    act.stat_shards = shards
     act.running_mean, act.running_var = rm.data_ptr(), rv.data_ptr()
     act.count, act.momentum, act.eps = M, 0.1, 1e-5
     act.N, act.Hout, act.Wout, act.Cout = N, H, W, Cout
@@ -392,6 +395,9 @@ def test_conv_atomic_stats_then_consumer_derives_affine(lib):
     np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * var * M / (M - 1)).numpy(), rtol=1e-3)
     assert int(acc[1].abs().sum()) == 0 and int(acc[0].abs().sum()) > 0
+    if shards > 1:                                      # 19 row tiles x 2 column tiles spread over the shards; totals = the plain sums
+        assert int((acc[0, :, 0].abs().sum(1) > 0).sum()) > 1
+        np.testing.assert_allclose((acc[0].sum(0)[0].cpu().double() / 2 ** 22).numpy(), ref.sum(0).numpy(), rtol=0, atol=2e-2 * M ** 0.5)
     # next step uses parity 1 and clears parity 0; same data => bit-identical output
     y_first = y1.clone()
     L.check(lib.sat_run_ops_parity(ops, 2, 1, st()))
