@@ -113,7 +113,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // barrier kt (one in-flight K-step fewer than the ring could hold, hence S >= 4).
 // DUAL: two-source A operand (ConvArgs::R/Y); BM: tile rows (128; 64 for the wide dual tiles, whose A side is the
 // expensive one: two sources and an in-LDS pass, so it is kept short and the tile covers all of N instead).
-template <int BN, int S, int NW, bool UNIFORM, bool SPEC = false, bool PF = false, int BM = 128, bool DUAL = false>
+// XA: single-source input affine (BatchNorm + ReLU of the operand) in the PIPELINED form of the dual kernel -- the transform
+// of stage kt+1 is issued around the MFMAs of stage kt, one barrier per K-step -- and for ANY uniform geometry: on a 3x3
+// conv a per-row tap mask keeps the zero padding zero (relu(0*s+t) is not 0).
+template <int BN, int S, int NW, bool UNIFORM, bool SPEC = false, bool PF = false, int BM = 128, bool DUAL = false, bool XA = false>
 __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     constexpr int BK = 64, NT = NW * 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES + (DUAL ? A_BYTES : 0);
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     constexpr int NAI = BM / 8 / LW, NBI = BN / 8 / LW;   // LDS-DMA pieces (8 rows x 128 B) per loader wave per stage
     constexpr int LPW = NAI + NBI + (DUAL ? NAI : 0);
     static_assert(!DUAL || (UNIFORM && !SPEC && !PF), "the dual-source transform lives in the plain unified-wave loop");
+    static_assert(!XA || (UNIFORM && !SPEC && !PF && !DUAL && S >= 3), "pipelined input affine: unified waves, a landed stage ahead");
     constexpr int D = S - 1;                               // K-steps kept in flight
     constexpr int WAITN = LPW * (PF ? D - 2 : D - 1);      // loader pieces that may still be in flight at a barrier
     static_assert(!PF || S >= 4, "fragment prefetch needs one more landed stage");
@@ -410,8 +414,33 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     // DUAL, software pipelined: the transform of stage kt+1 is split around the MFMAs of stage kt -- its LDS reads go out
     // first, the arithmetic / LDS write / global store of y follow the matrix work -- so the only per-K-step barrier is
     // the ring's own and a wave's VALU pass overlaps its SIMD partner's MFMAs
-    constexpr int NCH = DUAL ? BM * 8 / NT : 1;
+    constexpr int NCH = (DUAL || XA) ? BM * 8 / NT : 1;
     bf16x8 dv[NCH], dz[NCH];
+    unsigned t_mask[NCH];                 // XA: bit t = tap t of this thread's row j is inside the image
+    if constexpr (XA) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int grow = m0 + ((tid + j * NT) >> 3);
+            t_mask[j] = 0u;
+            if (grow < p.M) {
+                if (p.linear) {
+                    t_mask[j] = 1u;
+                } else {
+                    const int hw = p.Hout * p.Wout;
+                    const int n = grow / hw;
+                    const int rem = grow - n * hw;
+                    const int ho = rem / p.Wout;
+                    const int wo = rem - ho * p.Wout;
+                    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                    for (int kh = 0; kh < p.KH; ++kh)
+                        for (int kw = 0; kw < p.KW; ++kw) {
+                            const bool in = ((unsigned)(hi0 + kh) < (unsigned)p.Hin) && ((unsigned)(wi0 + kw) < (unsigned)p.Win);
+                            t_mask[j] |= (in ? 1u : 0u) << (kh * p.KW + kw);
+                        }
+                }
+            }
+        }
+    }
     auto dual_load = [&](int buf) {
         const char* sA = smem + buf * STAGE;
 #pragma unroll
@@ -419,24 +448,35 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             const int q = tid + j * NT;
             const int row = q >> 3, pos = q & 7;
             dv[j] = *(const bf16x8*)(sA + row * 128 + pos * 16);
-            dz[j] = *(const bf16x8*)(sA + R_OFF + row * 128 + pos * 16);
+            if constexpr (DUAL) dz[j] = *(const bf16x8*)(sA + R_OFF + row * 128 + pos * 16);
         }
     };
-    auto dual_finish = [&](int buf, int kt) {
+    // cbase: first input channel of the stage (DUAL / 1x1: kt * 64; 3x3: the tap's channel block); tap: the stage's filter tap
+    auto dual_finish = [&](int buf, int cbase, int tap) {
         char* sA = smem + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int q = tid + j * NT;
             const int row = q >> 3, pos = q & 7;
-            if (m0 + row < p.M) {
-                const int c0 = kt * BK + ((pos ^ ((row >> 1) & 7)) << 3);
+            bool live = m0 + row < p.M;
+            if constexpr (XA) live = ((t_mask[j] >> tap) & 1u) != 0u;       // padded taps (and rows past M) stay exact zeros
+            if (live) {
+                const int c0 = cbase + ((pos ^ ((row >> 1) & 7)) << 3);
                 const f32x4 s0 = *(const f32x4*)(in_tab + c0), s1 = *(const f32x4*)(in_tab + c0 + 4);
                 const f32x4 t0 = *(const f32x4*)(in_tab + p.Cin + c0), t1 = *(const f32x4*)(in_tab + p.Cin + c0 + 4);
                 bf16x8 v = dv[j];
+                if constexpr (DUAL) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e] + (float)dz[j][e], 0.0f);
-                    v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e] + (float)dz[j][e + 4], 0.0f);
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e] + (float)dz[j][e], 0.0f);
+                        v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e] + (float)dz[j][e + 4], 0.0f);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e], 0.0f);
+                        v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e], 0.0f);
+                    }
                 }
                 *(bf16x8*)(sA + row * 128 + pos * 16) = v;
             }
@@ -535,8 +575,14 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 buf = (buf + 1 == S) ? 0 : buf + 1;
             }
         }
-    } else if constexpr (DUAL) {
-        static_assert(S >= 3, "the pipelined dual transform needs a landed stage ahead of the one being computed");
+    } else if constexpr (DUAL || XA) {
+        static_assert(S >= 3, "the pipelined transform needs a landed stage ahead of the one being computed");
+        // channel block / tap of the stage being transformed (scalar walk, like the loader's)
+        int xf_cb = 0, xf_tap = 0;
+        auto xf_next = [&]() {
+            xf_cb += BK;
+            if (!p.linear && xf_cb >= p.Cin) { xf_cb = 0; ++xf_tap; }
+        };
         constexpr int WAITD = LPW * (D - 2);     // pieces that may still be in flight once stage kt+1 must have landed
         if (is_loader) {
 #pragma unroll
@@ -546,7 +592,8 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         __builtin_amdgcn_s_barrier();            // ... and everybody's
         asm volatile("" ::: "memory");
         dual_load(0);
-        dual_finish(0, 0);
+        dual_finish(0, xf_cb, xf_tap);
+        xf_next();
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my transform writes of stage kt (and LDS reads) are done
@@ -559,9 +606,11 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             const int tbuf = (buf + 1 == S) ? 0 : buf + 1;
             const bool more = kt + 1 < nk;
             if (more) dual_load(tbuf);
-            if (!is_loader && tile_n == 0) dual_store_y(buf, kt);  // stage kt is final: y goes out under the MFMAs
+            if constexpr (DUAL) {
+                if (!is_loader && tile_n == 0) dual_store_y(buf, kt);  // stage kt is final: y goes out under the MFMAs
+            }
             if (!(p.dbg & 2)) compute(buf);
-            if (more) dual_finish(tbuf, kt + 1);
+            if (more) { dual_finish(tbuf, xf_cb, xf_tap); xf_next(); }
             buf = tbuf;
         }
     } else {
@@ -689,7 +738,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     }
 }
 
-template <int BN, int S, int NW, bool SPEC = false, bool PF = false, int BM = 128, bool DUAL = false>
+template <int BN, int S, int NW, bool SPEC = false, bool PF = false, int BM = 128, bool DUAL = false, bool XA = false>
 int launch_glds(ConvArgs& a, hipStream_t s) {
     const int tm = sat_cdiv(a.M, BM), tn = sat_cdiv(a.N, BN);
     a.tiles_n = tn;
@@ -697,10 +746,10 @@ int launch_glds(ConvArgs& a, hipStream_t s) {
     const dim3 grid(tm * tn), block(NW * 64);
     hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;     // armed: timed diagnostic launch (same kernel, same grid, + the packet's timestamps)
     t_ev_start = t_ev_stop = nullptr;
-    if constexpr (DUAL) {
+    if constexpr (DUAL || XA) {
         if (!uniform) return SAT_ERR_UNSUPPORTED;
-        if (e0) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM, true>), grid, block, 0, s, e0, e1, 0, a);
-        else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM, true>), grid, block, 0, s, a);
+        if (e0) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM, DUAL, XA>), grid, block, 0, s, e0, e1, 0, a);
+        else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM, DUAL, XA>), grid, block, 0, s, a);
     } else if (uniform) {
         if (e0) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM>), grid, block, 0, s, a);
@@ -719,7 +768,7 @@ int tune_env(const char* name, int dflt) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows, dual-source A).
 // LDS = S * (BM/8 + BN/8 [+ BM/8]) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, dual; };
+struct Variant { int bn, s, nw, spec, pf, bm, dual, xa; };
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128, 0}, {128, 3, 8, 0, 0, 128, 0}, {128, 2, 8, 0, 0, 128, 0}, {64, 4, 8, 0, 0, 128, 0}, {64, 3, 8, 0, 0, 128, 0},
     {64, 2, 8, 0, 0, 128, 0}, {128, 4, 4, 0, 0, 128, 0}, {128, 2, 4, 0, 0, 128, 0}, {64, 3, 4, 0, 0, 128, 0}, {64, 2, 4, 0, 0, 128, 0},
@@ -730,6 +779,8 @@ constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 64, 1},                                                                                                       // dual-source A (bn3 + add + ReLU of the previous block)
     {256, 2, 8, 0, 0, 128, 0}, {256, 3, 8, 0, 0, 128, 0}, {256, 3, 8, 0, 0, 64, 0},                                                   // wide tiles
     {128, 3, 8, 0, 0, 64, 0}, {128, 2, 8, 0, 0, 64, 0},                                                                             // 64-row tiles: 2 workgroups per CU on the N = 256 layers
+    {128, 3, 8, 0, 0, 128, 0, 1}, {128, 4, 8, 0, 0, 128, 0, 1}, {64, 3, 8, 0, 0, 128, 0, 1}, {64, 4, 8, 0, 0, 128, 0, 1},
+    {128, 3, 8, 0, 0, 64, 0, 1}, {128, 4, 8, 0, 0, 64, 0, 1}, {256, 3, 8, 0, 0, 128, 0, 1},                                          // pipelined input affine (any uniform geometry)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -767,6 +818,13 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 29: return launch_glds<256, 3, 8, false, false, 64>(a, s);
         case 30: return launch_glds<128, 3, 8, false, false, 64>(a, s);
         case 31: return launch_glds<128, 2, 8, false, false, 64>(a, s);
+        case 32: return launch_glds<128, 3, 8, false, false, 128, false, true>(a, s);
+        case 33: return launch_glds<128, 4, 8, false, false, 128, false, true>(a, s);
+        case 34: return launch_glds<64, 3, 8, false, false, 128, false, true>(a, s);
+        case 35: return launch_glds<64, 4, 8, false, false, 128, false, true>(a, s);
+        case 36: return launch_glds<128, 3, 8, false, false, 64, false, true>(a, s);
+        case 37: return launch_glds<128, 4, 8, false, false, 64, false, true>(a, s);
+        case 38: return launch_glds<256, 3, 8, false, false, 128, false, true>(a, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -816,6 +874,8 @@ bool variant_ok(int v, const ConvArgs& a) {
     if (k.bn == 256 && a.N <= 128) return false;
     if ((k.spec || k.pf) && a.in_affine) return false;
     if ((k.dual != 0) != (a.R != nullptr)) return false;             // dual-source ops run dual kernels and nothing else
+    if (k.xa && (!a.in_affine || a.R || !((a.Cin % 64 == 0) && (a.KH * a.KW <= 32)))) return false;
+    if (!k.xa && !k.dual && a.in_affine && !a.linear) return false;  // the un-pipelined in-LDS transform is 1x1-only (no tap mask)
     if (k.bm != 128 && a.stat_partial) return false;                 // the per-tile statistics slabs are 128-row tiles
     return true;
 }
@@ -824,6 +884,7 @@ int heuristic_variant(const ConvArgs& a) {
     // 128x128 with a deep ring when it still leaves >= 2 tiles per CU and K is long enough to use the ring;
     // otherwise 128x64 with a shallower ring (more workgroups per CU to overlap prologue/epilogue phases)
     if (a.R) return a.N > 128 ? 21 : 25;          // dual-source: 64-row tiles covering all of N where N <= 256
+    if (a.in_affine && !a.linear) return a.N > 64 ? 32 : 34;      // 3x3 with a fused input BatchNorm: pipelined transform only
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const int nk = sat_cdiv(a.K, 64);
     if (a.N > 64 && t128 >= 512) return nk <= 4 ? 2 : 0;
@@ -847,7 +908,7 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
         if ((const void*)a.Y == (const void*)a.A || (const void*)a.Y == (const void*)a.R || (const void*)a.Y == (const void*)a.C) return SAT_ERR_ARG;
     }
     if (a.in_affine) {
-        if (!a.linear || a.Cin > (a.R ? 2048 : 512) || (a.Cin % 64)) return SAT_ERR_UNSUPPORTED;
+        if (a.Cin > (a.R ? 2048 : 512) || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;
         if (a.in_acc) {
             if (!a.in_gamma || !a.in_beta || a.in_count < 1) return SAT_ERR_ARG;
             long long* base = (long long*)op->stat_acc1;       // [2 parities][2][Cin]
@@ -901,7 +962,7 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
         if (a.in_affine) {           // ... nor derive from / clear the live accumulators: the neutral table stands in
             a.in_acc = nullptr; a.in_acc_clear = nullptr; a.in_running_mean = nullptr;
             a.in_scale = scratch; a.in_shift = scratch + kTuneTab;
-            if (!a.linear || a.Cin > (a.R ? 2048 : 512) || (a.Cin % 64)) continue;
+            if (a.Cin > (a.R ? 2048 : 512) || (a.Cin % 64) || (a.KH * a.KW > 32)) continue;
         }
         float best = 1e30f;
         int best_v = heuristic_variant(a);

@@ -227,6 +227,7 @@ class ConvStackProgram:
         self._parity = 0
         bnref = {}
         fuse_in_bn = dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_INPUT_BN", "1") != "0"   # bn2+ReLU inside conv3
+        fuse_bn1 = training and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_BN1", "1") != "0"   # bn1+ReLU inside conv2 (3x3)
         slab_to_acc = os.environ.get("SAT_SLAB_TO_ACC", "1") != "0"
         fuse_out_bn = (not training) and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_EVAL_BN", "1") != "0"
         # many-tile layers (ATOMIC_MAX_TILES < tiles <= SHARD_MAX_TILES): the same integer atomics into 8 SHARDS of the
@@ -396,8 +397,23 @@ class ConvStackProgram:
                 ops.append(std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_))
             f, s1, t1 = fin_op(blk.bn1, planes, N * h * w_, tm1)
             add(f)
-            ops.append(act_op(L.OP_BN_RELU, self.c1, s1, t1, self.a1, N, h, w_, planes))
-            ops.append(std_conv(blk.conv2, self.a1, self.c2, N, h, w_, h2, w2))
+            if fuse_bn1 and planes <= 512 and planes % 64 == 0:
+                # conv2 (3x3) reads the RAW c1 and applies bn1 + ReLU to every landed A stage in LDS (pipelined one K-step
+                # ahead of the MFMAs; a per-row tap mask keeps the zero padding zero): a1 never exists in HBM
+                cv2 = std_conv(blk.conv2, self.c1, self.c2, N, h, w_, h2, w2)
+                ref = bnref.get(s1.data_ptr())
+                if ref is None:
+                    cv2.scale0, cv2.shift0 = s1.data_ptr(), t1.data_ptr()
+                else:
+                    acc1_, bn1m, count1_, shards1_ = ref
+                    cv2.stat_acc1, cv2.stat_shards1 = acc1_, shards1_
+                    cv2.gamma1, cv2.beta1 = bn1m.weight.data_ptr(), bn1m.bias.data_ptr()
+                    cv2.running_mean1, cv2.running_var1 = bn1m.running_mean.data_ptr(), bn1m.running_var.data_ptr()
+                    cv2.count, cv2.momentum, cv2.eps = count1_, BN_MOMENTUM, BN_EPS
+                ops.append(cv2)
+            else:
+                ops.append(act_op(L.OP_BN_RELU, self.c1, s1, t1, self.a1, N, h, w_, planes))
+                ops.append(std_conv(blk.conv2, self.a1, self.c2, N, h, w_, h2, w2))
             f, s2, t2 = fin_op(blk.bn2, planes, N * h2 * w2, tm2)
             add(f)
             if fuse_in_bn and planes <= 512 and planes % 64 == 0:

@@ -107,8 +107,8 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 32
-PLAIN_CONV_VARIANTS = list(range(1, 22)) + [28, 29, 30, 31, 32]      # 22..27 are dual-source only (their own test)
+NUM_CONV_VARIANTS = 39
+PLAIN_CONV_VARIANTS = list(range(1, 22)) + [28, 29, 30, 31, 32]      # 33..39: pipelined input affine (their own test)      # 22..27 are dual-source only (their own test)
 
 
 @pytest.mark.parametrize("variant", PLAIN_CONV_VARIANTS)
@@ -755,3 +755,42 @@ def test_fused_vocab_ce_fwd_and_bwd_vs_fp64(lib, N, H, V):
     np.testing.assert_allclose(dw.cpu().numpy(), Wq.grad.numpy(), rtol=1e-4, atol=2e-8)
     np.testing.assert_allclose(db.cpu().numpy(), bq.grad.numpy(), rtol=1e-4, atol=2e-8)
     np.testing.assert_allclose(dH.cpu().numpy(), Hq.grad.numpy(), rtol=1e-4, atol=2e-8)
+
+
+@pytest.mark.parametrize("variant", [0, 33, 34, 35, 36, 37, 38, 39])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(3, 14, 14, 128, 192, 3, 1, 1), (2, 15, 13, 64, 64, 3, 2, 1), (4, 9, 9, 256, 320, 1, 1, 0)])
+def test_conv_with_pipelined_input_bn_relu_any_geometry(lib, variant, N, H, W, Cin, Cout, k, stride, pad):
+    """XA variants: the operand's BatchNorm + ReLU applied to each landed LDS stage one K-step ahead of the MFMAs, for 3x3 convs
+    too: a per-row tap mask keeps the zero padding zero (relu(0*s+t) would not be).  Table derived from integer sums."""
+    g = torch.Generator().manual_seed(171 + variant + Cin)
+    x = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.5 + 0.3       # positive shifts: a wrong pad shows
+    xf = x.float().reshape(-1, Cin).double()
+    Mi = xf.shape[0]
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
+    shift = (beta.double() - mean * scale.double()).float()
+    a = torch.clamp(x.float() * scale + shift, min=0).bfloat16().float()
+    ref = F.conv2d(a.permute(0, 3, 1, 2).double(), w.float().permute(0, 3, 1, 2).double(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+    o, keep, _ = _conv_op(L.SAT_BF16, x.float(), w.float(), stride, pad, stats=False)
+    o.variant = variant
+    own = torch.zeros(2, 8, 2, Cout, dtype=torch.int64, device="cuda")
+    o.stat_acc, o.stat_shards = own.data_ptr(), 8
+    acc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
+    acc[0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
+    acc[0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
+    acc[1] = 777
+    gd, bd, rm, rv = cu(gamma), cu(beta), cu(torch.zeros(Cin)), cu(torch.ones(Cin))
+    o.stat_acc1, o.gamma1, o.beta1 = acc.data_ptr(), gd.data_ptr(), bd.data_ptr()
+    o.running_mean1, o.running_var1 = rm.data_ptr(), rv.data_ptr()
+    o.count, o.momentum, o.eps = Mi, 0.1, 1e-5
+    L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+    sync()
+    out = keep[2].float().cpu().double()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < 3e-2 + 6e-3 * ref.abs().max().item(), (out - ref).abs().max().item()
+    s1 = own[0].sum(0)[0].cpu().double() / 2 ** 22
+    np.testing.assert_allclose(s1.numpy(), ref.sum(0).numpy(), rtol=2e-3, atol=0.3 + 2e-3 * ref.shape[0] ** 0.5)
+    assert int(acc[1].abs().sum()) == 0
+    np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-4, atol=1e-6)
