@@ -235,7 +235,9 @@ class ConvStackProgram:
         fuse_out_bn = (not training) and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_EVAL_BN", "1") != "0"
         # many-tile layers (ATOMIC_MAX_TILES < tiles <= SHARD_MAX_TILES): the same integer atomics into 8 SHARDS of the
         # accumulator (workgroup id % 8), summed by the consumer: no per-tile slabs, no reducer launch
-        SHARD_MAX_TILES = int(os.environ.get("SAT_SHARDED_BN_MAX_TILES", "1600"))
+        # OPT-IN (SAT_SHARDED_BN_MAX_TILES=1600): measured a wash at cfg 2 (6.861 vs 6.866 ms/step: the 36 reducer launches
+        # it removes cost 0.18 ms, the contended atomics and the 8-shard table derivation in every consumer give it back)
+        SHARD_MAX_TILES = int(os.environ.get("SAT_SHARDED_BN_MAX_TILES", "0"))
         self.stat_accs = []
 
         eval_items = []
