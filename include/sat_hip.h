@@ -60,6 +60,8 @@ enum {
     SAT_OP_BN_ADD_RELU = 5,/* out = relu(in0*scale0+shift0 + (in1*scale1+shift1 | in1)) */
     SAT_OP_BN_RELU_MAXPOOL = 6, /* out = maxpool3x3/2(relu(in0*scale0+shift0)) */
     SAT_OP_AVGPOOL = 7,    /* out f32 [N][C] = mean over Hin*Win of in0 */
+    SAT_OP_MAXPOOL3S2 = 10,/* out = maxpool 3x3 / stride 2 / no padding of in0 (NHWC, Cout channels; ldc = output row pitch) */
+    SAT_OP_AVGPOOL3 = 11,  /* out = avgpool 3x3 / stride 1 / pad 1, count_include_pad (divide by 9) of in0 (NHWC, Cout channels) */
     SAT_OP_MAXPOOL2 = 9,   /* out = maxpool 2x2 / stride 2 of in0 (NHWC; Hin, Win even; Cout channels): VGG16, model2.py:15-16 */
     SAT_OP_BN_EVAL_BATCH = 8 /* eval mode: in0 = DEVICE array of `count` sat_bn_eval_item; every item's (scale, shift)
                               * from its running statistics in ONE launch (replaces one BN_FINALIZE per layer); eps */
@@ -131,7 +133,15 @@ typedef struct sat_op {
      * describes stat_acc1 the same way. */
     int32_t stat_shards;
     int32_t stat_shards1;
+    /* SAT_OP_CONV extras for Inception-style stacks (BASELINE configs[3]): flags bit 1 (SAT_CONV_PADW) = the padding differs per
+     * axis: `pad` is the vertical one, pad_w the horizontal one (1x7 / 7x1 / 1x3 / 3x1 kernels); ldc = row pitch of `out` in
+     * elements (0 = Cout): a conv / activation may write its channels into a slice of a wider (concatenated) NHWC tensor.
+     * SAT_OP_BN_RELU honours ldc the same way for its output. */
+    int32_t pad_w;
+    int32_t reserved0;
+    int64_t ldc;
 } sat_op;
+#define SAT_CONV_PADW 2
 
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
 /* same, with the step parity (0/1) that selects the half of every stat_acc buffer in use */

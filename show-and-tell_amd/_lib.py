@@ -15,6 +15,8 @@ OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_M
 
 OP_BN_EVAL_BATCH = 8
 OP_MAXPOOL2 = 9
+OP_MAXPOOL3S2, OP_AVGPOOL3 = 10, 11
+CONV_PADW = 2
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -43,6 +45,7 @@ class SatOp(C.Structure):
         ("stat_acc", _vp), ("stat_acc1", _vp), ("gamma1", _vp), ("beta1", _vp),
         ("running_mean1", _vp), ("running_var1", _vp), ("out1", _vp),
         ("stat_shards", C.c_int32), ("stat_shards1", C.c_int32),
+        ("pad_w", C.c_int32), ("reserved0", C.c_int32), ("ldc", C.c_int64),
     ]
 
 

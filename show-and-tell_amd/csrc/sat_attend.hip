@@ -188,6 +188,55 @@ __global__ void maxpool2_kernel(const T* __restrict__ in, T* __restrict__ out, i
     }
 }
 
+// 3x3 pools of the Inception blocks (BASELINE configs[3]), NHWC, 16 B per lane.  MAX: stride 2, no padding, output row pitch
+// ldo (the pooled branch is a slice of the block's concatenated output).  AVG: stride 1, pad 1, count_include_pad (/9).
+template <typename T, bool AVG>
+__global__ void pool3_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int Hin, int Win, int C, int Ho, int Wo, long ldo) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int cch = C / V;
+    const long total = (long)N * Ho * Wo * cch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cch);
+        long r = i / cch;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = AVG ? 0.0f : -INFINITY;
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hi = AVG ? ho - 1 + dh : ho * 2 + dh;
+            if ((unsigned)hi >= (unsigned)Hin) continue;
+            for (int dw = 0; dw < 3; ++dw) {
+                const int wi = AVG ? wo - 1 + dw : wo * 2 + dw;
+                if ((unsigned)wi >= (unsigned)Win) continue;
+                const T* q = in + (((long)n * Hin + hi) * Win + wi) * C + cc * V;
+                if constexpr (sizeof(T) == 4) {
+                    const f32x4 x = *(const f32x4*)q;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] = AVG ? acc[k] + x[k] : fmaxf(acc[k], x[k]);
+                } else {
+                    const bf16x8 x = *(const bf16x8*)q;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = AVG ? acc[k] + (float)x[k] : fmaxf(acc[k], (float)x[k]);
+                }
+            }
+        }
+        T* o = out + (((long)n * Ho + ho) * Wo + wo) * ldo + cc * V;
+        if constexpr (sizeof(T) == 4) {
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = AVG ? acc[k] * (1.0f / 9.0f) : acc[k];
+            *(f32x4*)o = y;
+        } else {
+            bf16x8 y;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = (bf16_t)(AVG ? acc[k] * (1.0f / 9.0f) : acc[k]);
+            *(bf16x8*)o = y;
+        }
+    }
+}
+
 // out[r*ldo + c] = in[idx(r)*ldi + c]: row gather / strided row copy (idx NULL: identity)
 __global__ __launch_bounds__(256) void rows_copy_kernel(const float* __restrict__ in, long ldi, const int64_t* __restrict__ idx,
                                                         long idx_stride, long nrows_in, int cols, float* __restrict__ out, long ldo) {
@@ -422,6 +471,28 @@ extern "C" int sat_lstmcell_bwd_point(const float* dh_out, const float* dh_carry
     if (!dh_out || !gates || !c || !dc_state || !DG || n < 1 || H < 1 || (n_carry > 0 && !dh_carry)) return SAT_ERR_ARG;
     return sat_lstm_bwd_point_launch(dh_out, dh_carry, n_carry > 0 ? 1 : 0, 0, n_carry, gates, c, c_prev, dc_state, DG, n, H,
                                      (hipStream_t)stream);
+}
+
+int sat_pool3_launch(const sat_op* op, bool avg, hipStream_t s) {
+    if (!op->in0 || !op->out || op->in0 == op->out) return SAT_ERR_ARG;
+    const int C = op->Cout;
+    const int V = op->dtype == SAT_BF16 ? 8 : 4;
+    const long ldo = op->ldc ? op->ldc : C;
+    if ((C % V) || (ldo % V) || ldo < C) return SAT_ERR_ARG;
+    const int Ho = avg ? op->Hin : (op->Hin - 3) / 2 + 1, Wo = avg ? op->Win : (op->Win - 3) / 2 + 1;
+    if (Ho < 1 || Wo < 1 || (op->Hout && (op->Hout != Ho || op->Wout != Wo))) return SAT_ERR_ARG;
+    const long total = (long)op->N * Ho * Wo * (C / V);
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipStream_t st = s;
+    if (op->dtype == SAT_BF16) {
+        if (avg) hipLaunchKernelGGL((pool3_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)op->in0, (bf16_t*)op->out, op->N, op->Hin, op->Win, C, Ho, Wo, ldo);
+        else hipLaunchKernelGGL((pool3_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)op->in0, (bf16_t*)op->out, op->N, op->Hin, op->Win, C, Ho, Wo, ldo);
+    } else {
+        if (avg) hipLaunchKernelGGL((pool3_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)op->in0, (float*)op->out, op->N, op->Hin, op->Win, C, Ho, Wo, ldo);
+        else hipLaunchKernelGGL((pool3_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)op->in0, (float*)op->out, op->N, op->Hin, op->Win, C, Ho, Wo, ldo);
+    }
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
 }
 
 int sat_maxpool2_launch(const sat_op* op, hipStream_t s) {

@@ -36,7 +36,7 @@ struct ConvArgs {
     float* stat_partial;
     int M, N, K;
     long ldb, ldc;
-    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
+    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad, padw;
     long sN, sH, sW;
     int tiles_n;
     int linear;     // 1x1 / stride 1 / no padding on a dense NHWC tensor: output row m reads input pixel m
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             const int ho = rem / p.Wout;
             const int wo = rem - ho * p.Wout;
             a_hi0[i] = ho * p.stride - p.pad;
-            a_wi0[i] = wo * p.stride - p.pad;
+            a_wi0[i] = wo * p.stride - p.padw;
             a_ptr[i] = p.A + ((long)n * p.sN + (long)a_hi0[i] * p.sH + (long)a_wi0[i] * p.sW + a_c[i]);
             if constexpr (UNIFORM) {
                 for (int kh = 0; kh < p.KH; ++kh)
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                     const int rem = grow - n * hw;
                     const int ho = rem / p.Wout;
                     const int wo = rem - ho * p.Wout;
-                    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.padw;
                     for (int kh = 0; kh < p.KH; ++kh)
                         for (int kw = 0; kw < p.KW; ++kw) {
                             const bool in = ((unsigned)(hi0 + kh) < (unsigned)p.Hin) && ((unsigned)(wi0 + kw) < (unsigned)p.Win);
@@ -853,11 +853,12 @@ ConvArgs make_args(const sat_op* op) {
     }
     a.out_relu = op->flags & 1;
     a.M = op->N * op->Hout * op->Wout; a.N = op->Cout; a.K = op->KH * op->KW * op->Cin;
-    a.ldb = a.K; a.ldc = op->Cout;
+    a.ldb = a.K; a.ldc = (op->ldc >= op->Cout) ? op->ldc : op->Cout;
     a.Hin = op->Hin; a.Win = op->Win; a.Cin = op->Cin; a.Hout = op->Hout; a.Wout = op->Wout;
     a.KH = op->KH; a.KW = op->KW; a.stride = op->stride; a.pad = op->pad;
+    a.padw = (op->flags & SAT_CONV_PADW) ? op->pad_w : op->pad;
     a.sN = op->sN; a.sH = op->sH; a.sW = op->sW;
-    a.linear = (op->KH == 1 && op->KW == 1 && op->stride == 1 && op->pad == 0 && op->Hout == op->Hin &&
+    a.linear = (op->KH == 1 && op->KW == 1 && op->stride == 1 && op->pad == 0 && a.padw == 0 && op->Hout == op->Hin &&
                 op->Wout == op->Win && op->sH == (long)op->Win * op->sW && op->sN == (long)op->Hin * op->sH) ? 1 : 0;
     static const int dbg = tune_env("SAT_CONV_DBG", 0);
     a.dbg = dbg;

@@ -344,6 +344,34 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
     }
 }
 
+// out[pixel * ldo + c] = relu(in[pixel * C + c] * s[c] + t[c]): the activation of a conv lands in a channel slice of a wider
+// (concatenated) NHWC tensor -- Inception blocks (BASELINE configs[3]).  One thread per 16-byte chunk.
+template <typename T>
+__global__ void bn_relu_strided_kernel(const T* __restrict__ in, T* __restrict__ out, long ldo, const BnSrc b, double count,
+                                       float momentum, float eps, long npix, int C) {
+    constexpr int V = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    const float* s = b.scale;
+    const float* t = b.shift;
+    if (b.acc) {
+        bn_table_from_acc(b, C, count, momentum, eps, tab, tab + C);
+        __syncthreads();
+        s = tab;
+        t = tab + C;
+    }
+    const int cch = C / V;
+    const long total = npix * cch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cch;
+        const int c0 = (int)(i - pix * cch) * V;
+        float x[V], y[V];
+        load_chunk<T>(in + pix * C + c0, x);
+#pragma unroll
+        for (int k = 0; k < V; ++k) y[k] = fmaxf(x[k] * s[c0 + k] + t[c0 + k], 0.0f);
+        store_chunk<T>(out + pix * ldo + c0, y);
+    }
+}
+
 // out[n][ho][wo][c] = max_{3x3, stride 2, pad 1} relu(in*s + t)
 template <typename T>
 __global__ void bn_relu_maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, const BnSrc b, double count,
@@ -958,8 +986,38 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
     return SAT_OK;
 }
 
+template <typename T>
+static int bn_relu_strided_launch_t(const sat_op* op, int parity, hipStream_t s) {
+    constexpr int V = Vec<T>::N;
+    const int C = op->Cout;
+    if ((C % V) || (op->ldc % V) || op->ldc < C) return SAT_ERR_ARG;
+    BnSrc b = {};
+    b.scale = op->scale0; b.shift = op->shift0;
+    size_t lds = 0;
+    if (op->stat_acc) {
+        if (!op->gamma || !op->beta || op->count < 1) return SAT_ERR_ARG;
+        long long* base = (long long*)op->stat_acc;
+        b.shards = op->stat_shards > 1 ? op->stat_shards : 1;
+        b.acc = base + (long)parity * b.shards * 2 * C;
+        b.acc_clear = base + (long)(1 - parity) * b.shards * 2 * C;
+        b.gamma = op->gamma; b.beta = op->beta; b.running_mean = op->running_mean; b.running_var = op->running_var;
+        lds = (size_t)2 * C * sizeof(float);
+    } else if (!op->scale0 || !op->shift0) {
+        return SAT_ERR_ARG;
+    }
+    const long npix = (long)op->N * op->Hout * op->Wout;
+    int grid = ew_grid(npix * (C / V));
+    if (lds && grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(bn_relu_strided_kernel<T>, dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (T*)op->out, (long)op->ldc, b,
+                       (double)op->count, op->momentum, op->eps, npix, C);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
 int sat_bn_act_launch(const sat_op* op, bool add, int parity, hipStream_t s) {
     if (!op->in0 || !op->out || (add && !op->in1)) return SAT_ERR_ARG;
+    if (!add && op->ldc && op->ldc != op->Cout)        // activation written into a channel slice of a wider tensor
+        return op->dtype == SAT_BF16 ? bn_relu_strided_launch_t<bf16_t>(op, parity, s) : bn_relu_strided_launch_t<float>(op, parity, s);
     return op->dtype == SAT_BF16 ? bn_act_launch_t<bf16_t>(op, add, parity, s) : bn_act_launch_t<float>(op, add, parity, s);
 }
 

@@ -31,7 +31,7 @@ struct GemmArgs {
     float* stat_partial;
     int M, N, K;
     long lda, ldb, ldc;
-    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
+    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad, padw;
     long sN, sH, sW;
     int tiles_n;
     int ksplit;          // gridDim.y: K-steps are dealt to ksplit slices, slice z writes C + z*slab_stride
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                     const int ho = rem / p.Wout;
                     const int wo = rem - ho * p.Wout;
                     a_hi0[i] = ho * p.stride - p.pad;
-                    a_wi0[i] = wo * p.stride - p.pad;
+                    a_wi0[i] = wo * p.stride - p.padw;
                     a_base[i] = (long)n * p.sN + (long)a_hi0[i] * p.sH + (long)a_wi0[i] * p.sW;
                 } else {
                     a_hi0[i] = -(1 << 28); a_wi0[i] = -(1 << 28); a_base[i] = 0;
@@ -639,7 +639,7 @@ int sat_conv_launch(const sat_op* op, int parity, hipStream_t s) {
     if (!aligned16(op->in0) || !aligned16(op->w)) return SAT_ERR_ARG;
     // every 16-byte chunk address n*sN + hi*sH + wi*sW + c must be 16-byte aligned
     if ((op->sN % ch) || (op->sH % ch)) return SAT_ERR_ARG;
-    if ((op->KW > 1 || op->pad) ? (op->sW % ch) != 0 : ((long)op->stride * op->sW) % ch != 0) return SAT_ERR_ARG;
+    if ((op->KW > 1 || op->pad || (op->flags & SAT_CONV_PADW)) ? (op->sW % ch) != 0 : ((long)op->stride * op->sW) % ch != 0) return SAT_ERR_ARG;
     GemmArgs a = {};
     a.A = op->in0; a.B = op->w; a.C = op->out; a.bias = nullptr; a.bias2 = nullptr;
     a.stat_partial = op->stat_partial;
@@ -647,6 +647,8 @@ int sat_conv_launch(const sat_op* op, int parity, hipStream_t s) {
     a.lda = 0; a.ldb = a.K; a.ldc = op->Cout;
     a.Hin = op->Hin; a.Win = op->Win; a.Cin = op->Cin; a.Hout = op->Hout; a.Wout = op->Wout;
     a.KH = op->KH; a.KW = op->KW; a.stride = op->stride; a.pad = op->pad;
+    a.padw = (op->flags & SAT_CONV_PADW) ? op->pad_w : op->pad;
+    if (op->ldc) { if (op->ldc < op->Cout) return SAT_ERR_ARG; a.ldc = op->ldc; }
     a.sN = op->sN; a.sH = op->sH; a.sW = op->sW;
     if (op->stat_partial && op->tiles_m != sat_cdiv(a.M, 128)) return SAT_ERR_ARG;
     if (op->dtype == SAT_BF16 && (op->Cout % 8) == 0 && !conv_legacy()) return sat_conv_glds_launch(op, parity, s);

@@ -38,6 +38,8 @@ extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_
             case SAT_OP_AVGPOOL: rc = sat_avgpool_launch(op, s); break;
             case SAT_OP_BN_EVAL_BATCH: rc = sat_bn_eval_batch_launch(op, s); break;
             case SAT_OP_MAXPOOL2: rc = sat_maxpool2_launch(op, s); break;
+            case SAT_OP_MAXPOOL3S2: rc = sat_pool3_launch(op, false, s); break;
+            case SAT_OP_AVGPOOL3: rc = sat_pool3_launch(op, true, s); break;
             default: rc = SAT_ERR_UNSUPPORTED;
         }
         if (rc != SAT_OK) return rc;

@@ -11,6 +11,7 @@ int sat_bn_act_launch(const sat_op* op, bool add, int parity, hipStream_t s);
 int sat_bn_relu_maxpool_launch(const sat_op* op, int parity, hipStream_t s);
 int sat_avgpool_launch(const sat_op* op, hipStream_t s);
 int sat_maxpool2_launch(const sat_op* op, hipStream_t s);
+int sat_pool3_launch(const sat_op* op, bool avg, hipStream_t s);
 
 int sat_skinny_store(const float* A, long lda, const float* W, long ldw, int wkm, int M, int N, int K, int nz,
                      float* out, long ldo, long slab_stride, const float* bias, hipStream_t s);

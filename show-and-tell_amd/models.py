@@ -95,7 +95,11 @@ class EncoderCNN(nn.Module):
 
     def __init__(self, embed_size, arch=RESNET152, compute_dtype="bf16"):
         super().__init__()
-        self.resnet = ResNetStack(embed_size, arch)         # frozen stack + trainable fc (models.py:13-16)
+        if arch == "inception_v3":                          # BASELINE configs[3]; the attribute keeps the reference's name
+            from .inception import InceptionStack
+            self.resnet = InceptionStack(embed_size)
+        else:
+            self.resnet = ResNetStack(embed_size, arch)     # frozen stack + trainable fc (models.py:13-16)
         self.bn = _BN1d(embed_size)                         # models.py:17
         self.compute_dtype = compute_dtype
         self._programs = {}
@@ -121,7 +125,9 @@ class EncoderCNN(nn.Module):
         if prog is None:
             if len(self._programs) >= 4:
                 self._programs.clear()
-            prog = self._programs[key] = ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device)
+            make = getattr(self.resnet, "program", None)
+            prog = self._programs[key] = (make(N, H, W, dt, self.training, images.device) if make is not None else
+                                          ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device))
         return prog
 
     def refresh_weights(self):
