@@ -92,7 +92,7 @@ def test_pool3_ops_and_strided_bn_relu(dtype):
     assert (ao.float().cpu() - F.avg_pool2d(xf, 3, 1, 1).permute(0, 2, 3, 1)).abs().max().item() < tol
     ref = torch.clamp(x.float() * sc + sh, min=0)
     assert (bo[..., off:off + Cc].float().cpu() - ref).abs().max().item() < (1e-5 if dtype == L.SAT_F32 else 4e-2)
-    assert float((bo[..., off + Cc:].float() - 3).abs().max()) == 0
+    assert float((bo[..., :off].float() - 3).abs().max()) == 0
 
 
 def _encoder(dtype, seed=3, E=64):
@@ -174,7 +174,7 @@ def test_cfg4_train_step_inception_encoder_two_layer_lstm_vs_oracle():
         losses[dtype] = loss.item()
         if dtype == "f32":
             assert abs(loss.item() - ref_loss.item()) < 1e-4
-            np.testing.assert_allclose(ts.flat.grad("decoder.lstm.weight_hh_l1").cpu().numpy(), ref_grads["lstm.weight_hh_l1"].numpy(), rtol=5e-3, atol=1e-8)
+            np.testing.assert_allclose(ts.flat.grad("decoder.lstm.weight_hh_l1").cpu().numpy(), ref_grads["lstm.weight_hh_l1"].numpy(), rtol=5e-3, atol=2e-7)
             np.testing.assert_allclose(ts.flat.grad("encoder.bn.weight").cpu().numpy(), hg["bn.weight"].numpy(), rtol=5e-2, atol=1e-6)
         ts.optimizer_step()
         ts.check_ids()
