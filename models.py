@@ -10,3 +10,4 @@ if _root not in _sys.path:
 _m = _il.import_module("show-and-tell_amd.models")
 EncoderCNN, DecoderRNN, ShowAndTell = _m.EncoderCNN, _m.DecoderRNN, _m.ShowAndTell
 Encoder, Decoder, CaptionModel = _m.Encoder, _m.Decoder, _m.CaptionModel
+ShowAttendTellModel = _il.import_module("show-and-tell_amd.attend").ShowAttendTellModel      # model2.py:9 (what train.py:37 builds)
