@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 7
+#define SAT_ABI_VERSION 8
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -266,6 +266,12 @@ int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t lda, const
                         float* C, int64_t ldc, const float* bias, const float* bias2, int M, int N, int K,
                         int ksplit, int64_t slab_stride, sat_stream_t stream);
 int sat_sum_slabs_f32(const float* in, int nslab, int64_t slab_stride, int64_t n, float* out, sat_stream_t stream);
+/* out[M,N] = A[M,K] * op(W) + bias for FEW rows (a decode / recurrence step: M <= a few hundred): K is split over the waves of
+ * a workgroup and over grid slices so that 64 rows still fill the chip (the per-step GEMMs of model2.py:54-62 and their
+ * backward).  w_kmajor 0: W[n*ldw + k]; 1: W[k*ldw + n].  K % 4 == 0, lda % 4 == 0.  Exact f32 (v_mfma_f32_16x16x4_f32). */
+int sat_skinny_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, int w_kmajor, int M, int N, int K,
+                        const float* bias, float* out, int64_t ldo, float* workspace, int64_t ws_bytes, sat_stream_t stream);
+int64_t sat_skinny_gemm_ws_bytes(int M, int N, int K);
 /* greedy argmax of one decode step (models.py:61-63): ids[b*ids_stride] = first argmax_v (h[b] . w[v] + b[v]) */
 int sat_vocab_argmax(const float* h /*[B,H]*/, const float* w, const float* b, int B, int H, int V,
                      int64_t* ids, int64_t ids_stride, float* workspace, int64_t ws_bytes, sat_stream_t stream);
@@ -286,16 +292,20 @@ int sat_embed_rows(const float* embed, const int64_t* ids, int64_t ids_stride, i
  * sat_attention_bwd: its backward given d_context (h_att recomputed): d_ctx_enc[rows][P][C] += ..., d_proj [rows][C],
  *   d_watt_part [rows][C] (sum over rows = d weight_att; kept per row for a fixed-order reduction); d_feats (fine-tuning only):
  *   the gradient the weighted mean sends back into the features, accumulated.
+ *   Both run as two launches (a per-position row-dot over (rows x position chunks) workgroups, then a per-channel pass over
+ *   (rows x C/64) workgroups) so that a 64-row step fills the chip; the workspace carries the P-long vector between them.
  * sat_lstmcell_fwd: one nn.LSTMCell step (model2.py:58), c in place, optional tapes (activated gates, new c).
  * sat_rows_copy: out[r] = in[idx ? idx[r*idx_stride] : r] (embedding rows into a strided destination, state slices).
  * sat_rows_sum: out[c] (+)= sum_r in[r][c] in fixed order.
  */
 int sat_attention_fwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
-                      int rows, int P, int C, float* alpha, float* context, int64_t ld_ctx, sat_stream_t stream);
+                      int rows, int P, int C, float* alpha, float* context, int64_t ld_ctx, float* workspace, int64_t ws_bytes,
+                      sat_stream_t stream);
+int64_t sat_attention_ws_bytes(int rows, int P);     /* raw scores (forward) / d_alpha (backward) between the two launches */
 int sat_attention_bwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
                       const float* alpha, const float* d_ctx, int64_t ld_dctx, int rows, int P, int C,
                       float* d_ctx_enc, float* d_proj, float* d_watt_part, float* d_feats /*[rows][P][C] += , or NULL*/,
-                      sat_stream_t stream);
+                      float* workspace, int64_t ws_bytes, sat_stream_t stream);
 int sat_lstmcell_fwd(const float* x /*[B,In]*/, const float* h_in /*[B,H]*/, float* c /*[B,H] in place*/, const float* w_ih,
                      const float* w_hh, const float* b_ih, const float* b_hh, int B, int In, int H, float* h_out,
                      float* gates /*[B,4H] or NULL*/, float* c_tape /*[B,H] or NULL*/, sat_stream_t stream);

@@ -268,10 +268,28 @@ class _Cell(nn.Module):
         self.bias_hh = nn.Parameter(torch.empty(4 * h).uniform_(-k, k))
 
 
+_SKINNY_WS = {}
+_SKINNY_ROWS = int(os.environ.get("SAT_SKINNY_ROWS", "128"))   # per-step GEMMs with at most this many rows take the split-K kernel
+
+
+def _ptr(x):
+    return x if isinstance(x, int) or x is None else x.data_ptr()
+
+
 def _gemm(lib, amode, bmode, A, lda, B, ldb, Cout, ldc, M, N, K, bias=None, bias2=None):
-    L.check(lib.sat_gemm_f32(amode, bmode, L.ptr(A) if torch.is_tensor(A) else A, lda, L.ptr(B) if torch.is_tensor(B) else B, ldb,
-                             L.ptr(Cout) if torch.is_tensor(Cout) else Cout, ldc, L.ptr(bias), L.ptr(bias2), M, N, K, L.stream()),
-            "sat_gemm_f32")
+    """C[M,N] = op(A) op(B) + bias (+ bias2).  A 64 x 64-tiled GEMM of a 64-row decode step runs on N/64 workgroups; those go to
+    sat_skinny_gemm_f32, which splits K over waves and grid slices instead."""
+    if amode == 0 and M <= _SKINNY_ROWS and bias2 is None and ldc == N and K % 4 == 0 and lda % 4 == 0 and (bmode == 1 or ldb % 4 == 0):
+        need = lib.sat_skinny_gemm_ws_bytes(M, N, K)
+        dev = torch.cuda.current_device()
+        ws = _SKINNY_WS.get(dev)
+        if ws is None or ws.numel() * 4 < need:
+            ws = _SKINNY_WS[dev] = torch.empty(max(need // 4, 1 << 20), dtype=torch.float32, device="cuda")
+        L.check(lib.sat_skinny_gemm_f32(_ptr(A), lda, _ptr(B), ldb, bmode, M, N, K, L.ptr(bias), _ptr(Cout), ldc,
+                                        ws.data_ptr(), ws.numel() * 4, L.stream()), "sat_skinny_gemm_f32")
+        return
+    L.check(lib.sat_gemm_f32(amode, bmode, _ptr(A), lda, _ptr(B), ldb, _ptr(Cout), ldc, L.ptr(bias), L.ptr(bias2), M, N, K,
+                             L.stream()), "sat_gemm_f32")
 
 
 def _p(t, row0=0):
@@ -303,12 +321,13 @@ class _AttendFn(torch.autograd.Function):
         CS, ALPHA = torch.empty(N, H, device=dev), torch.empty(N, P, device=dev)
         proj = torch.empty(B, C, device=dev)
         watt = m.weight_att.view(-1)
+        att_ws = torch.empty(B * P, device=dev)
         for t, bs in enumerate(pi.batch_sizes):                                                  # model2.py:54-62
             r0 = pi.prefix[t]
             hprev = h0.data_ptr() if t == 0 else _p(HS, pi.prefix[t - 1])
             _gemm(lib, 0, 0, hprev, H, m.weight_hh.weight, H, proj, C, bs, C, H, m.weight_hh.bias)
             L.check(lib.sat_attention_fwd(L.ptr(ctx_enc), L.ptr(f2), L.ptr(proj), C, L.ptr(watt), bs, P, C, _p(ALPHA, r0),
-                                          _p(CTX, r0), C, st), "sat_attention_fwd")
+                                          _p(CTX, r0), C, att_ws.data_ptr(), att_ws.numel() * 4, st), "sat_attention_fwd")
             L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, captions.data_ptr() + t * 8, captions.stride(0), V, bs, E,
                                       _p(X, r0), Hin, st), "sat_rows_copy")
             L.check(lib.sat_rows_copy(_p(CTX, r0), C, None, 0, bs, bs, C, _p(X, r0) + E * 4, Hin, st), "sat_rows_copy")
@@ -489,10 +508,11 @@ class ShowAttendTellModel(nn.Module):
         wsb = lib.sat_vocab_argmax_ws_bytes(B, V)
         ws = torch.empty(wsb // 4, device=dev)
         watt = m.weight_att.view(-1)
+        att_ws = torch.empty(B * P, device=dev)
         for i in range(steps):
             _gemm(lib, 0, 0, h, H, m.weight_hh.weight, H, proj, C, B, C, H, m.weight_hh.bias)
-            L.check(lib.sat_attention_fwd(L.ptr(ctx_enc), L.ptr(f2), L.ptr(proj), C, L.ptr(watt), B, P, C, None, L.ptr(ctxb), C, st),
-                    "sat_attention_fwd")
+            L.check(lib.sat_attention_fwd(L.ptr(ctx_enc), L.ptr(f2), L.ptr(proj), C, L.ptr(watt), B, P, C, None, L.ptr(ctxb), C,
+                                          att_ws.data_ptr(), att_ws.numel() * 4, st), "sat_attention_fwd")
             if i == 0:                                                               # model2.py:101-102
                 L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, start.data_ptr(), 1, V, B, E, L.ptr(X), Hin, st), "sat_rows_copy")
                 L.check(lib.sat_rows_copy(L.ptr(ctxb), C, None, 0, B, B, C, X.data_ptr() + E * 4, Hin, st), "sat_rows_copy")

@@ -4,13 +4,7 @@ per packed step for the recurrence (BPTT).  The conv stack is frozen (model2.py:
 import torch
 
 from . import _lib as L
-
-
-def _gemm(lib, amode, bmode, A, lda, B, ldb, Cout, ldc, M, N, K, bias=None):
-    pa = A if isinstance(A, int) else A.data_ptr()
-    pb = B if isinstance(B, int) else B.data_ptr()
-    pc = Cout if isinstance(Cout, int) else Cout.data_ptr()
-    L.check(lib.sat_gemm_f32(amode, bmode, pa, lda, pb, ldb, pc, ldc, L.ptr(bias), None, M, N, K, L.stream()), "sat_gemm_f32")
+from .attend import _gemm
 
 
 def _rows(t, r0):
@@ -64,6 +58,7 @@ def attend_backward(m, pi, captions, tp, dlogits, want_dfeat=False):
     d_ctx_enc = torch.zeros_like(ctx_enc)
     d_feats = torch.zeros_like(ctx_enc) if want_dfeat else None      # [B*P, C]: what the weighted means send back (per step)
     dwatt_part = torch.empty(B, C, device=dev)
+    att_ws = torch.empty(B * P, device=dev)
     g["weight_att"] = torch.zeros(C, device=dev)
     proj = torch.empty(B, C, device=dev)
     watt = m.weight_att.view(-1)
@@ -80,7 +75,7 @@ def attend_backward(m, pi, captions, tp, dlogits, want_dfeat=False):
         _gemm(lib, 0, 0, hprev, H, m.weight_hh.weight, H, proj, C, bs, C, H, m.weight_hh.bias)           # recompute the projection
         L.check(lib.sat_attention_bwd(ctx_enc.data_ptr(), f2.data_ptr(), proj.data_ptr(), C, watt.data_ptr(), _rows(ALPHA, r0),
                                       dctx.data_ptr(), C, bs, P, C, d_ctx_enc.data_ptr(), _rows(DPROJ, r0), dwatt_part.data_ptr(),
-                                      d_feats.data_ptr() if d_feats is not None else None, st),
+                                      d_feats.data_ptr() if d_feats is not None else None, att_ws.data_ptr(), att_ws.numel() * 4, st),
                 "sat_attention_bwd")
         L.check(lib.sat_rows_sum(dwatt_part.data_ptr(), C, bs, C, g["weight_att"].data_ptr(), 1, st), "sat_rows_sum")
         _gemm(lib, 0, 1, _rows(DG, r0), 4 * H, m.lstmcell.weight_hh, H, dh_a, H, bs, H, 4 * H)           # dh_{t-1} via the LSTM

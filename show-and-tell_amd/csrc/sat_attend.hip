@@ -27,123 +27,152 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
     return r;
 }
 
-// One workgroup per batch row b (model2.py:73-78):
+// Soft attention step (model2.py:73-78), spread over the chip in two launches per direction so that a 64-row decode step is
+// not a 64-workgroup launch:
 //   h_att[p,c] = tanh(ctx_enc[b,p,c] + proj[b,c]);  s[p] = sum_c h_att[p,c] * w_att[c];  alpha = softmax_p(s)
 //   context[b,c] = (1/P) * sum_p alpha[p] * feats[b,p,c]            (the reference takes the MEAN of the weighted features)
-// Scores: one wave per position (lanes stride the channels, 16 B per lane), fixed-order wave reduction.
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ ctx_enc, const float* __restrict__ feats,
-                                                            const float* __restrict__ proj, long ld_proj,
-                                                            const float* __restrict__ w_att, int P, int C,
-                                                            float* __restrict__ alpha, float* __restrict__ context, long ld_ctx) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // [C] proj | [C] w_att | [P] scores | [8] scratch
-    float* s_proj = sm;
-    float* s_w = sm + C;
-    float* s_sc = sm + 2 * C;
-    float* s_red = s_sc + ((P + 3) & ~3);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    for (int c = tid; c < C; c += blockDim.x) {
-        s_proj[c] = proj[(long)b * ld_proj + c];
-        s_w[c] = w_att[c];
+// (1) row-dot kernel, grid (rows, position chunks): one wave per position, lanes stride the channels (16 B per lane), fixed-order
+//     wave reduction -> raw scores (forward) or d_alpha (backward) in the workspace;
+// (2) channel kernel, grid (rows, 64-channel chunks): every workgroup redoes the P-long softmax (a few hundred expf) and owns 64
+//     channels; its 8 waves take positions p = w (mod 8), partials are combined through LDS in wave order (deterministic).
+constexpr int kAttWaves = 8;
+
+// TANH = true: v[p] = sum_c tanh(x[b,p,c] + add[b,c]) * mul[c]      (scores)
+// TANH = false: v[p] = scale * sum_c x[b,p,c] * mul_row[b,c]         (d_alpha = feats . d_ctx / P)
+template <bool TANH>
+__global__ __launch_bounds__(256) void att_rowdot_kernel(const float* __restrict__ x, const float* __restrict__ add, long ld_add,
+                                                         const float* __restrict__ mul, long ld_mul, float scale, int P, int C,
+                                                         int pchunk, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [C] add | [C] mul
+    float* s_add = sm;
+    float* s_mul = sm + C;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        if (TANH) s_add[c] = add[(long)b * ld_add + c];
+        s_mul[c] = mul[(long)b * ld_mul + c];
     }
     __syncthreads();
-    const float* ce = ctx_enc + (long)b * P * C;
-    for (int p = wave; p < P; p += nw) {
+    const int p0 = blockIdx.y * pchunk;
+    const int p1 = p0 + pchunk < P ? p0 + pchunk : P;
+    const float* xb = x + (long)b * P * C;
+    for (int p = p0 + wave; p < p1; p += 4) {
         float acc = 0.0f;
         for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 x = *(const f32x4*)(ce + (long)p * C + c);
+            const f32x4 v = *(const f32x4*)(xb + (long)p * C + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc += tanhf(x[e] + s_proj[c + e]) * s_w[c + e];
+            for (int e = 0; e < 4; ++e) acc += TANH ? tanhf(v[e] + s_add[c + e]) * s_mul[c + e] : v[e] * s_mul[c + e];
         }
         acc = wave_sum(acc);
-        if (lane == 0) s_sc[p] = acc;
-    }
-    __syncthreads();
-    float m = -INFINITY;
-    for (int p = tid; p < P; p += blockDim.x) m = fmaxf(m, s_sc[p]);
-    m = block_max(m, s_red);
-    float z = 0.0f;
-    for (int p = tid; p < P; p += blockDim.x) z += expf(s_sc[p] - m);
-    z = block_sum(z, s_red);
-    const float inv = 1.0f / z;
-    for (int p = tid; p < P; p += blockDim.x) {
-        const float a = expf(s_sc[p] - m) * inv;
-        s_sc[p] = a;
-        if (alpha) alpha[(long)b * P + p] = a;
-    }
-    __syncthreads();
-    const float* fb = feats + (long)b * P * C;
-    const float invP = 1.0f / (float)P;
-    for (int c = tid; c < C; c += blockDim.x) {
-        float acc = 0.0f;
-        for (int p = 0; p < P; ++p) acc += s_sc[p] * fb[(long)p * C + c];
-        context[(long)b * ld_ctx + c] = acc * invP;
+        if (lane == 0) out[(long)b * P + p] = acc * scale;
     }
 }
 
-// Backward of the step above for one batch row (h_att recomputed, never stored):
-//   d_alpha[p] = (1/P) feats[b,p,:] . d_ctx[b,:]
+__global__ __launch_bounds__(kAttWaves * 64) void att_context_kernel(const float* __restrict__ scores, const float* __restrict__ feats,
+                                                                     int P, int C, float* __restrict__ alpha,
+                                                                     float* __restrict__ context, long ld_ctx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [P4] alpha | [8] scratch | [kAttWaves][64] partials
+    const int P4 = (P + 3) & ~3;
+    float* s_a = sm;
+    float* s_red = sm + P4;
+    float* s_part = s_red + 8;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int p = tid; p < P; p += blockDim.x) s_a[p] = scores[(long)b * P + p];
+    __syncthreads();
+    float m = -INFINITY;
+    for (int p = tid; p < P; p += blockDim.x) m = fmaxf(m, s_a[p]);
+    m = block_max(m, s_red);
+    float z = 0.0f;
+    for (int p = tid; p < P; p += blockDim.x) z += expf(s_a[p] - m);
+    z = block_sum(z, s_red);
+    const float inv = 1.0f / z;
+    __syncthreads();
+    for (int p = tid; p < P; p += blockDim.x) {
+        const float a = expf(s_a[p] - m) * inv;
+        s_a[p] = a;
+        if (alpha && blockIdx.y == 0) alpha[(long)b * P + p] = a;
+    }
+    __syncthreads();
+    const int c = blockIdx.y * 64 + lane;
+    float acc = 0.0f;
+    if (c < C) {
+        const float* fb = feats + (long)b * P * C + c;
+#pragma unroll 4
+        for (int p = wave; p < P; p += kAttWaves) acc += s_a[p] * fb[(long)p * C];
+    }
+    s_part[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        float r = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kAttWaves; ++w) r += s_part[w * 64 + lane];
+        context[(long)b * ld_ctx + c] = r / (float)P;
+    }
+}
+
+// Backward of the step for one (row, 64-channel chunk) (h_att recomputed, never stored):
+//   d_alpha[p] = (1/P) feats[b,p,:] . d_ctx[b,:]                    (att_rowdot_kernel<false>, in `d_alpha`)
 //   d_s[p]     = alpha[p] * (d_alpha[p] - sum_q alpha[q] d_alpha[q])
 //   d_pre[p,c] = d_s[p] * w_att[c] * (1 - h_att[p,c]^2)        -> d_ctx_enc[b,p,c] += d_pre   (accumulated over steps)
 //   d_proj[b,c] = sum_p d_pre[p,c];   d_w_att partial[b,c] = sum_p d_s[p] * h_att[p,c]
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ ctx_enc, const float* __restrict__ feats,
-                                                            const float* __restrict__ proj, long ld_proj,
-                                                            const float* __restrict__ w_att, const float* __restrict__ alpha,
-                                                            const float* __restrict__ d_ctx, long ld_dctx, int P, int C,
-                                                            float* __restrict__ d_ctx_enc, float* __restrict__ d_proj,
-                                                            float* __restrict__ d_watt_part, float* __restrict__ d_feats) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // [C] proj | [C] w_att | [C] d_ctx | [P] d_s | [8]
-    float* s_proj = sm;
-    float* s_w = sm + C;
-    float* s_dc = sm + 2 * C;
-    float* s_ds = sm + 3 * C;
-    float* s_red = s_ds + ((P + 3) & ~3);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    for (int c = tid; c < C; c += blockDim.x) {
-        s_proj[c] = proj[(long)b * ld_proj + c];
-        s_w[c] = w_att[c];
-        s_dc[c] = d_ctx[(long)b * ld_dctx + c];
-    }
-    __syncthreads();
-    const float* fb = feats + (long)b * P * C;
-    const float invP = 1.0f / (float)P;
-    for (int p = wave; p < P; p += nw) {
-        float acc = 0.0f;
-        for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 x = *(const f32x4*)(fb + (long)p * C + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc += x[e] * s_dc[c + e];
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) s_ds[p] = acc * invP;                           // d_alpha for now
-    }
-    __syncthreads();
+__global__ __launch_bounds__(kAttWaves * 64) void att_bwd_channel_kernel(const float* __restrict__ ctx_enc,
+                                                                         const float* __restrict__ proj, long ld_proj,
+                                                                         const float* __restrict__ w_att,
+                                                                         const float* __restrict__ alpha,
+                                                                         const float* __restrict__ d_alpha,
+                                                                         const float* __restrict__ d_ctx, long ld_dctx, int P, int C,
+                                                                         float* __restrict__ d_ctx_enc, float* __restrict__ d_proj,
+                                                                         float* __restrict__ d_watt_part, float* __restrict__ d_feats) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [P4] d_s | [P4] alpha | [8] | [2][kAttWaves][64]
+    const int P4 = (P + 3) & ~3;
+    float* s_ds = sm;
+    float* s_al = sm + P4;
+    float* s_red = sm + 2 * P4;
+    float* s_part = s_red + 8;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float dot = 0.0f;
-    for (int p = tid; p < P; p += blockDim.x) dot += alpha[(long)b * P + p] * s_ds[p];
-    dot = block_sum(dot, s_red);
-    for (int p = tid; p < P; p += blockDim.x) s_ds[p] = alpha[(long)b * P + p] * (s_ds[p] - dot);
-    __syncthreads();
-    const float* ce = ctx_enc + (long)b * P * C;
-    float* dce = d_ctx_enc + (long)b * P * C;
-    if (d_feats) {      // fine-tuning: context = mean_p alpha[p] feats[p]  =>  d feats[p,c] += alpha[p] * d_ctx[c] / P
-        float* dfe = d_feats + (long)b * P * C;
-        for (int c = tid; c < C; c += blockDim.x) {
-            const float dc = s_dc[c] * invP;
-            for (int p = 0; p < P; ++p) dfe[(long)p * C + c] += alpha[(long)b * P + p] * dc;
-        }
+    for (int p = tid; p < P; p += blockDim.x) {
+        const float a = alpha[(long)b * P + p], da = d_alpha[(long)b * P + p];
+        s_al[p] = a;
+        s_ds[p] = da;
+        dot += a * da;
     }
-    for (int c = tid; c < C; c += blockDim.x) {                          // a thread owns a channel: fixed order over p
-        const float pj = s_proj[c], w = s_w[c];
-        float dp = 0.0f, dw = 0.0f;
-        for (int p = 0; p < P; ++p) {
-            const float ha = tanhf(ce[(long)p * C + c] + pj);
+    dot = block_sum(dot, s_red);
+    for (int p = tid; p < P; p += blockDim.x) s_ds[p] = s_al[p] * (s_ds[p] - dot);
+    __syncthreads();
+    const int c = blockIdx.y * 64 + lane;
+    float dp = 0.0f, dw = 0.0f;
+    if (c < C) {
+        const float pj = proj[(long)b * ld_proj + c], w = w_att[c];
+        const float* ce = ctx_enc + (long)b * P * C + c;
+        float* dce = d_ctx_enc + (long)b * P * C + c;
+#pragma unroll 4
+        for (int p = wave; p < P; p += kAttWaves) {
+            const float ha = tanhf(ce[(long)p * C] + pj);
             const float ds = s_ds[p];
             const float dpre = ds * w * (1.0f - ha * ha);
-            dce[(long)p * C + c] += dpre;
+            dce[(long)p * C] += dpre;
             dp += dpre;
             dw += ds * ha;
         }
-        d_proj[(long)b * C + c] = dp;
-        d_watt_part[(long)b * C + c] = dw;
+        if (d_feats) {      // fine-tuning: context = mean_p alpha[p] feats[p]  =>  d feats[p,c] += alpha[p] * d_ctx[c] / P
+            const float dc = d_ctx[(long)b * ld_dctx + c] / (float)P;
+            float* dfe = d_feats + (long)b * P * C + c;
+#pragma unroll 4
+            for (int p = wave; p < P; p += kAttWaves) dfe[(long)p * C] += s_al[p] * dc;
+        }
+    }
+    s_part[wave * 64 + lane] = dp;
+    s_part[(kAttWaves + wave) * 64 + lane] = dw;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        float rp = 0.0f, rw = 0.0f;
+#pragma unroll
+        for (int w2 = 0; w2 < kAttWaves; ++w2) {
+            rp += s_part[w2 * 64 + lane];
+            rw += s_part[(kAttWaves + w2) * 64 + lane];
+        }
+        d_proj[(long)b * C + c] = rp;
+        d_watt_part[(long)b * C + c] = rw;
     }
 }
 
@@ -510,28 +539,54 @@ int sat_maxpool2_launch(const sat_op* op, hipStream_t s) {
     return SAT_OK;
 }
 
+static int att_pchunk(int rows, int P) {
+    int nch = 512 / rows;                                    // aim at >= 512 workgroups
+    if (nch < 1) nch = 1;
+    const int maxch = sat_cdiv(P, 4);                         // at least one position per wave
+    if (nch > maxch) nch = maxch;
+    return sat_cdiv(P, nch);
+}
+
+extern "C" int64_t sat_attention_ws_bytes(int rows, int P) { return (int64_t)rows * P * (int64_t)sizeof(float); }
+
 extern "C" int sat_attention_fwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
-                                 int rows, int P, int C, float* alpha, float* context, int64_t ld_ctx, sat_stream_t stream) {
+                                 int rows, int P, int C, float* alpha, float* context, int64_t ld_ctx, float* workspace,
+                                 int64_t ws_bytes, sat_stream_t stream) {
     if (!ctx_enc || !feats || !proj || !w_att || !context || rows < 1 || P < 1 || C < 4 || (C & 3) || ld_proj < C || ld_ctx < C)
         return SAT_ERR_ARG;
-    const size_t lds = (size_t)(2 * C + ((P + 3) & ~3) + 8) * sizeof(float);
-    if (lds > 60 * 1024) return SAT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, ctx_enc, feats, proj, (long)ld_proj,
-                       w_att, P, C, alpha, context, (long)ld_ctx);
+    if (!workspace || ws_bytes < sat_attention_ws_bytes(rows, P)) return SAT_ERR_WORKSPACE;
+    const size_t lds1 = (size_t)2 * C * sizeof(float);
+    const size_t lds2 = (size_t)(((P + 3) & ~3) + 8 + kAttWaves * 64) * sizeof(float);
+    if (lds1 > 60 * 1024 || lds2 > 60 * 1024) return SAT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int pch = att_pchunk(rows, P);
+    hipLaunchKernelGGL(att_rowdot_kernel<true>, dim3(rows, sat_cdiv(P, pch)), dim3(256), lds1, s, ctx_enc, proj, (long)ld_proj, w_att,
+                       0L, 1.0f, P, C, pch, workspace);
+    SAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(att_context_kernel, dim3(rows, sat_cdiv(C, 64)), dim3(kAttWaves * 64), lds2, s, workspace, feats, P, C, alpha,
+                       context, (long)ld_ctx);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
 
 extern "C" int sat_attention_bwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
                                  const float* alpha, const float* d_ctx, int64_t ld_dctx, int rows, int P, int C,
-                                 float* d_ctx_enc, float* d_proj, float* d_watt_part, float* d_feats, sat_stream_t stream) {
+                                 float* d_ctx_enc, float* d_proj, float* d_watt_part, float* d_feats, float* workspace,
+                                 int64_t ws_bytes, sat_stream_t stream) {
     if (!ctx_enc || !feats || !proj || !w_att || !alpha || !d_ctx || !d_ctx_enc || !d_proj || !d_watt_part || rows < 1 || P < 1 ||
         C < 4 || (C & 3) || ld_proj < C || ld_dctx < C)
         return SAT_ERR_ARG;
-    const size_t lds = (size_t)(3 * C + ((P + 3) & ~3) + 8) * sizeof(float);
-    if (lds > 60 * 1024) return SAT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, ctx_enc, feats, proj, (long)ld_proj,
-                       w_att, alpha, d_ctx, (long)ld_dctx, P, C, d_ctx_enc, d_proj, d_watt_part, d_feats);
+    if (!workspace || ws_bytes < sat_attention_ws_bytes(rows, P)) return SAT_ERR_WORKSPACE;
+    const size_t lds1 = (size_t)2 * C * sizeof(float);
+    const size_t lds2 = (size_t)(2 * ((P + 3) & ~3) + 8 + 2 * kAttWaves * 64) * sizeof(float);
+    if (lds1 > 60 * 1024 || lds2 > 60 * 1024) return SAT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int pch = att_pchunk(rows, P);
+    hipLaunchKernelGGL(att_rowdot_kernel<false>, dim3(rows, sat_cdiv(P, pch)), dim3(256), lds1, s, feats, (const float*)nullptr, 0L,
+                       d_ctx, (long)ld_dctx, 1.0f / (float)P, P, C, pch, workspace);
+    SAT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(att_bwd_channel_kernel, dim3(rows, sat_cdiv(C, 64)), dim3(kAttWaves * 64), lds2, s, ctx_enc, proj, (long)ld_proj,
+                       w_att, alpha, workspace, d_ctx, (long)ld_dctx, P, C, d_ctx_enc, d_proj, d_watt_part, d_feats);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }

@@ -8,8 +8,7 @@
 // K permutation on both operands).  One workgroup = 16 output columns x 64 rows; its 4 waves split K and
 // reduce through LDS.  The LSTM epilogue applies the i,f,g,o gate math on the reduced tile, so h_t and
 // c_t never leave the kernel un-activated: the "16 columns" of a workgroup are the 4 gates of 4 hidden units.
-#include "sat_common.h"
-#include "../../include/sat_hip.h"
+#include "sat_internal.h"
 
 namespace {
 
@@ -369,4 +368,40 @@ int sat_lstm_bwd_step(const float* dHS, const float* DG_next, int n_next, const 
     hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(NWV * 64), 0, s, a);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// General M <= 64-rows-per-chunk GEMM on the skinny kernel: out[M,N] = A[M,K] * op(W) + bias, with the K range split over
+// the 8 waves of a workgroup AND over grid.z slices so that a 64-row problem still fills the chip (a 64 x 64-tile GEMM would
+// run on N/64 workgroups).  The per-step GEMMs of the Show-Attend-Tell decoder (model2.py:54-62: weight_hh projection,
+// LSTMCell input / hidden gradients) have exactly this shape.  w_kmajor: 0 = W[n*ldw + k] ("NT"), 1 = W[k*ldw + n].
+static int skinny_nz(int M, int N, int K) {
+    const long wgs = (long)sat_cdiv(N, 16) * sat_cdiv(M, 64);
+    int nz = (int)(384 / (wgs > 0 ? wgs : 1));
+    const int max_by_k = K / (16 * NWV * 2);                 // at least two 16-wide K blocks per wave and slice
+    if (nz > max_by_k) nz = max_by_k;
+    return nz < 1 ? 1 : (nz > 16 ? 16 : nz);
+}
+
+extern "C" int64_t sat_skinny_gemm_ws_bytes(int M, int N, int K) {
+    const int nz = skinny_nz(M, N, K);
+    return nz > 1 ? (int64_t)nz * M * N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int sat_sum_slabs_f32(const float* in, int nslab, int64_t slab_stride, int64_t n, float* out, sat_stream_t stream);
+
+extern "C" int sat_skinny_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, int w_kmajor, int M, int N, int K,
+                                   const float* bias, float* out, int64_t ldo, float* workspace, int64_t ws_bytes,
+                                   sat_stream_t stream) {
+    if (!A || !W || !out || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || ldo < N) return SAT_ERR_ARG;
+    if (!w_kmajor && (ldw & 3)) return SAT_ERR_ARG;
+    const int nz = skinny_nz(M, N, K);
+    hipStream_t s = (hipStream_t)stream;
+    if (nz == 1) return sat_skinny_store(A, lda, W, ldw, w_kmajor, M, N, K, 1, out, ldo, 0, bias, s);
+    if (ldo != N || (((long)M * N) & 3)) {                   // the slab sum wants a dense, 16-byte-granular result
+        return sat_skinny_store(A, lda, W, ldw, w_kmajor, M, N, K, 1, out, ldo, 0, bias, s);
+    }
+    if (!workspace || ws_bytes < sat_skinny_gemm_ws_bytes(M, N, K)) return SAT_ERR_WORKSPACE;
+    SAT_TRY(sat_skinny_store(A, lda, W, ldw, w_kmajor, M, N, K, nz, workspace, N, (long)M * N, bias, s));
+    return sat_sum_slabs_f32(workspace, nz, (int64_t)M * N, (int64_t)M * N, out, stream);
 }

@@ -39,8 +39,9 @@ def test_attention_fwd_bwd_kernels_vs_fp64():
     ctx.backward(dctx.double())
     d = [t.cuda() for t in (ce, fe, proj, w, dctx)]
     al, co = torch.empty(B, P, device="cuda"), torch.full((B, C + 8), float("nan"), device="cuda")
+    ws = torch.empty(lib.sat_attention_ws_bytes(B, P) // 4, device="cuda")
     L.check(lib.sat_attention_fwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), C, d[3].data_ptr(), B, P, C, al.data_ptr(),
-                                  co.data_ptr() + 16, C + 8, st()))
+                                  co.data_ptr() + 16, C + 8, ws.data_ptr(), ws.numel() * 4, st()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(al.cpu().numpy(), alpha.detach().numpy(), rtol=0, atol=2e-7)
     np.testing.assert_allclose(co[:, 4:4 + C].cpu().numpy(), ctx.detach().numpy(), rtol=0, atol=2e-7)
@@ -49,13 +50,16 @@ def test_attention_fwd_bwd_kernels_vs_fp64():
     dpj, dwp = torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda")
     dfe = torch.zeros(B, P, C, device="cuda")
     L.check(lib.sat_attention_bwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), C, d[3].data_ptr(), al.data_ptr(), d[4].data_ptr(), C,
-                                  B, P, C, dce.data_ptr(), dpj.data_ptr(), dwp.data_ptr(), dfe.data_ptr(), st()))
+                                  B, P, C, dce.data_ptr(), dpj.data_ptr(), dwp.data_ptr(), dfe.data_ptr(), ws.data_ptr(),
+                                  ws.numel() * 4, st()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(dce.cpu().numpy() - 1.0, ce64.grad.numpy(), rtol=0, atol=3e-7)
     np.testing.assert_allclose(dpj.cpu().numpy(), pj64.grad.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(dwp.sum(0).cpu().numpy(), w64.grad.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(dfe.cpu().numpy(), fe64.grad.numpy(), rtol=1e-4, atol=1e-8)       # fine-tuning: gradient into the features
-    assert lib.sat_attention_fwd(None, None, None, C, None, B, P, C, None, None, C, st()) == 1001
+    assert lib.sat_attention_fwd(None, None, None, C, None, B, P, C, None, None, C, None, 0, st()) == 1001
+    assert lib.sat_attention_fwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), C, d[3].data_ptr(), B, P, C, None, co.data_ptr(), C + 8,
+                                 None, 0, st()) == 1002        # workspace missing
 
 
 @pytest.mark.parametrize("dtype", [L.SAT_F32, L.SAT_BF16])

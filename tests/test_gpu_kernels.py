@@ -794,3 +794,30 @@ def test_conv_with_pipelined_input_bn_relu_any_geometry(lib, variant, N, H, W, C
     np.testing.assert_allclose(s1.numpy(), ref.sum(0).numpy(), rtol=2e-3, atol=0.3 + 2e-3 * ref.shape[0] ** 0.5)
     assert int(acc[1].abs().sum()) == 0
     np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,wkm,bias", [(64, 512, 1024, 0, True), (64, 1024, 4096, 1, False), (37, 1536, 4096, 1, False),
+                                            (5, 1024, 512, 1, True), (128, 48, 64, 0, False), (1, 10000, 512, 0, True)])
+def test_skinny_gemm_f32(M, N, K, wkm, bias):
+    """sat_skinny_gemm_f32: the split-K few-rows GEMM of a decode / BPTT step (model2.py:54-62) against float64."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn((K, N) if wkm else (N, K), generator=g) * 0.05
+    b = torch.randn(N, generator=g) if bias else None
+    want = A.double() @ (W.double() if wkm else W.double().t())
+    if bias:
+        want = want + b.double()
+    Ad, Wd = A.cuda(), W.cuda()
+    bd = b.cuda() if bias else None
+    out = torch.full((M, N), float("nan"), device="cuda")
+    need = lib.sat_skinny_gemm_ws_bytes(M, N, K)
+    ws = torch.empty(max(need // 4, 1), device="cuda")
+    L.check(lib.sat_skinny_gemm_f32(Ad.data_ptr(), K, Wd.data_ptr(), N if wkm else K, wkm, M, N, K, L.ptr(bd), out.data_ptr(), N,
+                                    ws.data_ptr(), need, L.stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5 * float(K) ** 0.5 * 0.05 * 4)
+    if need:
+        assert lib.sat_skinny_gemm_f32(Ad.data_ptr(), K, Wd.data_ptr(), N if wkm else K, wkm, M, N, K, None, out.data_ptr(), N,
+                                       None, 0, L.stream()) == 1002
