@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-mode", action="store_true", help="skip the secondary f32 parity-mode measurement")
+    ap.add_argument("--no-lookahead", dest="lookahead", action="store_false",
+                    help="run the frozen conv stack of batch i+1 strictly after batch i's optimizer step (no side-stream overlap)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the bucket all-reduces even with one rank")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU-only check of the rank plumbing (spawn, rendezvous, barrier, max-over-ranks, one JSON line): gloo, no GPU work")
@@ -200,14 +202,27 @@ def main():
     images, caps, lengths = synth_batch(torch, CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 123 + rank)
     global_tokens = world * sum(l - 1 for l in lengths)
 
-    for _ in range(args.warmup):
-        loss = dp.step((images, caps, lengths), global_tokens)
+    # three synthetic image batches in rotation: with look-ahead (default) a step hands the NEXT TWO batches' images to the engine,
+    # which runs their frozen conv stacks on side streams next to each other and under this batch's decoder work
+    # (TrainStep.prefetch_encoder).  Warm-up leaves nothing in flight, so the timed region holds exactly K conv-stack passes and K
+    # decoder passes: pipeline fill (step 1's stack runs alone, on the main stream) and drain are inside it.
+    batches = [images] + [synth_batch(torch, CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 977 * (k + 1) + rank)[0]
+                          for k in range(2)]
+
+    def run_steps(n):
+        out = None
+        for i in range(n):
+            nxt = [batches[j % 3] for j in (i + 1, i + 2) if j < n] if args.lookahead else None
+            out = dp.step((batches[i % 3], caps, lengths), global_tokens, next_images=nxt or None)
+        return out
+
+    if args.warmup:
+        loss = run_steps(args.warmup)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = dp.step((images, caps, lengths), global_tokens)
+    loss = run_steps(args.steps)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -232,6 +247,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: batch=64/GPU 224x224x3 + len-20 captions, ResNet-152 encoder (frozen, train-mode BN), embed=256 hidden=512 vocab=10000 L=1; fwd+CE+bwd+clamp+Adam",
                        "global_batch": world * CFG["batch"], "parallelism": "dp%d" % world,
                        "precision": "conv stack bf16 MFMA / f32 accumulate; head, LSTM, vocab, CE, Adam f32 (exact-f32 MFMA)",
+                       "schedule": ("encoder look-ahead: the frozen conv stacks of batches i+1 and i+2 run on side streams next to each other and under batch i's head/decoder/backward/Adam; "
+                                    "K conv passes + K decoder passes inside the timed region, fill and drain included") if args.lookahead
+                                   else "strictly sequential steps",
                        "final_loss": round(final_loss, 4)},
             "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel (bf16 implicit-GEMM conv, %d launches/step, variants autotuned per geometry)" % n_conv,
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 8
+#define SAT_ABI_VERSION 9
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -78,6 +78,16 @@ typedef struct sat_bn_eval_item {
     int32_t C;
     int32_t reserved;
 } sat_bn_eval_item;
+
+/* one BatchNorm of a train-mode stack whose running-statistics update was deferred (sat_bn_running_apply) */
+typedef struct sat_bn_running_item {
+    float* running_mean;          /* the model's buffers (models.py:14 resnet152 BatchNorm2d), C floats */
+    float* running_var;
+    const float* batch_mean;      /* this batch's mean / unbiased variance as the program left them (f32) */
+    const float* batch_var;
+    int32_t C;
+    int32_t reserved;
+} sat_bn_running_item;
 
 typedef struct sat_op {
     int32_t kind;
@@ -145,6 +155,12 @@ typedef struct sat_op {
 
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
 /* same, with the step parity (0/1) that selects the half of every stat_acc buffer in use */
+/* Deferred running statistics.  A program built with its sat_op running_mean / running_var pointers aimed at PRIVATE, zeroed
+ * buffers and momentum 1 leaves each layer's batch (mean, unbiased variance) there and touches no model state, so two batches'
+ * frozen conv stacks may be in flight at once (TrainStep.prefetch_encoder).  This applies one finished batch to the model:
+ * running = (1-momentum)*running + momentum*batch for every item, one launch, bit-identical to the in-kernel update.  The
+ * caller orders the calls like the batches (nn.BatchNorm2d momentum update, train.py:128 `encoder.train()`). */
+int sat_bn_running_apply(const sat_bn_running_item* items /*[device]*/, int n_items, float momentum, sat_stream_t stream);
 int sat_run_ops_parity(const sat_op* ops /*[host]*/, int n_ops, int parity, sat_stream_t stream);
 /* The same program as ONE hipGraph launch (the reference's `self.resnet(images)` issues ~1500 eager kernels per
  * forward, models.py:27; here the host enqueues one graph).  sat_graph_create records ops[0..n) for the given step

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -25,6 +25,12 @@ class SatBnEvalItem(C.Structure):
     """mirror of `struct sat_bn_eval_item` (include/sat_hip.h)"""
     _fields_ = [("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
                 ("scale_out", _vp), ("shift_out", _vp), ("C", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SatBnRunningItem(C.Structure):
+    """mirror of `struct sat_bn_running_item` (include/sat_hip.h)"""
+    _fields_ = [("running_mean", _vp), ("running_var", _vp), ("batch_mean", _vp), ("batch_var", _vp),
+                ("C", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SatOp(C.Structure):
@@ -95,6 +101,7 @@ SIGNATURES = {
     "sat_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
     "sat_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_attention_ws_bytes": (_i64, [_i, _i]),
+    "sat_bn_running_apply": (_i, [_vp, _i, _f, _vp]),
     "sat_pad_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sat_maxpool2_bwd_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sat_bcast_add_f32": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),

@@ -357,8 +357,9 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 if (bid == 0) {
                     if (p.in_running_mean) {
                         const double unbiased = p.in_count > 1.0 ? var * p.in_count / (p.in_count - 1.0) : var;
-                        p.in_running_mean[c] = (float)((1.0 - p.in_momentum) * p.in_running_mean[c] + p.in_momentum * mean);
-                        p.in_running_var[c] = (float)((1.0 - p.in_momentum) * p.in_running_var[c] + p.in_momentum * unbiased);
+                        // the batch statistic enters as an f32 value: a deferred update (sat_bn_running_apply) is then bit-identical
+                        p.in_running_mean[c] = (float)((1.0 - p.in_momentum) * p.in_running_mean[c] + p.in_momentum * (double)(float)mean);
+                        p.in_running_var[c] = (float)((1.0 - p.in_momentum) * p.in_running_var[c] + p.in_momentum * (double)(float)unbiased);
                     }
                     if (p.in_acc_clear)
                         for (int sh = 0; sh < p.in_shards; ++sh) {

@@ -122,8 +122,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
             if (var < 0.0) var = 0.0;
             if (running_mean) {
                 const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (double)(float)mean);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * (double)(float)unbiased);
             }
         } else {
             mean = running_mean[c];
@@ -188,6 +188,17 @@ __global__ __launch_bounds__(256) void bn_eval_batch_kernel(const sat_bn_eval_it
     }
 }
 
+// Deferred running-statistics update: a program run with momentum 1 into private buffers leaves every layer's batch (mean,
+// unbiased var) there as f32; this applies them to the model's running statistics with the real momentum -- the same expression
+// on the same f32 inputs as the in-kernel update, so bit-identical to it -- one workgroup per layer, in the caller's batch order.
+__global__ __launch_bounds__(256) void bn_running_apply_kernel(const sat_bn_running_item* __restrict__ items, float momentum) {
+    const sat_bn_running_item it = items[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += 256) {
+        it.running_mean[c] = (float)((1.0 - momentum) * it.running_mean[c] + momentum * (double)it.batch_mean[c]);
+        it.running_var[c] = (float)((1.0 - momentum) * it.running_var[c] + momentum * (double)it.batch_var[c]);
+    }
+}
+
 // Where a BatchNorm's (scale, shift) comes from: either a table the finalize kernel wrote, or -- `acc` set -- the
 // fixed-point integer sums the producing conv accumulated (sat_conv_glds.hip): then every workgroup derives the
 // table itself into LDS (a few KB of loads, f64 arithmetic identical to bn_finalize_kernel), and workgroup 0 also
@@ -223,8 +234,8 @@ __device__ __forceinline__ void bn_table_from_acc(const BnSrc& b, int C, double 
         if (blockIdx.x == 0) {
             if (b.running_mean) {
                 const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                b.running_mean[c] = (float)((1.0 - momentum) * b.running_mean[c] + momentum * mean);
-                b.running_var[c] = (float)((1.0 - momentum) * b.running_var[c] + momentum * unbiased);
+                b.running_mean[c] = (float)((1.0 - momentum) * b.running_mean[c] + momentum * (double)(float)mean);
+                b.running_var[c] = (float)((1.0 - momentum) * b.running_var[c] + momentum * (double)(float)unbiased);
             }
             if (b.acc_clear)
                 for (int sh = 0; sh < b.shards; ++sh) { b.acc_clear[(long)sh * 2 * C + c] = 0; b.acc_clear[(long)sh * 2 * C + C + c] = 0; }
@@ -889,6 +900,14 @@ int sat_image_prep_launch(const sat_op* op, hipStream_t s) {
     else
         hipLaunchKernelGGL(image_prep_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (const float*)op->in0,
                            (float*)op->out, op->N, op->Hin, op->Win, op->Hout, op->Wout, op->pad);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+extern "C" int sat_bn_running_apply(const sat_bn_running_item* items, int n_items, float momentum, sat_stream_t stream) {
+    if (!items || n_items < 0 || !(momentum >= 0.0f && momentum <= 1.0f)) return SAT_ERR_ARG;
+    if (n_items == 0) return SAT_OK;
+    hipLaunchKernelGGL(bn_running_apply_kernel, dim3(n_items), dim3(256), 0, (hipStream_t)stream, items, momentum);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }

@@ -314,6 +314,7 @@ class InceptionProgram(ConvStackProgram):
         self._parity = 0
         self._use_graph = os.environ.get("SAT_GRAPH", "1") != "0" and torch.device(device).type == "cuda"
         self._runs, self._graphs = [0, 0], [None, None]
+        self._running_items = None
         if dtype == L.SAT_BF16 and os.environ.get("SAT_AUTOTUNE", "1") != "0" and torch.device(device).type == "cuda":
             scratch = alloc((4096,), torch.float32)         # per-geometry kernel selection, as on the ResNet path
             L.check(lib.sat_conv_autotune(self.ops, self.n_ops, 3, scratch.data_ptr(), scratch.numel() * 4, L.stream()), "sat_conv_autotune")

@@ -117,17 +117,22 @@ class EncoderCNN(nn.Module):
         self._programs.clear()      # device / dtype moves invalidate cached device pointers
         return super()._apply(fn, *a, **k)
 
-    def _program(self, images):
+    def _program(self, images, instance=None):
+        """instance None: the program `forward` runs (updates running statistics itself).  instance 0, 1, ...: independent
+        copies (own activations, statistics accumulators, graphs) with DEFERRED running-statistics updates, for batches in
+        flight next to each other on side streams (TrainStep.prefetch_encoder)."""
         N, _, H, W = images.shape
         dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
-        key = (N, H, W, dt, self.training, str(images.device), weights_signature(self.resnet))
+        key = (N, H, W, dt, self.training, str(images.device), weights_signature(self.resnet), instance)
         prog = self._programs.get(key)
         if prog is None:
-            if len(self._programs) >= 4:
+            if len(self._programs) >= 6:
                 self._programs.clear()
             make = getattr(self.resnet, "program", None)
             prog = self._programs[key] = (make(N, H, W, dt, self.training, images.device) if make is not None else
                                           ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device))
+            if instance is not None:
+                prog.defer_running_stats()
         return prog
 
     def refresh_weights(self):

@@ -468,6 +468,7 @@ class ConvStackProgram:
         # replay as a hipGraph (SAT_GRAPH=0: eager launches).  Per step parity: first run eager, then captured.
         self._use_graph = os.environ.get("SAT_GRAPH", "1") != "0" and torch.device(device).type == "cuda"
         self._runs, self._graphs = [0, 0], [None, None]
+        self._running_items = None              # defer_running_stats(): number of redirected BatchNorms
         # build-time kernel selection per conv geometry (bf16): time every variant on this program's own buffers.
         # The choice is timing dependent and the tile shape fixes the BatchNorm summation order, so bf16 results are
         # bit-reproducible across processes only with the same choices: SAT_TUNE_FILE=<json> saves them / loads them back.
@@ -513,6 +514,52 @@ class ConvStackProgram:
                 except Exception:
                     pass
 
+    def defer_running_stats(self):
+        """Aim every running-statistics update of this (train-mode) program at private zeroed buffers with momentum 1, so that a
+        run leaves each layer's batch (mean, unbiased var) there and touches NO model state; `apply_running_stats()` then does
+        the real momentum update in one launch.  Lets two batches' frozen stacks be in flight at once while the model's
+        running statistics still advance in batch order (TrainStep.prefetch_encoder).  Call before the first run."""
+        if not self.training or self._running_items is not None:
+            return
+        if self._runs != [0, 0]:
+            raise RuntimeError("defer_running_stats must precede the first run (the hipGraph captures the pointers)")
+        dev = self.pooled.device
+        by_ptr = {bn.running_mean.data_ptr(): bn for bn in self.stack.bns()}
+        items, seen = [], set()
+        for i in range(self.n_ops):
+            o = self.ops[i]
+            hit = False
+            for fm, fv in (("running_mean", "running_var"), ("running_mean1", "running_var1")):
+                ptr = getattr(o, fm)
+                if not ptr:
+                    continue
+                bn = by_ptr.get(ptr)
+                if bn is None or ptr in seen:
+                    raise RuntimeError("op %d updates running statistics this program cannot attribute to one BatchNorm" % i)
+                seen.add(ptr)
+                log = torch.zeros(2, bn.running_mean.numel(), dtype=torch.float32, device=dev)
+                self.keep.append(log)
+                setattr(o, fm, log[0].data_ptr())
+                setattr(o, fv, log[1].data_ptr())
+                it = L.SatBnRunningItem()
+                it.running_mean, it.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                it.batch_mean, it.batch_var, it.C = log[0].data_ptr(), log[1].data_ptr(), bn.running_mean.numel()
+                items.append(it)
+                hit = True
+            if hit:
+                o.momentum = 1.0           # running' = 0 * running + 1 * f32(batch statistic): the log holds the statistic itself
+        arr = (L.SatBnRunningItem * max(len(items), 1))(*items)
+        self._running_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self._running_items = len(items)
+
+    def apply_running_stats(self):
+        """Momentum update of the model's running statistics from the last run's batch statistics (deferred programs only),
+        on the current stream; the caller has ordered that stream behind the run."""
+        if self._running_items:
+            L.check(L.load().sat_bn_running_apply(self._running_table.data_ptr(), self._running_items, BN_MOMENTUM, L.stream()),
+                    "sat_bn_running_apply")
+            self.stack._nbt_flat += 1
+
     def run(self, images):
         """images f32 [N,3,H,W] NCHW on the device -> pooled f32 [N, feature_dim] (owned by the program)."""
         L.require_gpu(images, "images")
@@ -535,7 +582,7 @@ class ConvStackProgram:
             L.check(lib.sat_graph_launch(self._graphs[p], L.stream()), "sat_graph_launch")
         self._runs[p] += 1
         self._parity ^= 1
-        if self.training:
+        if self.training and self._running_items is None:
             self.stack._nbt_flat += 1
         return self.pooled
 

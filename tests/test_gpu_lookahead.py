@@ -1,0 +1,57 @@
+"""Encoder look-ahead (TrainStep.prefetch_encoder): running the frozen conv stack of batch i+1 on a side stream under batch i's
+decoder work must not change a single bit of any step's loss or of the parameters (models.py:14-15, 25-27: the stack is frozen
+and under no_grad, so it does not depend on the optimizer step in between)."""
+import importlib
+
+import pytest
+import torch
+
+sat = importlib.import_module("show-and-tell_amd")
+pytestmark = pytest.mark.gpu
+
+
+def _run(lookahead, steps=6, B=8, img=64):
+    torch.manual_seed(5)
+    model = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().train()
+    ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+    g = torch.Generator().manual_seed(11)
+    batches = [torch.rand(B, 3, img, img, generator=g).cuda() for _ in range(3)]
+    caps = torch.randint(1, 120, (B, 9), generator=g).cuda()
+    lengths = [9, 9, 8, 7, 6, 5, 4, 3]
+    losses = []
+    for i in range(steps):
+        nxt = [batches[j % 3] for j in (i + 1, i + 2)[:lookahead] if j < steps] or None
+        losses.append(ts.step(batches[i % 3], caps, lengths, next_images=nxt))
+    torch.cuda.synchronize()
+    ts.check_ids()
+    rs = torch.cat([torch.cat([bn.running_mean, bn.running_var]) for bn in model.encoder.resnet.bns()])
+    nbt = next(iter(model.encoder.resnet.bns())).num_batches_tracked
+    return torch.cat(losses).cpu(), ts.flat.params.clone().cpu(), model.encoder.bn.running_mean.clone().cpu(), rs.cpu(), nbt.cpu()
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+def test_lookahead_is_bitwise_identical_to_sequential(depth):
+    """losses, parameters, the head's and EVERY conv-stack BatchNorm's running statistics and num_batches_tracked"""
+    a = _run(0)
+    b = _run(depth)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert int(a[4]) == 6
+
+
+def test_lookahead_of_a_different_tensor_is_discarded():
+    torch.manual_seed(5)
+    model = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().train()
+    ts = sat.TrainStep(model)
+    g = torch.Generator().manual_seed(11)
+    x0, x1, x2 = (torch.rand(4, 3, 64, 64, generator=g).cuda() for _ in range(3))
+    caps = torch.randint(1, 120, (4, 6), generator=g).cuda()
+    lengths = [6, 5, 4, 3]
+    ts.step(x0, caps, lengths, next_images=x1)
+    got = ts.step(x2, caps, lengths)                     # NOT the prefetched batch: must be computed for x2
+    torch.manual_seed(5)
+    model2 = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().train()
+    ts2 = sat.TrainStep(model2)
+    ts2.step(x0, caps, lengths)
+    want = ts2.step(x2, caps, lengths)
+    assert torch.equal(got.cpu(), want.cpu())
