@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 9
+#define SAT_ABI_VERSION 10
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -288,6 +288,11 @@ int sat_sum_slabs_f32(const float* in, int nslab, int64_t slab_stride, int64_t n
 int sat_skinny_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, int w_kmajor, int M, int N, int K,
                         const float* bias, float* out, int64_t ldo, float* workspace, int64_t ws_bytes, sat_stream_t stream);
 int64_t sat_skinny_gemm_ws_bytes(int M, int N, int K);
+/* ... with an optional second product into the same output: out = A W + A2 W2 + bias (both W in the layout w_kmajor names);
+ * workspace as for (M, N, K). */
+int sat_skinny_gemm2_f32(const float* A, int64_t lda, const float* W, int64_t ldw, int K, const float* A2, int64_t lda2,
+                         const float* W2, int64_t ldw2, int K2, int w_kmajor, int M, int N, const float* bias, float* out,
+                         int64_t ldo, float* workspace, int64_t ws_bytes, sat_stream_t stream);
 /* greedy argmax of one decode step (models.py:61-63): ids[b*ids_stride] = first argmax_v (h[b] . w[v] + b[v]) */
 int sat_vocab_argmax(const float* h /*[B,H]*/, const float* w, const float* b, int B, int H, int V,
                      int64_t* ids, int64_t ids_stride, float* workspace, int64_t ws_bytes, sat_stream_t stream);
@@ -319,7 +324,9 @@ int sat_attention_fwd(const float* ctx_enc, const float* feats, const float* pro
                       sat_stream_t stream);
 int64_t sat_attention_ws_bytes(int rows, int P);     /* raw scores (forward) / d_alpha (backward) between the two launches */
 int sat_attention_bwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
-                      const float* alpha, const float* d_ctx, int64_t ld_dctx, int rows, int P, int C,
+                      const float* alpha, const float* d_ctx, int64_t ld_dctx,
+                      const float* d_ctx2 /* nullable: d_context = d_ctx + d_ctx2 (its two consumers, model2.py:58 and :82) */,
+                      int64_t ld_dctx2, int rows, int P, int C,
                       float* d_ctx_enc, float* d_proj, float* d_watt_part, float* d_feats /*[rows][P][C] += , or NULL*/,
                       float* workspace, int64_t ws_bytes, sat_stream_t stream);
 int sat_lstmcell_fwd(const float* x /*[B,In]*/, const float* h_in /*[B,H]*/, float* c /*[B,H] in place*/, const float* w_ih,

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -94,12 +94,13 @@ SIGNATURES = {
     "sat_sum_slabs_f32": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
     "sat_skinny_gemm_f32": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
     "sat_skinny_gemm_ws_bytes": (_i64, [_i, _i, _i]),
+    "sat_skinny_gemm2_f32": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
     "sat_vocab_argmax": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _i64, _vp]),
     "sat_vocab_argmax_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_embed_rows": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "sat_attention_fwd": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
-    "sat_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sat_attention_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_attention_ws_bytes": (_i64, [_i, _i]),
     "sat_bn_running_apply": (_i, [_vp, _i, _f, _vp]),
     "sat_pad_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

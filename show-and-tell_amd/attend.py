@@ -316,27 +316,29 @@ class _AttendFn(torch.autograd.Function):
         _gemm(lib, 0, 0, fmean, C, m.init_hidden.weight, C, h0, H, B, H, C, m.init_hidden.bias)  # model2.py:67-71
         _gemm(lib, 0, 0, fmean, C, m.init_memory.weight, C, c0, H, B, H, C, m.init_memory.bias)
         c = c0.clone()
-        CTX, HS = torch.empty(N, C, device=dev), torch.empty(N, H, device=dev)
+        HS, PROJ = torch.empty(N, H, device=dev), torch.empty(N, C, device=dev)
         X, GATES = torch.empty(N, Hin, device=dev), torch.empty(N, 4 * H, device=dev)
         CS, ALPHA = torch.empty(N, H, device=dev), torch.empty(N, P, device=dev)
-        proj = torch.empty(B, C, device=dev)
         watt = m.weight_att.view(-1)
         att_ws = torch.empty(B * P, device=dev)
+        # the embedding half of every step's LSTMCell input [emb | ctx] (model2.py:55-57) in one gather
+        toks = torch.empty(N, dtype=torch.int64, device=dev)
+        L.check(lib.sat_pack_tokens(captions.data_ptr(), captions.stride(0), pi.prefix_dev.data_ptr(), T, N, 0, toks.data_ptr(), st),
+                "sat_pack_tokens")
+        L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, toks.data_ptr(), 1, V, N, E, L.ptr(X), Hin, st), "sat_rows_copy")
         for t, bs in enumerate(pi.batch_sizes):                                                  # model2.py:54-62
             r0 = pi.prefix[t]
             hprev = h0.data_ptr() if t == 0 else _p(HS, pi.prefix[t - 1])
-            _gemm(lib, 0, 0, hprev, H, m.weight_hh.weight, H, proj, C, bs, C, H, m.weight_hh.bias)
-            L.check(lib.sat_attention_fwd(L.ptr(ctx_enc), L.ptr(f2), L.ptr(proj), C, L.ptr(watt), bs, P, C, _p(ALPHA, r0),
-                                          _p(CTX, r0), C, att_ws.data_ptr(), att_ws.numel() * 4, st), "sat_attention_fwd")
-            L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, captions.data_ptr() + t * 8, captions.stride(0), V, bs, E,
-                                      _p(X, r0), Hin, st), "sat_rows_copy")
-            L.check(lib.sat_rows_copy(_p(CTX, r0), C, None, 0, bs, bs, C, _p(X, r0) + E * 4, Hin, st), "sat_rows_copy")
+            _gemm(lib, 0, 0, hprev, H, m.weight_hh.weight, H, _p(PROJ, r0), C, bs, C, H, m.weight_hh.bias)
+            # the context lands in its half of the LSTMCell input row (ld = Hin)
+            L.check(lib.sat_attention_fwd(L.ptr(ctx_enc), L.ptr(f2), _p(PROJ, r0), C, L.ptr(watt), bs, P, C, _p(ALPHA, r0),
+                                          _p(X, r0) + E * 4, Hin, att_ws.data_ptr(), att_ws.numel() * 4, st), "sat_attention_fwd")
             L.check(lib.sat_lstmcell_fwd(_p(X, r0), hprev, L.ptr(c), L.ptr(m.lstmcell.weight_ih), L.ptr(m.lstmcell.weight_hh),
                                          L.ptr(m.lstmcell.bias_ih), L.ptr(m.lstmcell.bias_hh), bs, Hin, H, _p(HS, r0),
                                          _p(GATES, r0), _p(CS, r0), st), "sat_lstmcell_fwd")
         # output_layer over all packed rows at once (model2.py:80-85): z = [ctx | h] [W_c2o | W_h2o]^T + b1 + b2
         Zin, Wz = torch.empty(N, C + H, device=dev), torch.empty(E, C + H, device=dev)
-        L.check(lib.sat_rows_copy(L.ptr(CTX), C, None, 0, N, N, C, L.ptr(Zin), C + H, st), "sat_rows_copy")
+        L.check(lib.sat_rows_copy(X.data_ptr() + E * 4, Hin, None, 0, N, N, C, L.ptr(Zin), C + H, st), "sat_rows_copy")
         L.check(lib.sat_rows_copy(L.ptr(HS), H, None, 0, N, N, H, Zin.data_ptr() + C * 4, C + H, st), "sat_rows_copy")
         L.check(lib.sat_rows_copy(L.ptr(m.context2out.weight), C, None, 0, E, E, C, L.ptr(Wz), C + H, st), "sat_rows_copy")
         L.check(lib.sat_rows_copy(L.ptr(m.hidden2tout.weight), H, None, 0, E, E, H, Wz.data_ptr() + C * 4, C + H, st), "sat_rows_copy")
@@ -346,8 +348,8 @@ class _AttendFn(torch.autograd.Function):
         logits = torch.zeros(N, ldl, device=dev) if V % 4 else torch.empty(N, V, device=dev)
         _gemm(lib, 0, 0, Z, E, m.classifier.weight, E, logits, ldl, N, V, E, m.classifier.bias)
         ctx.m, ctx.pi, ctx.captions = m, pi, captions
-        ctx.tapes = dict(f2=f2, fmean=fmean, ctx_enc=ctx_enc, h0=h0, c0=c0, CTX=CTX, HS=HS, X=X, GATES=GATES, CS=CS, ALPHA=ALPHA,
-                         Zin=Zin, Wz=Wz, Z=Z)
+        ctx.tapes = dict(f2=f2, fmean=fmean, ctx_enc=ctx_enc, h0=h0, c0=c0, PROJ=PROJ, HS=HS, X=X, GATES=GATES, CS=CS, ALPHA=ALPHA,
+                         Zin=Zin, Wz=Wz, Z=Z, toks=toks)
         return logits if ldl == V else logits[:, :V]
 
     @staticmethod
@@ -413,6 +415,7 @@ class ShowAttendTellModel(nn.Module):
         self.hidden_size, self.embed_size, self.vocab_size, self.feat = hidden_size, embed_size, vocab_size, feat
         self.compute_dtype = compute_dtype
         self._programs, self._guard = {}, None
+        self._pf, self._pf_stream = None, None
         self.register_load_state_dict_post_hook(lambda mod, k: mod._programs.clear())
         self.encoder.register_load_state_dict_post_hook(lambda mod, k: self._programs.clear())
 
@@ -428,8 +431,47 @@ class ShowAttendTellModel(nn.Module):
         self._programs.clear()
         return super()._apply(fn, *a, **k)
 
+    def prefetch_features(self, images):
+        """Start the FROZEN conv stack (model2.py:17 `finetune(allow=False)`) of a LATER batch on a side stream, under the current
+        batch's decoder forward / backward / optimizer (hundreds of small launches that leave most of the chip idle).  The
+        features depend on the images and the frozen weights only, so this changes the schedule, not a bit of the result;
+        `forward(images, ...)` / `sample(images)` of the SAME tensor object picks them up.  No-op while fine-tuning."""
+        if images is None or any(p.requires_grad for p in self.encoder.parameters()):
+            return False
+        if self._pf is not None and self._pf[0] is images:
+            return False
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream(device=images.device, priority=int(os.environ.get("SAT_PF_PRIORITY", "0")))
+        main = torch.cuda.current_stream(images.device)
+        self._pf_stream.wait_stream(main)
+        with torch.cuda.stream(self._pf_stream), torch.no_grad():
+            feats, fmean = self._program_for(images).run(images)
+            feats, fmean = feats.clone(), fmean.clone()
+            ev = torch.cuda.Event()
+            ev.record(self._pf_stream)
+        feats.record_stream(main)
+        fmean.record_stream(main)
+        self._pf = (images, feats, fmean, ev)
+        return True
+
+    def _program_for(self, images):
+        N, _, H, W = images.shape
+        dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
+        sig = sum(p._version * 7 + (p.data_ptr() & 0xffffffff) for p in self.encoder.parameters())
+        key = (N, H, W, dt, str(images.device), sig)
+        prog = self._programs.get(key)
+        if prog is None:
+            self._programs.clear()
+            prog = self._programs[key] = VggProgram(self.encoder, N, H, W, dt, images.device)
+        return prog
+
     def _encode(self, images):
         L.require_gpu(images, "images")
+        pf, self._pf = self._pf, None
+        if pf is not None:
+            torch.cuda.current_stream(images.device).wait_event(pf[3])      # also orders the program's buffers behind it
+            if pf[0] is images and not any(p.requires_grad for p in self.encoder.parameters()):
+                return pf[1], pf[2]
         N, _, H, W = images.shape
         dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
         sig = sum(p._version * 7 + (p.data_ptr() & 0xffffffff) for p in self.encoder.parameters())

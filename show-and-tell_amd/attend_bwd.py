@@ -17,11 +17,11 @@ def attend_backward(m, pi, captions, tp, dlogits, want_dfeat=False):
     lib, st = L.load(), L.stream()
     dev = dlogits.device
     f2, fmean, ctx_enc = tp["f2"], tp["fmean"], tp["ctx_enc"]
-    CTX, HS, X, GATES, CS, ALPHA, Zin, Wz, Z = (tp[k] for k in ("CTX", "HS", "X", "GATES", "CS", "ALPHA", "Zin", "Wz", "Z"))
+    PROJ, HS, X, GATES, CS, ALPHA, Zin, Wz, Z = (tp[k] for k in ("PROJ", "HS", "X", "GATES", "CS", "ALPHA", "Zin", "Wz", "Z"))
     h0, c0 = tp["h0"], tp["c0"]
     N, T, B = pi.N, pi.T, pi.B
     P = ALPHA.shape[1]
-    C, H, E, V = CTX.shape[1], HS.shape[1], Z.shape[1], m.vocab_size
+    C, H, E, V = PROJ.shape[1], HS.shape[1], Z.shape[1], m.vocab_size
     Hin = X.shape[1]
     ldl = (V + 3) // 4 * 4
     if dlogits.shape[1] != ldl or not dlogits.is_contiguous():          # rows padded to 4 floats, zero pad
@@ -50,37 +50,36 @@ def attend_backward(m, pi, captions, tp, dlogits, want_dfeat=False):
     L.check(lib.sat_rows_copy(dZin.data_ptr() + C * 4, C + H, None, 0, N, N, H, DH.data_ptr(), H, st), "sat_rows_copy")
     # ---- the recurrence, last step first (model2.py:54-62) ----
     DG, DPROJ = torch.empty(N, 4 * H, device=dev), torch.empty(N, C, device=dev)
-    DX = torch.empty(B, Hin, device=dev)
-    DEMB = torch.empty(N, E, device=dev)
-    dctx = torch.empty(B, C, device=dev)
-    dh_carry, dh_a, dh_b = torch.zeros(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+    DX = torch.empty(N, Hin, device=dev)                # d[emb | ctx] of every packed row
+    DWATT = torch.empty(N, C, device=dev)               # per-row partials of d weight_att, reduced once after the loop
+    dh_carry = torch.zeros(B, H, device=dev)
     dc_state = torch.zeros(B, H, device=dev)
     d_ctx_enc = torch.zeros_like(ctx_enc)
     d_feats = torch.zeros_like(ctx_enc) if want_dfeat else None      # [B*P, C]: what the weighted means send back (per step)
-    dwatt_part = torch.empty(B, C, device=dev)
     att_ws = torch.empty(B * P, device=dev)
-    g["weight_att"] = torch.zeros(C, device=dev)
-    proj = torch.empty(B, C, device=dev)
+    sk_ws = torch.empty(max(lib.sat_skinny_gemm_ws_bytes(B, H, 4 * H) // 4, 4), device=dev)
     watt = m.weight_att.view(-1)
     for t in reversed(range(T)):
         bs, r0 = pi.batch_sizes[t], pi.prefix[t]
         n_carry = pi.batch_sizes[t + 1] if t + 1 < T else 0
-        hprev = h0.data_ptr() if t == 0 else _rows(HS, pi.prefix[t - 1])
         cprev = c0.data_ptr() if t == 0 else _rows(CS, pi.prefix[t - 1])
         L.check(lib.sat_lstmcell_bwd_point(_rows(DH, r0), dh_carry.data_ptr() if n_carry else None, n_carry, _rows(GATES, r0),
                                            _rows(CS, r0), cprev, dc_state.data_ptr(), _rows(DG, r0), bs, H, st), "sat_lstmcell_bwd_point")
-        _gemm(lib, 0, 1, _rows(DG, r0), 4 * H, m.lstmcell.weight_ih, Hin, DX, Hin, bs, Hin, 4 * H)       # d[emb | ctx]
-        L.check(lib.sat_rows_copy(DX.data_ptr(), Hin, None, 0, bs, bs, E, _rows(DEMB, r0), E, st), "sat_rows_copy")
-        L.check(lib.sat_rows_add(DX.data_ptr() + E * 4, Hin, _rows(dZin, r0), C + H, bs, C, dctx.data_ptr(), C, st), "sat_rows_add")
-        _gemm(lib, 0, 0, hprev, H, m.weight_hh.weight, H, proj, C, bs, C, H, m.weight_hh.bias)           # recompute the projection
-        L.check(lib.sat_attention_bwd(ctx_enc.data_ptr(), f2.data_ptr(), proj.data_ptr(), C, watt.data_ptr(), _rows(ALPHA, r0),
-                                      dctx.data_ptr(), C, bs, P, C, d_ctx_enc.data_ptr(), _rows(DPROJ, r0), dwatt_part.data_ptr(),
-                                      d_feats.data_ptr() if d_feats is not None else None, att_ws.data_ptr(), att_ws.numel() * 4, st),
-                "sat_attention_bwd")
-        L.check(lib.sat_rows_sum(dwatt_part.data_ptr(), C, bs, C, g["weight_att"].data_ptr(), 1, st), "sat_rows_sum")
-        _gemm(lib, 0, 1, _rows(DG, r0), 4 * H, m.lstmcell.weight_hh, H, dh_a, H, bs, H, 4 * H)           # dh_{t-1} via the LSTM
-        _gemm(lib, 0, 1, _rows(DPROJ, r0), C, m.weight_hh.weight, H, dh_b, H, bs, H, C)                  # ... and via the attention
-        L.check(lib.sat_rows_add(dh_a.data_ptr(), H, dh_b.data_ptr(), H, bs, H, dh_carry.data_ptr(), H, st), "sat_rows_add")
+        _gemm(lib, 0, 1, _rows(DG, r0), 4 * H, m.lstmcell.weight_ih, Hin, _rows(DX, r0), Hin, bs, Hin, 4 * H)   # d[emb | ctx]
+        # d context = its LSTMCell-input half + its output_layer half (summed where the attention backward reads it); the
+        # projection weight_hh(h_{t-1}) comes from the forward's tape
+        L.check(lib.sat_attention_bwd(ctx_enc.data_ptr(), f2.data_ptr(), _rows(PROJ, r0), C, watt.data_ptr(), _rows(ALPHA, r0),
+                                      _rows(DX, r0) + E * 4, Hin, _rows(dZin, r0), C + H, bs, P, C, d_ctx_enc.data_ptr(),
+                                      _rows(DPROJ, r0), _rows(DWATT, r0), d_feats.data_ptr() if d_feats is not None else None,
+                                      att_ws.data_ptr(), att_ws.numel() * 4, st), "sat_attention_bwd")
+        # dh_{t-1} = DG_t W_hh (through the LSTMCell) + DPROJ_t W_whh (through the attention projection): one launch
+        L.check(lib.sat_skinny_gemm2_f32(_rows(DG, r0), 4 * H, m.lstmcell.weight_hh.data_ptr(), H, 4 * H,
+                                         _rows(DPROJ, r0), C, m.weight_hh.weight.data_ptr(), H, C, 1, bs, H, None,
+                                         dh_carry.data_ptr(), H, sk_ws.data_ptr(), sk_ws.numel() * 4, st), "sat_skinny_gemm2_f32")
+    g["weight_att"] = torch.empty(C, device=dev)
+    L.check(lib.sat_colsum_f32(DWATT.data_ptr(), C, N, C, g["weight_att"].data_ptr(), st), "sat_colsum_f32")
+    DEMB = torch.empty(N, E, device=dev)
+    L.check(lib.sat_rows_copy(DX.data_ptr(), Hin, None, 0, N, N, E, DEMB.data_ptr(), E, st), "sat_rows_copy")
     # ---- batched weight gradients of the recurrence ----
     HPREV = torch.empty(N, H, device=dev)              # h_{t-1} per packed row: h0 for step 0, HS rows of step t-1 after
     L.check(lib.sat_rows_copy(h0.data_ptr(), H, None, 0, B, pi.batch_sizes[0], H, HPREV.data_ptr(), H, st), "sat_rows_copy")
@@ -109,9 +108,7 @@ def attend_backward(m, pi, captions, tp, dlogits, want_dfeat=False):
     _gemm(lib, 2, 1, f2, C, d_ctx_enc, C, g["image_att_w"], C, C, C, f2.shape[0])
     g["weight_att"] = g["weight_att"].view(C, 1)
     # ---- embedding (dense gradient, nn.Embedding default): deterministic scatter of the per-row input gradients ----
-    toks = torch.empty(N, dtype=torch.int64, device=dev)
-    L.check(lib.sat_pack_tokens(captions.data_ptr(), captions.stride(0), pi.prefix_dev.data_ptr(), T, N, 0, toks.data_ptr(), st),
-            "sat_pack_tokens")
+    toks = tp["toks"]
     g["embedding.weight"] = torch.empty(V, E, device=dev)
     L.check(lib.sat_scatter_rows_add(DEMB.data_ptr(), toks.data_ptr(), N, E, V, g["embedding.weight"].data_ptr(), st),
             "sat_scatter_rows_add")

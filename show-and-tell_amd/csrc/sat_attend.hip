@@ -41,7 +41,8 @@ constexpr int kAttWaves = 8;
 // TANH = false: v[p] = scale * sum_c x[b,p,c] * mul_row[b,c]         (d_alpha = feats . d_ctx / P)
 template <bool TANH>
 __global__ __launch_bounds__(256) void att_rowdot_kernel(const float* __restrict__ x, const float* __restrict__ add, long ld_add,
-                                                         const float* __restrict__ mul, long ld_mul, float scale, int P, int C,
+                                                         const float* __restrict__ mul, long ld_mul,
+                                                         const float* __restrict__ mul2, long ld_mul2, float scale, int P, int C,
                                                          int pchunk, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [C] add | [C] mul
     float* s_add = sm;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void att_rowdot_kernel(const float* __restrict
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c < C; c += 256) {
         if (TANH) s_add[c] = add[(long)b * ld_add + c];
-        s_mul[c] = mul[(long)b * ld_mul + c];
+        s_mul[c] = mul[(long)b * ld_mul + c] + (mul2 ? mul2[(long)b * ld_mul2 + c] : 0.0f);
     }
     __syncthreads();
     const int p0 = blockIdx.y * pchunk;
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(kAttWaves * 64) void att_bwd_channel_kernel(const f
                                                                          const float* __restrict__ w_att,
                                                                          const float* __restrict__ alpha,
                                                                          const float* __restrict__ d_alpha,
-                                                                         const float* __restrict__ d_ctx, long ld_dctx, int P, int C,
+                                                                         const float* __restrict__ d_ctx, long ld_dctx,
+                                                                         const float* __restrict__ d_ctx2, long ld_dctx2, int P, int C,
                                                                          float* __restrict__ d_ctx_enc, float* __restrict__ d_proj,
                                                                          float* __restrict__ d_watt_part, float* __restrict__ d_feats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [P4] d_s | [P4] alpha | [8] | [2][kAttWaves][64]
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(kAttWaves * 64) void att_bwd_channel_kernel(const f
             dw += ds * ha;
         }
         if (d_feats) {      // fine-tuning: context = mean_p alpha[p] feats[p]  =>  d feats[p,c] += alpha[p] * d_ctx[c] / P
-            const float dc = d_ctx[(long)b * ld_dctx + c] / (float)P;
+            const float dc = (d_ctx[(long)b * ld_dctx + c] + (d_ctx2 ? d_ctx2[(long)b * ld_dctx2 + c] : 0.0f)) / (float)P;
             float* dfe = d_feats + (long)b * P * C + c;
 #pragma unroll 4
             for (int p = wave; p < P; p += kAttWaves) dfe[(long)p * C] += s_al[p] * dc;
@@ -561,7 +563,7 @@ extern "C" int sat_attention_fwd(const float* ctx_enc, const float* feats, const
     hipStream_t s = (hipStream_t)stream;
     const int pch = att_pchunk(rows, P);
     hipLaunchKernelGGL(att_rowdot_kernel<true>, dim3(rows, sat_cdiv(P, pch)), dim3(256), lds1, s, ctx_enc, proj, (long)ld_proj, w_att,
-                       0L, 1.0f, P, C, pch, workspace);
+                       0L, (const float*)nullptr, 0L, 1.0f, P, C, pch, workspace);
     SAT_LAUNCH_CHECK();
     hipLaunchKernelGGL(att_context_kernel, dim3(rows, sat_cdiv(C, 64)), dim3(kAttWaves * 64), lds2, s, workspace, feats, P, C, alpha,
                        context, (long)ld_ctx);
@@ -570,11 +572,11 @@ extern "C" int sat_attention_fwd(const float* ctx_enc, const float* feats, const
 }
 
 extern "C" int sat_attention_bwd(const float* ctx_enc, const float* feats, const float* proj, int64_t ld_proj, const float* w_att,
-                                 const float* alpha, const float* d_ctx, int64_t ld_dctx, int rows, int P, int C,
-                                 float* d_ctx_enc, float* d_proj, float* d_watt_part, float* d_feats, float* workspace,
-                                 int64_t ws_bytes, sat_stream_t stream) {
+                                 const float* alpha, const float* d_ctx, int64_t ld_dctx, const float* d_ctx2, int64_t ld_dctx2,
+                                 int rows, int P, int C, float* d_ctx_enc, float* d_proj, float* d_watt_part, float* d_feats,
+                                 float* workspace, int64_t ws_bytes, sat_stream_t stream) {
     if (!ctx_enc || !feats || !proj || !w_att || !alpha || !d_ctx || !d_ctx_enc || !d_proj || !d_watt_part || rows < 1 || P < 1 ||
-        C < 4 || (C & 3) || ld_proj < C || ld_dctx < C)
+        C < 4 || (C & 3) || ld_proj < C || ld_dctx < C || (d_ctx2 && ld_dctx2 < C))
         return SAT_ERR_ARG;
     if (!workspace || ws_bytes < sat_attention_ws_bytes(rows, P)) return SAT_ERR_WORKSPACE;
     const size_t lds1 = (size_t)2 * C * sizeof(float);
@@ -583,10 +585,11 @@ extern "C" int sat_attention_bwd(const float* ctx_enc, const float* feats, const
     hipStream_t s = (hipStream_t)stream;
     const int pch = att_pchunk(rows, P);
     hipLaunchKernelGGL(att_rowdot_kernel<false>, dim3(rows, sat_cdiv(P, pch)), dim3(256), lds1, s, feats, (const float*)nullptr, 0L,
-                       d_ctx, (long)ld_dctx, 1.0f / (float)P, P, C, pch, workspace);
+                       d_ctx, (long)ld_dctx, d_ctx2, (long)ld_dctx2, 1.0f / (float)P, P, C, pch, workspace);
     SAT_LAUNCH_CHECK();
     hipLaunchKernelGGL(att_bwd_channel_kernel, dim3(rows, sat_cdiv(C, 64)), dim3(kAttWaves * 64), lds2, s, ctx_enc, proj, (long)ld_proj,
-                       w_att, alpha, workspace, d_ctx, (long)ld_dctx, P, C, d_ctx_enc, d_proj, d_watt_part, d_feats);
+                       w_att, alpha, workspace, d_ctx, (long)ld_dctx, d_ctx2, (long)ld_dctx2, P, C, d_ctx_enc, d_proj, d_watt_part,
+                       d_feats);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }

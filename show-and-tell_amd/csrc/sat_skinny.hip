@@ -170,7 +170,8 @@ __global__ __launch_bounds__(NWV * 64) void skinny_kernel(const SkinnyArgs p) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     accumulate_pair<WKM>(p.A, p.lda, p.W, p.ldw, p.K, p.M, rc0, wrow, wrow_ok, z * NWV + wave, NWV * p.nz, lane, acc);
-    if (p.A2) accumulate_pair<false>(p.A2, p.lda2, p.W2, p.ldw2, p.K2, p.M, rc0, wrow, wrow_ok, z * NWV + wave, NWV * p.nz, lane, acc);
+    // the second operand pair has the first one's weight layout (EPI_LSTM is only built with WKM = false)
+    if (p.A2) accumulate_pair<WKM>(p.A2, p.lda2, p.W2, p.ldw2, p.K2, p.M, rc0, wrow, wrow_ok, z * NWV + wave, NWV * p.nz, lane, acc);
 
     // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
@@ -390,18 +391,42 @@ extern "C" int64_t sat_skinny_gemm_ws_bytes(int M, int N, int K) {
 
 extern "C" int sat_sum_slabs_f32(const float* in, int nslab, int64_t slab_stride, int64_t n, float* out, sat_stream_t stream);
 
+static int skinny_store2(const float* A, long lda, const float* W, long ldw, int K, const float* A2, long lda2, const float* W2,
+                         long ldw2, int K2, int wkm, int M, int N, int nz, float* out, long ldo, long slab_stride,
+                         const float* bias, hipStream_t s) {
+    SkinnyArgs a = {};
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.K = K;
+    a.A2 = A2; a.lda2 = lda2; a.W2 = W2; a.ldw2 = ldw2; a.K2 = K2;
+    a.M = M; a.N = N; a.nz = nz;
+    a.out = out; a.ldo = ldo; a.slab_stride = slab_stride; a.bias = bias;
+    dim3 grid(sat_cdiv(N, 16), sat_cdiv(M, 64), nz);
+    if (wkm) hipLaunchKernelGGL((skinny_kernel<EPI_STORE, true>), grid, dim3(NWV * 64), 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<EPI_STORE, false>), grid, dim3(NWV * 64), 0, s, a);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+// out = A W (+ A2 W2) + bias: the optional second operand pair shares the output tile, so a sum of two products (dh_{t-1} through
+// the LSTMCell and through the attention projection, model2.py:58 / 74) is one launch
+extern "C" int sat_skinny_gemm2_f32(const float* A, int64_t lda, const float* W, int64_t ldw, int K, const float* A2, int64_t lda2,
+                                    const float* W2, int64_t ldw2, int K2, int w_kmajor, int M, int N, const float* bias,
+                                    float* out, int64_t ldo, float* workspace, int64_t ws_bytes, sat_stream_t stream) {
+    if (!A || !W || !out || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || ldo < N) return SAT_ERR_ARG;
+    if (!w_kmajor && (ldw & 3)) return SAT_ERR_ARG;
+    if (A2 && (!W2 || K2 < 4 || (K2 & 3) || (lda2 & 3) || (!w_kmajor && (ldw2 & 3)))) return SAT_ERR_ARG;
+    if (!A2) K2 = 0;
+    int nz = skinny_nz(M, N, K);
+    if (ldo != N || (((long)M * N) & 3)) nz = 1;             // the slab sum wants a dense, 16-byte-granular result
+    hipStream_t s = (hipStream_t)stream;
+    if (nz == 1) return skinny_store2(A, lda, W, ldw, K, A2, lda2, W2, ldw2, K2, w_kmajor, M, N, 1, out, ldo, 0, bias, s);
+    if (!workspace || ws_bytes < sat_skinny_gemm_ws_bytes(M, N, K)) return SAT_ERR_WORKSPACE;
+    SAT_TRY(skinny_store2(A, lda, W, ldw, K, A2, lda2, W2, ldw2, K2, w_kmajor, M, N, nz, workspace, N, (long)M * N, bias, s));
+    return sat_sum_slabs_f32(workspace, nz, (int64_t)M * N, (int64_t)M * N, out, stream);
+}
+
 extern "C" int sat_skinny_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, int w_kmajor, int M, int N, int K,
                                    const float* bias, float* out, int64_t ldo, float* workspace, int64_t ws_bytes,
                                    sat_stream_t stream) {
-    if (!A || !W || !out || M < 1 || N < 1 || K < 4 || (K & 3) || (lda & 3) || ldo < N) return SAT_ERR_ARG;
-    if (!w_kmajor && (ldw & 3)) return SAT_ERR_ARG;
-    const int nz = skinny_nz(M, N, K);
-    hipStream_t s = (hipStream_t)stream;
-    if (nz == 1) return sat_skinny_store(A, lda, W, ldw, w_kmajor, M, N, K, 1, out, ldo, 0, bias, s);
-    if (ldo != N || (((long)M * N) & 3)) {                   // the slab sum wants a dense, 16-byte-granular result
-        return sat_skinny_store(A, lda, W, ldw, w_kmajor, M, N, K, 1, out, ldo, 0, bias, s);
-    }
-    if (!workspace || ws_bytes < sat_skinny_gemm_ws_bytes(M, N, K)) return SAT_ERR_WORKSPACE;
-    SAT_TRY(sat_skinny_store(A, lda, W, ldw, w_kmajor, M, N, K, nz, workspace, N, (long)M * N, bias, s));
-    return sat_sum_slabs_f32(workspace, nz, (int64_t)M * N, (int64_t)M * N, out, stream);
+    return sat_skinny_gemm2_f32(A, lda, W, ldw, K, nullptr, 0, nullptr, 0, 0, w_kmajor, M, N, bias, out, ldo, workspace, ws_bytes,
+                                stream);
 }

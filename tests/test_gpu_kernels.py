@@ -821,3 +821,22 @@ def test_skinny_gemm_f32(M, N, K, wkm, bias):
     if need:
         assert lib.sat_skinny_gemm_f32(Ad.data_ptr(), K, Wd.data_ptr(), N if wkm else K, wkm, M, N, K, None, out.data_ptr(), N,
                                        None, 0, L.stream()) == 1002
+
+
+@pytest.mark.gpu
+def test_skinny_gemm2_sum_of_two_products():
+    """sat_skinny_gemm2_f32: out = A W + A2 W2 with K-major weights (dh_{t-1} through the LSTMCell and the attention projection)"""
+    lib = L.load()
+    g = torch.Generator().manual_seed(4)
+    M, N, K, K2 = 37, 1024, 4096, 512
+    A, W = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) * 0.03
+    A2, W2 = torch.randn(M, K2, generator=g), torch.randn(K2, N, generator=g) * 0.03
+    want = A.double() @ W.double() + A2.double() @ W2.double()
+    d = [t.cuda() for t in (A, W, A2, W2)]
+    out = torch.empty(M, N, device="cuda")
+    need = lib.sat_skinny_gemm_ws_bytes(M, N, K)
+    ws = torch.empty(max(need // 4, 1), device="cuda")
+    L.check(lib.sat_skinny_gemm2_f32(d[0].data_ptr(), K, d[1].data_ptr(), N, K, d[2].data_ptr(), K2, d[3].data_ptr(), N, K2, 1, M, N,
+                                     None, out.data_ptr(), N, ws.data_ptr(), need, L.stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-5, atol=5e-5)

@@ -25,9 +25,20 @@ opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e
 crit = torch.nn.CrossEntropyLoss()
 
 
-def step():
+images_b = torch.randn(B, 3, 224, 224, device="cuda")
+batches = [images, images_b]
+LOOKAHEAD = os.environ.get("SAT_LOOKAHEAD", "1") != "0"
+
+
+def step(i=0, last=True):
     model.zero_grad()
-    loss = crit(model(images, caps[:, :-1], l1), targets)
+    x = batches[i & 1]
+    # forward of THIS batch first consumes its (possibly prefetched) features; the NEXT batch's frozen VGG stack then starts on
+    # the side stream and runs under this batch's decoder forward / backward / Adam (ShowAttendTellModel.prefetch_features)
+    feats, fmean = model._encode(x)
+    if LOOKAHEAD and not last:
+        model.prefetch_features(batches[(i + 1) & 1])
+    loss = crit(model.decode(feats, fmean, caps[:, :-1], l1), targets)
     loss.backward()
     for p in opt.param_groups[0]["params"]:
         p.grad.data.clamp_(-0.1, 0.1)
@@ -35,13 +46,13 @@ def step():
     return loss
 
 
-for _ in range(3):
-    loss = step()
+for i in range(3):
+    loss = step(i, i == 2)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 n = 10
-for _ in range(n):
-    loss = step()
+for i in range(n):
+    loss = step(i, i == n - 1)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print("Show-Attend-Tell train step (%s conv stack, drop-in autograd path + torch CE/Adam): %.2f ms/step = %.0f img/s, loss %.4f"
