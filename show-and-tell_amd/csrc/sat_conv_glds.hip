@@ -945,8 +945,17 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
     if (hipMemsetD32Async((hipDeviceptr_t)scratch, 0x3f800000, kTuneTab, s) != hipSuccess ||
         hipMemsetAsync(scratch + kTuneTab, 0, kTuneTab * sizeof(float), s) != hipSuccess)
         return SAT_ERR_UNSUPPORTED;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SAT_ERR_UNSUPPORTED;
+    hipEvent_t e0, e1, e2;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess)
+        return SAT_ERR_UNSUPPORTED;
+    // SAT_TUNE_PAIRED=1: time every candidate as TWO copies in flight on two streams (the regime of TrainStep.prefetch_encoder,
+    // where two batches' stacks run next to each other): rewards tiles that leave room for a neighbour (LDS, CU count) and
+    // fewer staged bytes per flop rather than the shortest solo launch.  Tuning launches write the op's own output buffer
+    // with identical values from both copies and touch no statistics.
+    const char* paired_env = getenv("SAT_TUNE_PAIRED");
+    const bool paired = paired_env && paired_env[0] == '1';
+    hipStream_t s2 = nullptr;
+    if (paired && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return SAT_ERR_UNSUPPORTED;
     int rc = SAT_OK;
     for (int i = 0; i < n_ops && rc == SAT_OK; ++i) {
         sat_op* op = ops + i;
@@ -973,7 +982,15 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
             float tmin = 1e30f;
             for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
                 if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-                for (int r = 0; r < reps && rc == SAT_OK; ++r) rc = launch_variant(v, a, s);
+                if (paired && hipStreamWaitEvent(s2, e0, 0) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+                for (int r = 0; r < reps && rc == SAT_OK; ++r) {
+                    rc = launch_variant(v, a, s);
+                    if (paired && rc == SAT_OK) rc = launch_variant(v, a, s2);
+                }
+                if (paired && (hipEventRecord(e2, s2) != hipSuccess || hipStreamWaitEvent(s, e2, 0) != hipSuccess)) {
+                    rc = SAT_ERR_UNSUPPORTED;
+                    break;
+                }
                 if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
@@ -993,5 +1010,10 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    if (s2) {
+        (void)hipStreamSynchronize(s2);
+        (void)hipStreamDestroy(s2);
+    }
     return rc;
 }
