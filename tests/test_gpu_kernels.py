@@ -840,3 +840,46 @@ def test_skinny_gemm2_sum_of_two_products():
                                      None, out.data_ptr(), N, ws.data_ptr(), need, L.stream()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-5, atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_fixed_point_statistics_hold_for_small_magnitude_channels(lib):
+    """The conv's BatchNorm sums are 2^-22 fixed point per tile column (2.4e-7 absolute per tile sum).  Channels whose
+    activations are 1e-1 ... 1e-4 of the others: the normalised output and the running statistics still match float64 --
+    a channel small enough for the quantisation to show in its variance (var << eps = 1e-5) is dominated by eps in
+    rsqrt(var + eps), one above that has thousands of quanta per tile."""
+    N, H, W, Cin, Cout = 8, 28, 28, 64, 128
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(N, Cin, H, W, generator=g) + 0.2).bfloat16().float()
+    mag = torch.tensor([10.0 ** -(c % 5) for c in range(Cout)])
+    w = ((torch.randn(Cout, Cin, 1, 1, generator=g) / 8.0) * mag.view(-1, 1, 1, 1)).bfloat16().float()
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double()).permute(0, 2, 3, 1).reshape(-1, Cout)
+    M = ref.shape[0]
+    conv, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 0, stats=False)
+    acc = torch.zeros(2, 1, 2, Cout, dtype=torch.int64, device="cuda")
+    conv.stat_acc, conv.stat_shards = acc.data_ptr(), 1
+    gd, bd = cu(gamma), cu(beta)
+    rm, rv = cu(torch.zeros(Cout)), cu(torch.zeros(Cout))
+    y1 = torch.empty(M, Cout, device="cuda", dtype=torch.bfloat16)
+    act = L.SatOp()
+    act.kind, act.dtype = L.OP_BN_RELU, L.SAT_BF16
+    act.in0, act.out = keep[2].data_ptr(), y1.data_ptr()
+    act.stat_acc, act.gamma, act.beta, act.stat_shards = acc.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1
+    act.running_mean, act.running_var = rm.data_ptr(), rv.data_ptr()
+    act.count, act.momentum, act.eps = M, 1.0, 1e-5          # momentum 1: the running buffers receive the batch statistics
+    act.N, act.Hout, act.Wout, act.Cout = N, H, W, Cout
+    ops = (L.SatOp * 2)(conv, act)
+    L.check(lib.sat_run_ops_parity(ops, 2, 0, st()))
+    sync()
+    c_bf = keep[2].float().cpu().double()                    # what the kernel normalises: its own bf16 conv output
+    mean, var = ref.mean(0), ref.var(0, unbiased=False)
+    scale = gamma.double() / torch.sqrt(var + 1e-5)
+    want = (c_bf * scale + (beta.double() - mean * scale)).clamp(min=0)
+    err = (y1.float().cpu().double() - want).abs().max(0).values
+    assert err.max().item() < 3e-2, err                      # bf16 output rounding only, in every magnitude class
+    unb = var * M / (M - 1)
+    got_m, got_v = rm.cpu().double(), rv.cpu().double()
+    # mean: absolute error <= 1.2e-7 per tile sum / 128 rows; variance: relative to (var + eps), which is what the normalisation sees
+    assert (got_m - mean).abs().max().item() < 2e-6, (got_m - mean).abs().max()
+    assert (((got_v - unb).abs()) / (unb + 1e-5)).max().item() < 2e-3
