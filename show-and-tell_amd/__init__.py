@@ -8,6 +8,7 @@ from . import _lib  # noqa: F401
 from .models import (CaptionModel, Decoder, DecoderRNN, Encoder, EncoderCNN, ShowAndTell)  # noqa: F401
 from .attend import ShowAttendTellModel, VggFeatures  # noqa: F401
 from .input import DevicePrefetcher, collate_batch, collate_on_device  # noqa: F401
+from .optim import FusedClampAdam  # noqa: F401
 from .pack import PackInfo, pack_targets  # noqa: F401
 from .resnet import RESNET152, conv_flops  # noqa: F401
 from .trainer import (DataParallelStep, FlatParams, TrainStep, decode_shard, dp_shard, gather_decoded,  # noqa: F401

@@ -312,11 +312,12 @@ class _AttendFn(torch.autograd.Function):
         f2 = features.view(B * P, C)
         ctx_enc = torch.empty(B * P, C, device=dev)
         _gemm(lib, 0, 1, f2, C, m.image_att_w, C, ctx_enc, C, B * P, C, C)                      # model2.py:46
-        h0, c0 = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+        HSX = torch.empty(B + N, H, device=dev)            # [h_0 ; h of every packed row]: h_{t-1} of any row is one gather away
+        h0, c0 = HSX[:B], torch.empty(B, H, device=dev)
         _gemm(lib, 0, 0, fmean, C, m.init_hidden.weight, C, h0, H, B, H, C, m.init_hidden.bias)  # model2.py:67-71
         _gemm(lib, 0, 0, fmean, C, m.init_memory.weight, C, c0, H, B, H, C, m.init_memory.bias)
         c = c0.clone()
-        HS, PROJ = torch.empty(N, H, device=dev), torch.empty(N, C, device=dev)
+        HS, PROJ = HSX[B:], torch.empty(N, C, device=dev)
         X, GATES = torch.empty(N, Hin, device=dev), torch.empty(N, 4 * H, device=dev)
         CS, ALPHA = torch.empty(N, H, device=dev), torch.empty(N, P, device=dev)
         watt = m.weight_att.view(-1)
@@ -349,7 +350,7 @@ class _AttendFn(torch.autograd.Function):
         _gemm(lib, 0, 0, Z, E, m.classifier.weight, E, logits, ldl, N, V, E, m.classifier.bias)
         ctx.m, ctx.pi, ctx.captions = m, pi, captions
         ctx.tapes = dict(f2=f2, fmean=fmean, ctx_enc=ctx_enc, h0=h0, c0=c0, PROJ=PROJ, HS=HS, X=X, GATES=GATES, CS=CS, ALPHA=ALPHA,
-                         Zin=Zin, Wz=Wz, Z=Z, toks=toks)
+                         Zin=Zin, Wz=Wz, Z=Z, toks=toks, HSX=HSX)
         return logits if ldl == V else logits[:, :V]
 
     @staticmethod

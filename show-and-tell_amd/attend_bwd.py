@@ -82,10 +82,8 @@ def attend_backward(m, pi, captions, tp, dlogits, want_dfeat=False):
     L.check(lib.sat_rows_copy(DX.data_ptr(), Hin, None, 0, N, N, E, DEMB.data_ptr(), E, st), "sat_rows_copy")
     # ---- batched weight gradients of the recurrence ----
     HPREV = torch.empty(N, H, device=dev)              # h_{t-1} per packed row: h0 for step 0, HS rows of step t-1 after
-    L.check(lib.sat_rows_copy(h0.data_ptr(), H, None, 0, B, pi.batch_sizes[0], H, HPREV.data_ptr(), H, st), "sat_rows_copy")
-    for t in range(1, T):
-        L.check(lib.sat_rows_copy(_rows(HS, pi.prefix[t - 1]), H, None, 0, pi.batch_sizes[t], pi.batch_sizes[t], H,
-                                  _rows(HPREV, pi.prefix[t]), H, st), "sat_rows_copy")
+    L.check(lib.sat_rows_copy(tp["HSX"].data_ptr(), H, pi.prev_rows().data_ptr(), 1, B + N, N, H, HPREV.data_ptr(), H, st),
+            "sat_rows_copy")
     g["lstmcell.weight_ih"] = torch.empty(4 * H, Hin, device=dev)
     _gemm(lib, 2, 1, DG, 4 * H, X, Hin, g["lstmcell.weight_ih"], Hin, 4 * H, Hin, N)
     g["lstmcell.weight_hh"] = torch.empty(4 * H, H, device=dev)

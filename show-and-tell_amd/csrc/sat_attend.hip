@@ -311,21 +311,34 @@ __global__ void pack_tokens_kernel(const int64_t* __restrict__ captions, long ca
 // the FIRST row carrying an id sums every row with that id in row order; the table is zeroed by the launcher.
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int N,
                                                            int E, int V, float* __restrict__ table) {
-    extern __shared__ __attribute__((aligned(16))) int tok[];
+    extern __shared__ __attribute__((aligned(16))) int tok[];          // [N] ids | [ceil(N/32)] match bits of the later rows
     const int row = blockIdx.x;
+    const int nw = (N + 31) >> 5;
+    unsigned* bits = (unsigned*)(tok + N);
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         const long x = ids[i];
         tok[i] = (int)(x < 0 ? 0 : (x >= V ? V - 1 : x));            // memory safety only (sat_validate_ids reports bad ids)
     }
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) bits[i] = 0u;
     __syncthreads();
     const int v = tok[row];
     int dup = 0;
     for (int i = threadIdx.x; i < row; i += blockDim.x) dup |= (tok[i] == v);
     if (__syncthreads_or(dup)) return;
+    // later rows with the same id, as a bit set (built in any order, walked in row order: the sum's order is fixed)
+    for (int i = row + 1 + threadIdx.x; i < N; i += blockDim.x)
+        if (tok[i] == v) atomicOr(&bits[i >> 5], 1u << (i & 31));
+    __syncthreads();
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
         float acc = rows[(long)row * E + e];
-        for (int i = row + 1; i < N; ++i)
-            if (tok[i] == v) acc += rows[(long)i * E + e];
+        for (int w = (row + 1) >> 5; w < nw; ++w) {
+            unsigned m = bits[w];
+            while (m) {
+                const int i = (w << 5) + __ffs(m) - 1;
+                m &= m - 1;
+                acc += rows[(long)i * E + e];
+            }
+        }
         table[(long)v * E + e] = acc;
     }
 }
@@ -483,7 +496,7 @@ extern "C" int sat_pack_tokens(const int64_t* captions, int64_t cap_stride, cons
 
 extern "C" int sat_scatter_rows_add(const float* rows, const int64_t* ids, int N, int E, int V, float* table, sat_stream_t stream) {
     if (!rows || !ids || !table || N < 1 || E < 1 || V < 1) return SAT_ERR_ARG;
-    const size_t dyn = (size_t)N * 4;
+    const size_t dyn = ((size_t)N + (size_t)((N + 31) / 32)) * 4;
     if (dyn > 150 * 1024) return SAT_ERR_UNSUPPORTED;
     if (dyn > 48 * 1024) {
         hipError_t ea = hipFuncSetAttribute((const void*)scatter_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);

@@ -27,6 +27,17 @@ class PackInfo:
         self.bs_c = (C.c_int32 * self.T)(*self.batch_sizes)
         self.prefix_dev = torch.tensor(self.prefix, dtype=torch.int32, device=device)
 
+    def prev_rows(self):
+        """int64 [N] on the device: for packed row (t, b) the row of the table [h_0 (B rows) ; packed h (N rows)] that holds
+        h_{t-1} of sequence b (b for t = 0, B + prefix[t-1] + b after) -- one gather builds `h_prev` for every packed row."""
+        idx = getattr(self, "_prev_rows", None)
+        if idx is None:
+            rows = list(range(self.batch_sizes[0]))
+            for t in range(1, self.T):
+                rows += [self.B + self.prefix[t - 1] + b for b in range(self.batch_sizes[t])]
+            idx = self._prev_rows = torch.tensor(rows, dtype=torch.int64, device=self.prefix_dev.device)
+        return idx
+
     @classmethod
     def get(cls, lengths, device):
         key = (tuple(int(l) for l in lengths), str(device))

@@ -328,3 +328,47 @@ def test_prefetched_features_are_the_features():
     got_other = m(xs[0], caps, lengths).detach().clone()       # not the prefetched tensor: computed for xs[0]
     torch.cuda.synchronize()
     assert torch.equal(got0, want[0]) and torch.equal(got_other, want[0])
+
+
+@pytest.mark.parametrize("model_zero_grad", [False, True])
+def test_fused_clamp_adam_equals_torch_clamp_plus_adam(model_zero_grad):
+    """sat.FusedClampAdam = clip_gradient + optim.Adam (train.py:88-91, 145-146) in one launch: same parameters after 3 steps of
+    the Show-Attend-Tell drop-in loop as torch's clamp_ + Adam, with `opt.zero_grad()` (gradients accumulate into the flat
+    buffer) and with train.py:137's `model.zero_grad()` (fresh gradient tensors, copied in); state dict in torch.optim.Adam layout."""
+    def build():
+        torch.manual_seed(8)
+        return sat.ShowAttendTellModel(96, 64, 50, 32, None, feature_size=(16, 64), compute_dtype="f32", vgg_cfg=SMALL_VGG).cuda()
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(4, 3, 32, 32, generator=g).cuda()
+    caps = torch.randint(1, 50, (4, 7), generator=g).cuda()
+    lengths = [7, 6, 4, 3]
+    targets, l1 = sat.pack_targets(caps, lengths)
+    crit = torch.nn.CrossEntropyLoss()
+    ma, mb = build(), build()
+    oa = torch.optim.Adam([p for p in ma.parameters() if p.requires_grad], lr=1e-3)
+    ob = sat.FusedClampAdam([p for p in mb.parameters() if p.requires_grad], lr=1e-3, clip=0.1)
+    for _ in range(3):
+        ma.zero_grad()
+        crit(ma(x, caps[:, :-1], l1), targets).backward()
+        for p in oa.param_groups[0]["params"]:
+            p.grad.data.clamp_(-0.1, 0.1)
+        oa.step()
+        if model_zero_grad:
+            mb.zero_grad()
+        else:
+            ob.zero_grad()
+        crit(mb(x, caps[:, :-1], l1), targets).backward()
+        ob.step()
+    torch.cuda.synchronize()
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert (pa - pb).abs().max().item() <= 2e-6, n
+    sd = ob.state_dict()
+    oc = torch.optim.Adam([p for p in build().parameters() if p.requires_grad], lr=1e-3)
+    oc.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})      # torch accepts the layout
+    ref = oa.state_dict()["state"]
+    for i, st in sd["state"].items():
+        assert (st["exp_avg"].cpu() - ref[i]["exp_avg"].cpu()).abs().max().item() <= 1e-7
+        assert float(st["step"]) == 3.0
+    ob2 = sat.FusedClampAdam([p for p in build().parameters() if p.requires_grad], lr=5e-4, clip=0.1)
+    ob2.load_state_dict(sd)
+    assert ob2.step_count == 3 and ob2.param_groups[0]["lr"] == 1e-3 and torch.equal(ob2.exp_avg, ob.exp_avg)

@@ -21,7 +21,11 @@ caps = torch.randint(4, V, (B, T), device="cuda")
 caps[:, 0], caps[:, -1] = 1, 2
 lengths = [T] * B
 targets, l1 = sat.pack_targets(caps, lengths)
-opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+FUSED_OPT = os.environ.get("SAT_FUSED_OPT", "1") != "0"     # clip_gradient + Adam as one launch (sat.FusedClampAdam) vs torch
+if FUSED_OPT:
+    opt = sat.FusedClampAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, clip=0.1)
+else:
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
 crit = torch.nn.CrossEntropyLoss()
 
 
@@ -31,7 +35,10 @@ LOOKAHEAD = os.environ.get("SAT_LOOKAHEAD", "1") != "0"
 
 
 def step(i=0, last=True):
-    model.zero_grad()
+    if FUSED_OPT:
+        opt.zero_grad()
+    else:
+        model.zero_grad()
     x = batches[i & 1]
     # forward of THIS batch first consumes its (possibly prefetched) features; the NEXT batch's frozen VGG stack then starts on
     # the side stream and runs under this batch's decoder forward / backward / Adam (ShowAttendTellModel.prefetch_features)
@@ -40,8 +47,9 @@ def step(i=0, last=True):
         model.prefetch_features(batches[(i + 1) & 1])
     loss = crit(model.decode(feats, fmean, caps[:, :-1], l1), targets)
     loss.backward()
-    for p in opt.param_groups[0]["params"]:
-        p.grad.data.clamp_(-0.1, 0.1)
+    if not FUSED_OPT:
+        for p in opt.param_groups[0]["params"]:
+            p.grad.data.clamp_(-0.1, 0.1)
     opt.step()
     return loss
 
@@ -55,8 +63,8 @@ for i in range(n):
     loss = step(i, i == n - 1)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print("Show-Attend-Tell train step (%s conv stack, drop-in autograd path + torch CE/Adam): %.2f ms/step = %.0f img/s, loss %.4f"
-      % (dtype, dt * 1e3, B / dt, loss.item()))
+print("Show-Attend-Tell train step (%s conv stack, drop-in autograd path + torch CE, %s): %.2f ms/step = %.0f img/s, loss %.4f"
+      % (dtype, "FusedClampAdam" if FUSED_OPT else "torch clamp + Adam", dt * 1e3, B / dt, loss.item()))
 with torch.no_grad():
     feats, fmean = model._encode(images)
     torch.cuda.synchronize()
