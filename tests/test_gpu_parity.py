@@ -82,6 +82,29 @@ def test_fused_trainstep_three_adam_steps_match_reference(golden_dir):
                                            atol=2e-6, err_msg="%s after %d" % (k, it + 1))
 
 
+def test_dropin_loop_with_fused_clamp_adam_matches_reference_goldens(golden_dir):
+    """drop-in path (train.py:134-146 as written: forward, torch CE, loss.backward()) with `sat.FusedClampAdam` standing in for
+    clip_gradient + optim.Adam.step(): losses and parameters after 1 and 3 steps vs the reference-generated goldens"""
+    g = load(golden_dir, "G1_dec_fwd_bwd_small.npz")
+    dec, params, (E, H, V, Lh, B, T) = golden_setup(g)
+    opt = sat.FusedClampAdam(dec.parameters(), lr=1e-3, clip=0.1)
+    feats = torch.from_numpy(g["features"]).cuda()
+    caps = torch.from_numpy(g["captions"]).cuda()
+    lengths = [int(x) for x in g["lengths"]]
+    targets, l1 = sat.pack_targets(caps, lengths)
+    crit = torch.nn.CrossEntropyLoss()
+    for it in range(3):
+        dec.zero_grad()                                                # train.py:137 (drops the flat views: step() copies in)
+        loss = crit(dec(feats, caps[:, :-1], l1), targets)
+        assert abs(loss.item() - float(g["losses"][it])) < 1e-4
+        loss.backward()
+        opt.step()
+        if it + 1 in (1, 3):
+            for k, p in dec.named_parameters():
+                np.testing.assert_allclose(p.detach().cpu().numpy(), g["param_after%d.%s" % (it + 1, k)], rtol=0,
+                                           atol=2e-6, err_msg="%s after %d" % (k, it + 1))
+
+
 @pytest.mark.parametrize("name", ["G2_dec_varlen_small.npz", "G5_dec_L2.npz"])
 def test_fused_trainstep_grads_varlen_and_two_layers(golden_dir, name):
     g = load(golden_dir, name)
