@@ -98,59 +98,27 @@ class TrainStep:
         self.buckets = self.flat.buckets
         self.flat_grad = self.flat.grads
         self._bufs = {}
-        # encoder look-ahead (see prefetch_encoder): one side stream + one deferred-statistics program per batch in flight
-        self._enc_streams = []
-        self._inflight = []        # [(images tensor, instance, done event, program)], oldest first
 
     # -- encoder look-ahead ---------------------------------------------------------------------------
-    LOOKAHEAD_DEPTH = 2            # measured on MI355X at batch 64: 5.82 ms per stack alone, 4.43 with two in flight, 4.96 with three
-
     def prefetch_encoder(self, images):
-        """Start the FROZEN conv stack (models.py:14-15, 25-27: `requires_grad_(False)` + `no_grad`) of a LATER batch on a
-        side stream.  Its pooled features depend on the images and the frozen weights only, not on the optimizer steps in
-        between, so computing them early changes nothing but the schedule: up to LOOKAHEAD_DEPTH stacks run next to each
-        other (one's HBM-bound BatchNorm passes and under-filled launches under the other's convs) and under the current
-        batch's head / decoder / backward / Adam.  Each batch keeps its own BatchNorm batch statistics (separate program
-        instances); the model's running statistics are updated when the batch is consumed, i.e. in batch order.
-        `step(images, ...)` / `forward_backward` of the SAME tensor object later picks the result up."""
-        if images is None or images.dim() != 4 or any(e[0] is images for e in self._inflight):
-            return False
-        if len(self._inflight) >= self.LOOKAHEAD_DEPTH:
-            return False
-        enc = self.model.encoder
-        busy = {e[1] for e in self._inflight}
-        inst = next(i for i in range(self.LOOKAHEAD_DEPTH) if i not in busy)
-        while len(self._enc_streams) <= inst:
-            self._enc_streams.append(torch.cuda.Stream(device=images.device))
-        stream = self._enc_streams[inst]
-        stream.wait_stream(torch.cuda.current_stream(images.device))   # the images, and this instance's previous consumer
-        with torch.cuda.stream(stream), torch.no_grad():
-            prog = enc._program(images, instance=inst)
-            prog.run(images)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-        self._inflight.append((images, inst, ev, prog))
-        return True
+        """Start the frozen conv stack of a LATER batch on a side stream (`EncoderCNN.prefetch`: up to two batches' stacks in
+        flight next to each other and under this batch's decoder work; bitwise identical results)."""
+        return self.model.encoder.prefetch(images)
 
     def _encoder_pooled(self, images, out):
         """pooled features [B, F] of `images` into `out` (a buffer this step owns): from the look-ahead if this tensor was
         prefetched, computed now otherwise."""
         enc = self.model.encoder
-        for k, (im, inst, ev, prog) in enumerate(self._inflight):
-            if im is images:
-                del self._inflight[k]
-                torch.cuda.current_stream(images.device).wait_event(ev)
-                out.copy_(prog.pooled)
-                prog.apply_running_stats()          # batch order = consumption order
-                return out
+        prog = enc._take_prefetched(images)
+        if prog is not None:
+            out.copy_(prog.pooled)
+            prog.apply_running_stats()          # batch order = consumption order
+            return out
         out.copy_(enc._pooled_raw(images))
         return out
 
     def drop_lookahead(self):
-        """Forget batches in flight (their results are discarded; the model's running statistics never see them)."""
-        for e in self._inflight:
-            e[2].synchronize()
-        self._inflight = []
+        self.model.encoder.drop_lookahead()
 
     # -- engine interface used by DataParallelStep ----------------------------------------------------
     def forward_backward(self, batch, inv_denom, on_bucket_ready=None, next_images=None):

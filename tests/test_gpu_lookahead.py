@@ -55,3 +55,28 @@ def test_lookahead_of_a_different_tensor_is_discarded():
     ts2.step(x0, caps, lengths)
     want = ts2.step(x2, caps, lengths)
     assert torch.equal(got.cpu(), want.cpu())
+
+
+def test_dropin_encoder_prefetch_is_bitwise_identical():
+    """EncoderCNN.prefetch on the drop-in path (`features = encoder(images)`, models.py:25-29): features, head gradients and every
+    running statistic equal the un-prefetched sequence bit for bit, in train mode, with two batches in flight"""
+    def run(prefetch):
+        torch.manual_seed(9)
+        enc = sat.EncoderCNN(32).cuda().train()
+        g = torch.Generator().manual_seed(4)
+        xs = [torch.rand(6, 3, 64, 64, generator=g).cuda() for _ in range(4)]
+        outs = []
+        for i, x in enumerate(xs):
+            if prefetch:
+                for j in (i + 1, i + 2):
+                    if j < len(xs):
+                        enc.prefetch(xs[j])
+            f = enc(x)
+            f.sum().backward()
+            outs.append(f.detach().clone())
+        torch.cuda.synchronize()
+        rs = torch.cat([torch.cat([bn.running_mean, bn.running_var]) for bn in enc.resnet.bns()])
+        return torch.stack(outs).cpu(), enc.resnet.fc.weight.grad.clone().cpu(), rs.cpu(), enc.bn.running_var.clone().cpu()
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
