@@ -104,10 +104,21 @@ class EncoderCNN(nn.Module):
         self.compute_dtype = compute_dtype
         self._programs = {}
         self._streams, self._inflight = [], []      # look-ahead (prefetch): side streams, [(images, instance, event, program)]
-        self.register_load_state_dict_post_hook(lambda m, k: m._programs.clear())
+        self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
         # `encoder.resnet.load_state_dict(torchvision_sd)` -- the natural way to load the pretrained ResNet-152 the
         # reference uses (models.py:13) -- does not fire the parent's hook: hook the stack too
-        self.resnet.register_load_state_dict_post_hook(lambda m, k: self._programs.clear())
+        self.resnet.register_load_state_dict_post_hook(lambda m, k: self._invalidate())
+
+    def _invalidate(self):
+        """cached op programs AND batches in flight belong to the old weights / device / mode"""
+        self._programs.clear()
+        if self._inflight:
+            self.drop_lookahead()
+
+    def train(self, mode=True):
+        if bool(mode) != self.training and getattr(self, "_inflight", None):
+            self.drop_lookahead()           # a stack prefetched with batch statistics must not feed an eval-mode forward
+        return super().train(mode)
 
     def init_weights(self):
         """models.py:20-23."""
@@ -115,7 +126,7 @@ class EncoderCNN(nn.Module):
         self.resnet.fc.bias.data.fill_(0)
 
     def _apply(self, fn, *a, **k):
-        self._programs.clear()      # device / dtype moves invalidate cached device pointers
+        self._invalidate()          # device / dtype moves invalidate cached device pointers
         return super()._apply(fn, *a, **k)
 
     def _program(self, images, instance=None):
@@ -186,7 +197,7 @@ class EncoderCNN(nn.Module):
     def refresh_weights(self):
         """Drop the cached op programs (and their kernel-layout weight copies); needed only after writing conv weights
         through `.data`, which no version counter sees."""
-        self._programs.clear()
+        self._invalidate()
 
     def _pooled_raw(self, images):
         """The program-owned pooled buffer (overwritten by the next forward of the same shape): internal use within

@@ -80,3 +80,22 @@ def test_dropin_encoder_prefetch_is_bitwise_identical():
     a, b = run(False), run(True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_mode_or_weight_change_drops_batches_in_flight():
+    torch.manual_seed(9)
+    enc = sat.EncoderCNN(32).cuda().train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(4, 3, 64, 64, generator=g).cuda()
+    assert enc.prefetch(x) and not enc.prefetch(x)          # the same tensor is not started twice
+    enc.eval()                                              # batch-statistics features must not feed an eval forward
+    assert not enc._inflight
+    with torch.no_grad():
+        want = enc(x).clone()
+        enc.train(); enc.prefetch(x); enc.eval()
+        assert torch.equal(enc(x), want)
+    enc.train()
+    assert enc.prefetch(x)
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)                                 # new weights: the stack in flight belongs to the old ones
+    assert not enc._inflight and not enc._programs
