@@ -99,3 +99,22 @@ def test_mode_or_weight_change_drops_batches_in_flight():
     sd = {k: v.clone() for k, v in enc.state_dict().items()}
     enc.load_state_dict(sd)                                 # new weights: the stack in flight belongs to the old ones
     assert not enc._inflight and not enc._programs
+
+
+def test_eval_mode_decode_with_prefetch_gives_the_same_ids():
+    """eval.py:93-99 as a loop over batches with the next batches' stacks prefetched: greedy ids identical"""
+    torch.manual_seed(5)
+    model = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().eval()
+    g = torch.Generator().manual_seed(12)
+    xs = [torch.rand(4, 3, 64, 64, generator=g).cuda() for _ in range(3)]
+    with torch.no_grad():
+        want = [model.sample(x).clone() for x in xs]
+        got = []
+        for i, x in enumerate(xs):
+            for j in (i + 1, i + 2):
+                if j < len(xs):
+                    model.prefetch(xs[j])
+            got.append(model.sample(x).clone())
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)

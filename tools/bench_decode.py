@@ -47,6 +47,29 @@ def main():
     out["beam5_decode_ms"] = round(t_beam * 1e3, 3)
     out["greedy_captions_per_s"] = round(a.batch / (t_enc + t_greedy), 1)
     out["beam5_captions_per_s"] = round(a.batch / (t_enc + t_beam), 1)
+    # end to end with the encoder look-ahead (EncoderCNN.prefetch works in eval mode too: eval.py:93-99 is a loop over batches):
+    # the conv stacks of the next two batches run on side streams next to each other and under this batch's decode
+    batches = [images] + [torch.randn(a.batch, 3, 224, 224, device="cuda") for _ in range(2)]
+
+    def pipeline(n, beam):
+        ids = None
+        for i in range(n):
+            for j in (i + 1, i + 2):
+                if j < n:
+                    model.prefetch(batches[j % 3])
+            f = model.encoder(batches[i % 3])
+            ids = model.decoder.sample_beam(f, 5, end_id=2) if beam else model.decoder.sample(f)
+        return ids
+
+    with torch.no_grad():
+        for beam, key in ((False, "greedy"), (True, "beam5")):
+            pipeline(4, beam)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = max(a.iters, 12)
+            pipeline(n, beam)
+            torch.cuda.synchronize()
+            out[key + "_captions_per_s_lookahead"] = round(a.batch * n / (time.perf_counter() - t0), 1)
     if not a.no_cpu:
         sys.path.insert(0, ROOT)
         from oracle import decoder as OD          # checker / baseline only
