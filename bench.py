@@ -263,6 +263,22 @@ def main():
             with open(TRAFFIC_FILE) as f:
                 out["roofline"]["traffic"] = round(json.load(f)["hbm_bytes_per_launch_corrected"])
                 out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % os.path.relpath(TRAFFIC_FILE, ROOT)
+        if world == 1 and args.lookahead and not args.no_f32_mode:
+            # the same K steps with strictly sequential steps (what --no-lookahead times), for comparison in the same process
+            def seq_steps(n):
+                o = None
+                for i in range(n):
+                    o = dp.step((batches[i % 3], caps, lengths), global_tokens)
+                return o
+            seq_steps(2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            seq_steps(args.steps)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            out["sequential_schedule"] = {"value": round(CFG["batch"] * args.steps / dts, 1), "unit": "images/sec",
+                                          "ms_per_step": round(dts / args.steps * 1e3, 3),
+                                          "note": "same engine, no look-ahead: batch i+1's conv stack starts after batch i's optimizer step"}
         if world == 1 and not args.no_f32_mode:
             del dp, ts, model
             torch.cuda.empty_cache()
