@@ -132,7 +132,8 @@ def cpu_baseline(torch, seed):
     torch.set_num_threads(default_threads)
     return {"value": B * n / dt, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": "CPU oracle (oracle/train_step.py full_step, torch-CPU fp32), batch %d of the same shapes, %d timed "
-                      "steps at the best of {8,16,32,%d} torch threads (probed at batch %d)" % (B, n, default_threads, pb)}
+                      "steps at the best of {8,16,32,%d} torch threads (probed at batch %d, where one step ran at %.1f images/sec)"
+                      % (B, n, default_threads, pb, best[0])}
 
 
 def f32_mode_rate(torch, sat, dev, images, caps, lengths, steps=4):
