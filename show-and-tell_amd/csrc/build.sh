@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libsat_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+FLAGS="${SAT_EXTRA_FLAGS} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 pids=()
 for f in sat_gemm sat_conv_glds sat_lstm_persist sat_skinny sat_elementwise sat_attend sat_beam sat_host; do

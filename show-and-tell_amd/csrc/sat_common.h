@@ -31,6 +31,15 @@ static inline int sat_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 __device__ __forceinline__ float sat_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float sat_tanh(float x) { return tanhf(x); }
 
+// 16-byte global store, write-through to memory at system scope (sc0 sc1).  For a kernel's bulk OUTPUT that the NEXT launch reads:
+// every XCD has its own L2 and a launch ends with a write-back of the dirty lines its workgroups left there; lines that went
+// through already shorten that tail (conv output tiles: 19.8 -> 18.7 us for the 25.7 MB of a layer-3 conv3, -2 % on the step).
+__device__ __forceinline__ void store16_wt(void* dst, u32x4 v) {
+    // s_nop: a VMEM store of more than 64 bits needs wait states before its data VGPRs may be overwritten; the compiler's hazard
+    // recognizer does not look inside inline asm
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 }
                 *(bf16x8*)(p.C + (long)grow * p.ldc + gcol) = o;
             } else {
-                *(u32x4*)(p.C + (long)grow * p.ldc + gcol) = *(const u32x4*)(smem + row * CROW + cc * 16);
+                store16_wt(p.C + (long)grow * p.ldc + gcol, *(const u32x4*)(smem + row * CROW + cc * 16));
             }
         }
     }

@@ -54,7 +54,7 @@ template <> __device__ __forceinline__ void store_chunk<bf16_t>(bf16_t* p, const
     bf16x8 x;
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = (bf16_t)v[i];
-    *(bf16x8*)p = x;
+    store16_wt(p, __builtin_bit_cast(u32x4, x));     // bulk activations the next launch reads: write-through (sat_common.h)
 }
 
 // ------------------------------------------------------------------------------------------------------
