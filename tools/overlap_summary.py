@@ -30,8 +30,9 @@ def main():
     if len(adam) < 12:
         raise SystemExit("need a trace with at least 12 training steps")
     # steady state: skip the warm-up steps + the timed region's pipeline fill at the front and the drain at the back
-    a0, a1 = adam[5], adam[-4]
-    nsteps = len(adam) - 10
+    i0, i1 = 5, len(adam) - 4
+    a0, a1 = adam[i0], adam[i1]
+    nsteps = i1 - i0
     t0, t1 = a0['e'], a1['e']
     win = [r for r in rows if r['s'] >= t0 and r['e'] <= t1]
     wall = (t1 - t0) / 1e6 / nsteps
