@@ -175,17 +175,18 @@ class EncoderCNN(nn.Module):
             prog.run(images)
             ev = torch.cuda.Event()
             ev.record(stream)
-        self._inflight.append((images, inst, ev, prog))
+        self._inflight.append((images, inst, ev, prog, weights_signature(self.resnet)))
         return True
 
     def _take_prefetched(self, images):
         """The finished program instance of a prefetched `images` (the current stream now waits for it), or None.  The caller
         reads `prog.pooled` and then calls `prog.apply_running_stats()` -- both on the current stream."""
-        for k, (im, inst, ev, prog) in enumerate(self._inflight):
+        for k, (im, inst, ev, prog, sig) in enumerate(self._inflight):
             if im is images:
                 del self._inflight[k]
                 torch.cuda.current_stream(images.device).wait_event(ev)
-                return prog
+                # conv weights rewritten since (version counters): the stack in flight used the old ones -> recompute
+                return prog if sig == weights_signature(self.resnet) else None
         return None
 
     def drop_lookahead(self):

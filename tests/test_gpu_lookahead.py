@@ -118,3 +118,16 @@ def test_eval_mode_decode_with_prefetch_gives_the_same_ids():
     torch.cuda.synchronize()
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+
+
+def test_prefetched_stack_is_recomputed_after_an_in_place_weight_write():
+    torch.manual_seed(9)
+    enc = sat.EncoderCNN(32).cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(4, 3, 64, 64, generator=g).cuda()
+    with torch.no_grad():
+        assert enc.prefetch(x)
+        enc.resnet.conv1.weight.mul_(0.5)               # version counter moves: the stack in flight used the old weights
+        got = enc(x).clone()
+        want = enc(x).clone()                           # nothing in flight: computed with the current weights
+    assert torch.equal(got, want)
