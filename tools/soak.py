@@ -21,7 +21,8 @@ for i in range(8):
 mem0 = None
 t0 = time.time()
 for it in range(n):
-    loss = ts.step(*batches[it % 8], lr=sat.lr_for_epoch(1 + it // 100))
+    nxt = [batches[j % 8][0] for j in (it + 1, it + 2) if j < n] if os.environ.get("SAT_LOOKAHEAD", "1") != "0" else None
+    loss = ts.step(*batches[it % 8], lr=sat.lr_for_epoch(1 + it // 100), next_images=nxt or None)
     if it % 50 == 49 or it == n - 1:
         torch.cuda.synchronize()
         m = torch.cuda.memory_allocated() / 2**20
@@ -33,4 +34,5 @@ for it in range(n):
 assert torch.cuda.memory_reserved() / 2**20 <= mem0 * 1.05 + 64, "memory grew"
 for name, p in model.named_parameters():
     assert torch.isfinite(p).all(), name
+ts.check_ids()
 print("soak ok")
