@@ -13,6 +13,10 @@ reference holds no fixture for this half.  What is restated here is the publishe
 (torchvision "v1.5" bottleneck: stride on the 3x3 conv; stages [3,8,36,3]; expansion 4) using
 torch-CPU fp32 conv2d/batch-norm arithmetic with seeded weights.  State-dict key names are
 torchvision's, prefixed as the reference's module tree would (`resnet.`, `bn.`).
+Cross-check (not a pin): `tests/test_oracle_encoder_crosscheck.py` copies these parameters by name into
+`transformers.ResNetModel` configured as ResNet-152 -- an independent implementation of the same network, the one
+HF's conversion loads torchvision's checkpoint into -- and gets the same stem, stage outputs, pooled features and
+running-buffer updates in eval and train mode, and the same 58,143,808-parameter inventory.
 """
 import math
 
