@@ -128,9 +128,11 @@ def full_worker(rank, world, port, out, backend):
     model = full_model(sat, ep, eb, dp, dev)
     step = sat.DataParallelStep(sat.TrainStep(model))
     losses = []
-    for _ in range(2):
-        im, c, ln, tokens = sat.dp_shard(images.to(dev), caps.to(dev), lengths, rank, world)
-        losses.append(float(step.step((im, c, ln), tokens).item()))
+    shards = [sat.dp_shard(images.to(dev), caps.to(dev), lengths, rank, world) for _ in range(2)]
+    for i, (im, c, ln, tokens) in enumerate(shards):
+        # the second step's conv stack runs ahead on a side stream, under the first step's decoder work and all-reduces
+        nxt = shards[i + 1][0] if i + 1 < len(shards) else None
+        losses.append(float(step.step((im, c, ln), tokens, next_images=nxt).item()))
     torch.cuda.synchronize()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     torch.save({"sd": sd, "losses": losses}, out + ".%d" % rank)
