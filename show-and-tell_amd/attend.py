@@ -442,7 +442,8 @@ class ShowAttendTellModel(nn.Module):
         if self._pf is not None and self._pf[0] is images:
             return False
         if self._pf_stream is None:
-            self._pf_stream = torch.cuda.Stream(device=images.device, priority=int(os.environ.get("SAT_PF_PRIORITY", "0")))
+            from .models import lookahead_stream
+            self._pf_stream = lookahead_stream(images.device, 0)
         main = torch.cuda.current_stream(images.device)
         self._pf_stream.wait_stream(main)
         with torch.cuda.stream(self._pf_stream), torch.no_grad():

@@ -89,6 +89,20 @@ class _BN1d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
 
 
+_LOOKAHEAD_STREAMS = {}
+
+
+def lookahead_stream(device, i):
+    """Side stream i of `device` for look-ahead work, ONE set per process: HIP multiplexes streams onto a few hardware queues
+    (4 by default), so per-model streams end up sharing a queue with the main stream from the second model on -- measured: the
+    second model of a process lost the whole look-ahead gain (12.0 k -> 9.8 k img/s) until the streams became process-wide."""
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), i)
+    st = _LOOKAHEAD_STREAMS.get(key)
+    if st is None:
+        st = _LOOKAHEAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class EncoderCNN(nn.Module):
     """models.py:9-29.  `arch`/`compute_dtype` are build extensions (defaults = the reference: ResNet-152).
     compute_dtype: 'bf16' (MFMA bf16, f32 accumulate; throughput) or 'f32' (exact-f32 MFMA; parity)."""
@@ -103,7 +117,7 @@ class EncoderCNN(nn.Module):
         self.bn = _BN1d(embed_size)                         # models.py:17
         self.compute_dtype = compute_dtype
         self._programs = {}
-        self._streams, self._inflight = [], []      # look-ahead (prefetch): side streams, [(images, instance, event, program)]
+        self._inflight = []      # look-ahead (prefetch): [(images, instance, event, program, weights signature)]
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
         # `encoder.resnet.load_state_dict(torchvision_sd)` -- the natural way to load the pretrained ResNet-152 the
         # reference uses (models.py:13) -- does not fire the parent's hook: hook the stack too
@@ -166,9 +180,7 @@ class EncoderCNN(nn.Module):
         L.require_gpu(images, "images")
         busy = {e[1] for e in self._inflight}
         inst = next(i for i in range(self.LOOKAHEAD_DEPTH) if i not in busy)
-        while len(self._streams) <= inst:
-            self._streams.append(torch.cuda.Stream(device=images.device))
-        stream = self._streams[inst]
+        stream = lookahead_stream(images.device, inst)
         stream.wait_stream(torch.cuda.current_stream(images.device))   # the images, and this instance's previous consumer
         with torch.cuda.stream(stream), torch.no_grad():
             prog = self._program(images, instance=inst)
