@@ -26,6 +26,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# main stream + two look-ahead streams + RCCL's stream: more streams than HIP's default 4 hardware queues would serialise two of
+# them (the package sets the same default at import; here before torch can initialise the runtime, and inherited by spawned ranks)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 CFG = dict(batch=64, image=224, embed=256, hidden=512, vocab=10000, layers=1, cap_len=20)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -197,7 +200,17 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL announces itself on stdout ("Librccl path : ..."): keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     sat = importlib.import_module("show-and-tell_amd")
     torch.manual_seed(123)                                           # config.py:15; same weights on every rank
