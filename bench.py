@@ -222,18 +222,20 @@ def main():
     images, caps, lengths = synth_batch(torch, CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 123 + rank)
     global_tokens = world * sum(l - 1 for l in lengths)
 
-    # three synthetic image batches in rotation: with look-ahead (default) a step hands the NEXT TWO batches' images to the engine,
+    # synthetic image batches in rotation: with look-ahead (default) a step hands the next LOOKAHEAD_DEPTH (2) batches' images to the engine,
     # which runs their frozen conv stacks on side streams next to each other and under this batch's decoder work
     # (TrainStep.prefetch_encoder).  Warm-up leaves nothing in flight, so the timed region holds exactly K conv-stack passes and K
     # decoder passes: pipeline fill (step 1's stack runs alone, on the main stream) and drain are inside it.
+    depth = model.encoder.lookahead_depth
+    nb = depth + 1
     batches = [images] + [synth_batch(torch, CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 977 * (k + 1) + rank)[0]
-                          for k in range(2)]
+                          for k in range(nb - 1)]
 
     def run_steps(n):
         out = None
         for i in range(n):
-            nxt = [batches[j % 3] for j in (i + 1, i + 2) if j < n] if args.lookahead else None
-            out = dp.step((batches[i % 3], caps, lengths), global_tokens, next_images=nxt or None)
+            nxt = [batches[j % nb] for j in range(i + 1, i + 1 + depth) if j < n] if args.lookahead else None
+            out = dp.step((batches[i % nb], caps, lengths), global_tokens, next_images=nxt or None)
         return out
 
     if args.warmup:
@@ -288,7 +290,7 @@ def main():
             def seq_steps(n):
                 o = None
                 for i in range(n):
-                    o = dp.step((batches[i % 3], caps, lengths), global_tokens)
+                    o = dp.step((batches[i % nb], caps, lengths), global_tokens)
                 return o
             seq_steps(2)
             torch.cuda.synchronize()

@@ -116,6 +116,8 @@ class EncoderCNN(nn.Module):
             self.resnet = ResNetStack(embed_size, arch)     # frozen stack + trainable fc (models.py:13-16)
         self.bn = _BN1d(embed_size)                         # models.py:17
         self.compute_dtype = compute_dtype
+        env = os.environ.get("SAT_LOOKAHEAD_DEPTH")
+        self.lookahead_depth = int(env) if env else self.LOOKAHEAD_DEPTH.get(arch if isinstance(arch, str) else "", 3)
         self._programs = {}
         self._inflight = []      # look-ahead (prefetch): [(images, instance, event, program, weights signature)]
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
@@ -162,24 +164,27 @@ class EncoderCNN(nn.Module):
         return prog
 
     # -- look-ahead: the frozen stack of LATER batches on side streams ---------------------------------------------------
-    LOOKAHEAD_DEPTH = 2   # measured on MI355X at batch 64: 5.82 ms per stack alone, 4.43 with two in flight, 4.96 with three
+    # stacks in flight.  Measured on MI355X at batch 64, per stack: 5.68 ms alone, 4.40 with two in flight, 4.33 with three (with
+    # 8 hardware queues; 4.86 with HIP's default 4, where the third stream shares a queue)
+    # whole ResNet-152 step: 5.25 ms at depth 2, 5.10 at depth 3, 5.38 at depth 4; Inception-v3 299x299: 5.68 at 2, 5.98 at 3
+    LOOKAHEAD_DEPTH = {"inception_v3": 2}
 
     def prefetch(self, images):
         """Start the conv stack (frozen, `no_grad`: models.py:14-15, 25-27) of a LATER batch on a side stream.  Its pooled
         features depend on the images and the frozen weights only, not on the optimizer steps in between, so computing them
-        early changes nothing but the schedule: up to LOOKAHEAD_DEPTH stacks run next to each other (one's HBM-bound
+        early changes nothing but the schedule: up to `lookahead_depth` (3; Inception 2) stacks run next to each other (one's HBM-bound
         BatchNorm passes and under-filled launches under the other's convs) and under the current batch's head / decoder /
         backward / optimizer.  Each batch keeps its own BatchNorm batch statistics (separate program instances); the model's
         running statistics are updated when the batch is consumed, i.e. in batch order.  `forward(images)` /
         `pooled_features(images)` / `TrainStep.step(images, ...)` of the SAME tensor object later picks the result up.
-        Returns False (and does nothing) when the tensor is already in flight or LOOKAHEAD_DEPTH batches are."""
+        Returns False (and does nothing) when the tensor is already in flight or `lookahead_depth` batches are."""
         if images is None or images.dim() != 4 or any(e[0] is images for e in self._inflight):
             return False
-        if len(self._inflight) >= self.LOOKAHEAD_DEPTH:
+        if len(self._inflight) >= self.lookahead_depth:
             return False
         L.require_gpu(images, "images")
         busy = {e[1] for e in self._inflight}
-        inst = next(i for i in range(self.LOOKAHEAD_DEPTH) if i not in busy)
+        inst = next(i for i in range(self.lookahead_depth) if i not in busy)
         stream = lookahead_stream(images.device, inst)
         stream.wait_stream(torch.cuda.current_stream(images.device))   # the images, and this instance's previous consumer
         with torch.cuda.stream(stream), torch.no_grad():

@@ -10,18 +10,19 @@ sat = importlib.import_module("show-and-tell_amd")
 pytestmark = pytest.mark.gpu
 
 
-def _run(lookahead, steps=6, B=8, img=64):
+def _run(lookahead, steps=7, B=8, img=64):
     torch.manual_seed(5)
     model = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().train()
+    assert model.encoder.lookahead_depth == 3            # ResNet default (Inception: 2)
     ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
     g = torch.Generator().manual_seed(11)
-    batches = [torch.rand(B, 3, img, img, generator=g).cuda() for _ in range(3)]
+    batches = [torch.rand(B, 3, img, img, generator=g).cuda() for _ in range(4)]
     caps = torch.randint(1, 120, (B, 9), generator=g).cuda()
     lengths = [9, 9, 8, 7, 6, 5, 4, 3]
     losses = []
     for i in range(steps):
-        nxt = [batches[j % 3] for j in (i + 1, i + 2)[:lookahead] if j < steps] or None
-        losses.append(ts.step(batches[i % 3], caps, lengths, next_images=nxt))
+        nxt = [batches[j % 4] for j in range(i + 1, i + 1 + lookahead) if j < steps] or None
+        losses.append(ts.step(batches[i % 4], caps, lengths, next_images=nxt))
     torch.cuda.synchronize()
     ts.check_ids()
     rs = torch.cat([torch.cat([bn.running_mean, bn.running_var]) for bn in model.encoder.resnet.bns()])
@@ -29,14 +30,14 @@ def _run(lookahead, steps=6, B=8, img=64):
     return torch.cat(losses).cpu(), ts.flat.params.clone().cpu(), model.encoder.bn.running_mean.clone().cpu(), rs.cpu(), nbt.cpu()
 
 
-@pytest.mark.parametrize("depth", [1, 2])
+@pytest.mark.parametrize("depth", [1, 2, 3])
 def test_lookahead_is_bitwise_identical_to_sequential(depth):
     """losses, parameters, the head's and EVERY conv-stack BatchNorm's running statistics and num_batches_tracked"""
     a = _run(0)
     b = _run(depth)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
-    assert int(a[4]) == 6
+    assert int(a[4]) == 7
 
 
 def test_lookahead_of_a_different_tensor_is_discarded():

@@ -11,14 +11,16 @@ for B in [int(a) for a in sys.argv[1:]] or [32, 64, 128, 256]:
     torch.manual_seed(123)
     model = sat.ShowAndTell(CFG["embed"], CFG["hidden"], CFG["vocab"], CFG["layers"], compute_dtype="bf16").to(dev).train()
     ts = sat.TrainStep(model)
-    bt = [bench.synth_batch(torch, B, CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 100 + k) for k in range(3)]
+    depth = model.encoder.lookahead_depth
+    nb = depth + 1
+    bt = [bench.synth_batch(torch, B, CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 100 + k) for k in range(nb)]
     caps, lengths = bt[0][1], bt[0][2]
     res = []
     for la in (False, True):
         def run(n):
             for i in range(n):
-                nxt = [bt[j % 3][0] for j in (i + 1, i + 2) if j < n] if la else None
-                ts.step(bt[i % 3][0], caps, lengths, next_images=nxt or None)
+                nxt = [bt[j % nb][0] for j in range(i + 1, i + 1 + depth) if j < n] if la else None
+                ts.step(bt[i % nb][0], caps, lengths, next_images=nxt or None)
         run(4); torch.cuda.synchronize()
         n = 16
         t0 = time.perf_counter(); run(n); torch.cuda.synchronize()

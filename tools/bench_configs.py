@@ -21,15 +21,17 @@ images = torch.randn(B, 3, 299, 299, device="cuda")
 caps = torch.randint(4, V, (B, T), device="cuda")
 caps[:, 0], caps[:, -1] = 1, 2
 lengths = [T] * B
-batches = [images] + [torch.randn(B, 3, 299, 299, device="cuda") for _ in range(2)]
+DEPTH = model.encoder.lookahead_depth
+NB = DEPTH + 1
+batches = [images] + [torch.randn(B, 3, 299, 299, device="cuda") for _ in range(NB - 1)]
 LOOKAHEAD = os.environ.get("SAT_LOOKAHEAD", "1") != "0"
 
 
 def run(n):
     out = None
     for i in range(n):
-        nxt = [batches[j % 3] for j in (i + 1, i + 2) if j < n] if LOOKAHEAD else None
-        out = ts.step(batches[i % 3], caps, lengths, next_images=nxt or None)
+        nxt = [batches[j % NB] for j in range(i + 1, i + 1 + DEPTH) if j < n] if LOOKAHEAD else None
+        out = ts.step(batches[i % NB], caps, lengths, next_images=nxt or None)
     return out
 
 

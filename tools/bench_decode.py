@@ -49,15 +49,17 @@ def main():
     out["beam5_captions_per_s"] = round(a.batch / (t_enc + t_beam), 1)
     # end to end with the encoder look-ahead (EncoderCNN.prefetch works in eval mode too: eval.py:93-99 is a loop over batches):
     # the conv stacks of the next two batches run on side streams next to each other and under this batch's decode
-    batches = [images] + [torch.randn(a.batch, 3, 224, 224, device="cuda") for _ in range(2)]
+    depth = model.encoder.lookahead_depth
+    nb = depth + 1
+    batches = [images] + [torch.randn(a.batch, 3, 224, 224, device="cuda") for _ in range(nb - 1)]
 
     def pipeline(n, beam):
         ids = None
         for i in range(n):
-            for j in (i + 1, i + 2):
+            for j in range(i + 1, i + 1 + depth):
                 if j < n:
-                    model.prefetch(batches[j % 3])
-            f = model.encoder(batches[i % 3])
+                    model.prefetch(batches[j % nb])
+            f = model.encoder(batches[i % nb])
             ids = model.decoder.sample_beam(f, 5, end_id=2) if beam else model.decoder.sample(f)
         return ids
 

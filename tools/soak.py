@@ -21,7 +21,7 @@ for i in range(8):
 mem0 = None
 t0 = time.time()
 for it in range(n):
-    nxt = [batches[j % 8][0] for j in (it + 1, it + 2) if j < n] if os.environ.get("SAT_LOOKAHEAD", "1") != "0" else None
+    nxt = [batches[j % 8][0] for j in range(it + 1, it + 1 + model.encoder.lookahead_depth) if j < n] if os.environ.get("SAT_LOOKAHEAD", "1") != "0" else None
     loss = ts.step(*batches[it % 8], lr=sat.lr_for_epoch(1 + it // 100), next_images=nxt or None)
     if it % 50 == 49 or it == n - 1:
         torch.cuda.synchronize()
