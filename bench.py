@@ -269,8 +269,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: batch=64/GPU 224x224x3 + len-20 captions, ResNet-152 encoder (frozen, train-mode BN), embed=256 hidden=512 vocab=10000 L=1; fwd+CE+bwd+clamp+Adam",
                        "global_batch": world * CFG["batch"], "parallelism": "dp%d" % world,
                        "precision": "conv stack bf16 MFMA / f32 accumulate; head, LSTM, vocab, CE, Adam f32 (exact-f32 MFMA)",
-                       "schedule": ("encoder look-ahead: the frozen conv stacks of batches i+1 and i+2 run on side streams next to each other and under batch i's head/decoder/backward/Adam; "
-                                    "K conv passes + K decoder passes inside the timed region, fill and drain included") if args.lookahead
+                       "schedule": ("encoder look-ahead depth %d: the frozen conv stacks of batches i+1..i+%d run on side streams next to each other and under batch i's head/decoder/backward/Adam; "
+                                    "K conv passes + K decoder passes inside the timed region, fill and drain included" % (depth, depth)) if args.lookahead
                                    else "strictly sequential steps",
                        "final_loss": round(final_loss, 4)},
             "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel (bf16 implicit-GEMM conv, %d launches/step, variants autotuned per geometry)" % n_conv,
