@@ -53,7 +53,7 @@ def main():
     if ip:
         tail = [r for r in tail if r['s'] > ip[-1]['s']]
     if conv_win:
-        print("conv launches: mean span %.1f us while overlapped (two stacks + decoder in flight)"
+        print("conv launches: mean span %.1f us in the training steps of the look-ahead run (the profiler serialises the streams)"
               % (sum(r['e'] - r['s'] for r in conv_win) / len(conv_win) / 1e3))
     if tail:
         print("conv launches: %d in the last in-sequence pass, mean %.1f us, sum %.3f ms (what bench.py's roofline.achieved is computed from)"
