@@ -74,7 +74,13 @@ def bench_conv(shapes=None, reps=20):
         o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, Ho, Wo, Cout
         o.KH, o.KW, o.stride, o.pad = k, k, stride, pad
         o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
-        o.stat_partial, o.tiles_m = part.data_ptr(), tiles
+        mode = os.environ.get("SAT_MB_STATS", "partial")      # how the BatchNorm sums leave the kernel: slabs / integer atomics / not at all
+        if mode == "partial":
+            o.stat_partial, o.tiles_m = part.data_ptr(), tiles
+        elif mode == "acc":
+            shards = int(os.environ.get("SAT_MB_SHARDS", "1"))
+            acc = torch.zeros(2, shards, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc, o.stat_shards = acc.data_ptr(), shards
         ops = (L.SatOp * 1)(o)
         if os.environ.get("SAT_VARIANT"):
             ops[0].variant = int(os.environ["SAT_VARIANT"])
@@ -83,7 +89,7 @@ def bench_conv(shapes=None, reps=20):
             L.check(lib.sat_conv_autotune(ops, 1, 5, scratch.data_ptr(), 16384, L.stream()))
         us = time_ops(ops, 1, reps)
         fl = 2.0 * N * Ho * Wo * Cout * k * k * Cin
-        print("conv M=%d N=%d K=%d variant %d: %.1f us  %.0f TFLOP/s" % (N * Ho * Wo, Cout, k * k * Cin, ops[0].variant, us, fl / us / 1e6))
+        print("conv M=%d N=%d K=%d variant %d stats=%s: %.1f us  %.0f TFLOP/s" % (N * Ho * Wo, Cout, k * k * Cin, ops[0].variant, mode, us, fl / us / 1e6))
 
 
 ALL_SHAPES = [(64, 56, 56, 256, 64, 1, 1, 0), (64, 56, 56, 64, 64, 3, 1, 1), (64, 56, 56, 64, 256, 1, 1, 0),
