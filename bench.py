@@ -222,9 +222,9 @@ def main():
     images, caps, lengths = synth_batch(torch, CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 123 + rank)
     global_tokens = world * sum(l - 1 for l in lengths)
 
-    # synthetic image batches in rotation: with look-ahead (default) a step hands the next LOOKAHEAD_DEPTH (2) batches' images to the engine,
+    # synthetic image batches in rotation: with look-ahead (default) a step hands the next `lookahead_depth` (3) batches' images to the engine,
     # which runs their frozen conv stacks on side streams next to each other and under this batch's decoder work
-    # (TrainStep.prefetch_encoder).  Warm-up leaves nothing in flight, so the timed region holds exactly K conv-stack passes and K
+    # (EncoderCNN.prefetch).  Warm-up leaves nothing in flight, so the timed region holds exactly K conv-stack passes and K
     # decoder passes: pipeline fill (step 1's stack runs alone, on the main stream) and drain are inside it.
     depth = model.encoder.lookahead_depth
     nb = depth + 1
