@@ -945,17 +945,25 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
     if (hipMemsetD32Async((hipDeviceptr_t)scratch, 0x3f800000, kTuneTab, s) != hipSuccess ||
         hipMemsetAsync(scratch + kTuneTab, 0, kTuneTab * sizeof(float), s) != hipSuccess)
         return SAT_ERR_UNSUPPORTED;
-    hipEvent_t e0, e1, e2;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess)
-        return SAT_ERR_UNSUPPORTED;
-    // SAT_TUNE_PAIRED=1: time every candidate as TWO copies in flight on two streams (the regime of TrainStep.prefetch_encoder,
-    // where two batches' stacks run next to each other): rewards tiles that leave room for a neighbour (LDS, CU count) and
-    // fewer staged bytes per flop rather than the shortest solo launch.  Tuning launches write the op's own output buffer
-    // with identical values from both copies and touch no statistics.
-    const char* paired_env = getenv("SAT_TUNE_PAIRED");
-    const bool paired = paired_env && paired_env[0] == '1';
-    hipStream_t s2 = nullptr;
-    if (paired && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return SAT_ERR_UNSUPPORTED;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SAT_ERR_UNSUPPORTED;
+    // SAT_TUNE_COPIES=n (default 2): time every candidate as n copies in flight on n streams -- the regime of EncoderCNN.prefetch,
+    // where several batches' stacks run next to each other: rewards tiles that leave room for a neighbour (LDS, CU count) and
+    // fewer staged bytes per flop rather than the shortest solo launch (+2.6 % on the look-ahead step, the kernel alone
+    // unchanged: 0.147 of peak either way).  1 = each variant alone.  Needs GPU_MAX_HW_QUEUES > the streams in use, or the
+    // extra streams alias the caller's hardware queue and the copies serialise.  Tuning launches write the op's own output
+    // buffer with identical values from every copy and touch no statistics.
+    const char* copies_env = getenv("SAT_TUNE_COPIES");
+    int copies = copies_env ? atoi(copies_env) : 2;
+    if (const char* pe = getenv("SAT_TUNE_PAIRED")) copies = pe[0] == '1' ? 2 : 1;      // older switch
+    if (copies < 1) copies = 1;
+    if (copies > 4) copies = 4;
+    hipStream_t sx[3] = {nullptr, nullptr, nullptr};
+    for (int c = 1; c < copies; ++c)
+        if (hipStreamCreateWithFlags(&sx[c - 1], hipStreamNonBlocking) != hipSuccess) return SAT_ERR_UNSUPPORTED;
+    hipEvent_t ex[3] = {nullptr, nullptr, nullptr};
+    for (int c = 1; c < copies; ++c)
+        if (hipEventCreate(&ex[c - 1]) != hipSuccess) return SAT_ERR_UNSUPPORTED;
     int rc = SAT_OK;
     for (int i = 0; i < n_ops && rc == SAT_OK; ++i) {
         sat_op* op = ops + i;
@@ -982,19 +990,20 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
             float tmin = 1e30f;
             for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
                 if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-                if (paired && hipStreamWaitEvent(s2, e0, 0) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+                for (int c = 1; c < copies; ++c)
+                    if (hipStreamWaitEvent(sx[c - 1], e0, 0) != hipSuccess) rc = SAT_ERR_UNSUPPORTED;
                 for (int r = 0; r < reps && rc == SAT_OK; ++r) {
                     rc = launch_variant(v, a, s);
-                    if (paired && rc == SAT_OK) rc = launch_variant(v, a, s2);
+                    for (int c = 1; c < copies && rc == SAT_OK; ++c) rc = launch_variant(v, a, sx[c - 1]);
                 }
-                if (paired && (hipEventRecord(e2, s2) != hipSuccess || hipStreamWaitEvent(s, e2, 0) != hipSuccess)) {
-                    rc = SAT_ERR_UNSUPPORTED;
-                    break;
-                }
+                for (int c = 1; c < copies; ++c)
+                    if (hipEventRecord(ex[c - 1], sx[c - 1]) != hipSuccess || hipStreamWaitEvent(s, ex[c - 1], 0) != hipSuccess)
+                        rc = SAT_ERR_UNSUPPORTED;
+                if (rc != SAT_OK) break;
                 if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-                if (round >= 1 && ms / reps < tmin) tmin = ms / reps;
+                if (round >= 1 && ms / (reps * copies) < tmin) tmin = ms / (reps * copies);      // per launch
             }
             if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d v%d(%d,%d,%d,%s) %.2f us\n", a.M, a.N, a.K, v, kVariants[v].bn,
                                  kVariants[v].s, kVariants[v].nw, kVariants[v].spec ? (kVariants[v].pf ? "spec+pf" : "spec") : (kVariants[v].pf ? "pf" : "-"), tmin * 1e3f);
@@ -1010,10 +1019,12 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(e2);
-    if (s2) {
-        (void)hipStreamSynchronize(s2);
-        (void)hipStreamDestroy(s2);
+    for (int c = 0; c < 3; ++c) {
+        if (ex[c]) (void)hipEventDestroy(ex[c]);
+        if (sx[c]) {
+            (void)hipStreamSynchronize(sx[c]);
+            (void)hipStreamDestroy(sx[c]);
+        }
     }
     return rc;
 }
