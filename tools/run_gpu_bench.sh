@@ -3,6 +3,10 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 cd $R
+# one variant table for the bench line and for both traces: the autotuner's timing runs are distorted under the profiler (it
+# serialises the streams and adds per-dispatch overhead), so the profiled commands load the table the un-profiled run saved
+export SAT_TUNE_FILE=/tmp/sat_tune_bench.json
+rm -f $SAT_TUNE_FILE
 timeout -k 10 600 python bench.py --steps ${STEPS:-20} --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
 rc=$?
 cat gpurun_out/bench.json; tail -n 5 gpurun_out/bench.err
