@@ -416,7 +416,7 @@ class ShowAttendTellModel(nn.Module):
         self.hidden_size, self.embed_size, self.vocab_size, self.feat = hidden_size, embed_size, vocab_size, feat
         self.compute_dtype = compute_dtype
         self._programs, self._guard = {}, None
-        self._pf, self._pf_stream = None, None
+        self._pf_list = []          # features in flight: [(images, feats, fmean, event, weights signature, instance)]
         self.register_load_state_dict_post_hook(lambda mod, k: mod._programs.clear())
         self.encoder.register_load_state_dict_post_hook(lambda mod, k: self._programs.clear())
 
@@ -432,56 +432,61 @@ class ShowAttendTellModel(nn.Module):
         self._programs.clear()
         return super()._apply(fn, *a, **k)
 
+    PF_DEPTH = 2      # batches whose features may be in flight (own program instance and side stream each)
+
     def prefetch_features(self, images):
         """Start the FROZEN conv stack (model2.py:17 `finetune(allow=False)`) of a LATER batch on a side stream, under the current
         batch's decoder forward / backward / optimizer (hundreds of small launches that leave most of the chip idle).  The
         features depend on the images and the frozen weights only, so this changes the schedule, not a bit of the result;
-        `forward(images, ...)` / `sample(images)` of the SAME tensor object picks them up.  No-op while fine-tuning."""
+        `forward(images, ...)` / `sample(images)` of the SAME tensor object picks them up; other tensors are computed as usual
+        and leave the batches in flight alone.  No-op while fine-tuning."""
         if images is None or any(p.requires_grad for p in self.encoder.parameters()):
             return False
-        if self._pf is not None and self._pf[0] is images:
+        if any(e[0] is images for e in self._pf_list) or len(self._pf_list) >= self.PF_DEPTH:
             return False
-        if self._pf_stream is None:
-            from .models import lookahead_stream
-            self._pf_stream = lookahead_stream(images.device, 0)
+        from .models import lookahead_stream
+        busy = {e[5] for e in self._pf_list}
+        inst = next(i for i in range(self.PF_DEPTH) if i not in busy)
+        stream = lookahead_stream(images.device, inst)
         main = torch.cuda.current_stream(images.device)
-        self._pf_stream.wait_stream(main)
-        with torch.cuda.stream(self._pf_stream), torch.no_grad():
-            feats, fmean = self._program_for(images).run(images)
+        stream.wait_stream(main)
+        with torch.cuda.stream(stream), torch.no_grad():
+            feats, fmean = self._program_for(images, instance=inst).run(images)
             feats, fmean = feats.clone(), fmean.clone()
             ev = torch.cuda.Event()
-            ev.record(self._pf_stream)
+            ev.record(stream)
         feats.record_stream(main)
         fmean.record_stream(main)
-        self._pf = (images, feats, fmean, ev)
+        self._pf_list.append((images, feats, fmean, ev, self._encoder_sig(), inst))
         return True
 
-    def _program_for(self, images):
+    def _encoder_sig(self):
+        return sum(p._version * 7 + (p.data_ptr() & 0xffffffff) for p in self.encoder.parameters())
+
+    def _program_for(self, images, instance=None):
+        """instance None: the program `forward` runs; 0, 1: independent copies (own buffers) for batches in flight"""
         N, _, H, W = images.shape
         dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
-        sig = sum(p._version * 7 + (p.data_ptr() & 0xffffffff) for p in self.encoder.parameters())
-        key = (N, H, W, dt, str(images.device), sig)
+        sig = self._encoder_sig()
+        key = (N, H, W, dt, str(images.device), sig, instance)
         prog = self._programs.get(key)
         if prog is None:
-            self._programs.clear()
+            for k in [k for k in self._programs if k[5] != sig or len(self._programs) >= 6]:
+                del self._programs[k]
             prog = self._programs[key] = VggProgram(self.encoder, N, H, W, dt, images.device)
         return prog
 
     def _encode(self, images):
         L.require_gpu(images, "images")
-        pf, self._pf = self._pf, None
-        if pf is not None:
-            torch.cuda.current_stream(images.device).wait_event(pf[3])      # also orders the program's buffers behind it
-            if pf[0] is images and not any(p.requires_grad for p in self.encoder.parameters()):
-                return pf[1], pf[2]
-        N, _, H, W = images.shape
-        dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
-        sig = sum(p._version * 7 + (p.data_ptr() & 0xffffffff) for p in self.encoder.parameters())
-        key = (N, H, W, dt, str(images.device), sig)
-        prog = self._programs.get(key)
-        if prog is None:
-            self._programs.clear()
-            prog = self._programs[key] = VggProgram(self.encoder, N, H, W, dt, images.device)
+        frozen = not any(p.requires_grad for p in self.encoder.parameters())
+        for k, e in enumerate(self._pf_list):
+            if e[0] is images:
+                del self._pf_list[k]
+                torch.cuda.current_stream(images.device).wait_event(e[3])
+                if frozen and e[4] == self._encoder_sig():
+                    return e[1], e[2]
+                break                                  # weights changed meanwhile: compute again
+        prog = self._program_for(images)
         tuned = [p for p in self.encoder.parameters() if p.requires_grad]
         if tuned and torch.is_grad_enabled():
             if len(tuned) != 2 * len(self.encoder.conv_names):

@@ -325,9 +325,21 @@ def test_prefetched_features_are_the_features():
     assert m.prefetch_features(xs[0])
     got0 = m(xs[0], caps, lengths).detach().clone()
     assert m.prefetch_features(xs[1])
-    got_other = m(xs[0], caps, lengths).detach().clone()       # not the prefetched tensor: computed for xs[0]
+    got_other = m(xs[0], caps, lengths).detach().clone()       # not the prefetched tensor: computed for xs[0] ...
+    assert len(m._pf_list) == 1                                 # ... and the batch in flight is left alone
+    got1 = m(xs[1], caps, lengths).detach().clone()
+    assert not m._pf_list
+    assert m.prefetch_features(xs[0]) and m.prefetch_features(xs[1]) and not m.prefetch_features(xs[0])   # two in flight
+    got1b = m(xs[1], caps, lengths).detach().clone()            # consumed out of order
+    got0b = m(xs[0], caps, lengths).detach().clone()
+    with torch.no_grad():
+        assert m.prefetch_features(xs[0])
+        next(iter(m.encoder.parameters())).mul_(0.5)            # weights rewritten: the batch in flight is recomputed
+        got_new = m(xs[0], caps, lengths).clone()
+        want_new = m(xs[0], caps, lengths).clone()
     torch.cuda.synchronize()
-    assert torch.equal(got0, want[0]) and torch.equal(got_other, want[0])
+    assert torch.equal(got0, want[0]) and torch.equal(got_other, want[0]) and torch.equal(got1, want[1])
+    assert torch.equal(got0b, want[0]) and torch.equal(got1b, want[1]) and torch.equal(got_new, want_new)
 
 
 @pytest.mark.parametrize("model_zero_grad", [False, True])

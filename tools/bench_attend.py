@@ -80,3 +80,16 @@ with torch.no_grad():
     dec = (time.perf_counter() - t0) / 5
 print("VGG16 features[:-3] forward %.2f ms (%.0f TFLOP/s); greedy sample (20 steps) %.2f ms => %.0f captions/s end to end"
       % (enc * 1e3, 2 * 14.884e9 * B / enc / 1e12, dec * 1e3, B / (enc + dec)))
+with torch.no_grad():          # eval.py:99 as a loop over batches with the next batch's frozen VGG stack prefetched
+    def pipeline(n):
+        for i in range(n):
+            if i + 1 < n:
+                model.prefetch_features(batches[(i + 1) & 1])
+            model.sample(batches[i & 1])
+    pipeline(3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 12
+    pipeline(n)
+    torch.cuda.synchronize()
+    print("greedy sample with the features look-ahead: %.0f captions/s end to end" % (B * n / (time.perf_counter() - t0)))
