@@ -179,3 +179,11 @@ def test_collate_batch_keeps_the_reference_invariant():
         sat.collate_batch([])
     with pytest.raises(RuntimeError):
         sat.DevicePrefetcher([], "cpu")
+
+
+def test_inception_mac_constant_of_the_bench_tool_matches_the_oracle():
+    """tools/bench_configs.py prices its TFLOP/s with a constant (tools may not import the oracle): keep it equal to the oracle's count"""
+    import re
+    from oracle import inception as OI
+    src = open(os.path.join(ROOT, "tools", "bench_configs.py")).read()
+    assert int(re.search(r"INCEPTION_V3_CONV_MACS = (\d+)", src).group(1)) == OI.conv_macs()
