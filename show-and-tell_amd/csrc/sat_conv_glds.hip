@@ -782,6 +782,7 @@ constexpr Variant kVariants[] = {
     {128, 3, 8, 0, 0, 64, 0}, {128, 2, 8, 0, 0, 64, 0},                                                                             // 64-row tiles: 2 workgroups per CU on the N = 256 layers
     {128, 3, 8, 0, 0, 128, 0, 1}, {128, 4, 8, 0, 0, 128, 0, 1}, {64, 3, 8, 0, 0, 128, 0, 1}, {64, 4, 8, 0, 0, 128, 0, 1},
     {128, 3, 8, 0, 0, 64, 0, 1}, {128, 4, 8, 0, 0, 64, 0, 1}, {256, 3, 8, 0, 0, 128, 0, 1},                                          // pipelined input affine (any uniform geometry)
+    {256, 3, 8, 1, 0, 128, 0}, {256, 2, 8, 1, 0, 128, 0},                                                                           // wide tile, 4 consumer (64 x 128 each) + 4 loader waves
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -826,6 +827,8 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 36: return launch_glds<128, 3, 8, false, false, 64, false, true>(a, s);
         case 37: return launch_glds<128, 4, 8, false, false, 64, false, true>(a, s);
         case 38: return launch_glds<256, 3, 8, false, false, 128, false, true>(a, s);
+        case 39: return launch_glds<256, 3, 8, true>(a, s);
+        case 40: return launch_glds<256, 2, 8, true>(a, s);
         default: return SAT_ERR_ARG;
     }
 }
