@@ -782,7 +782,6 @@ constexpr Variant kVariants[] = {
     {128, 3, 8, 0, 0, 64, 0}, {128, 2, 8, 0, 0, 64, 0},                                                                             // 64-row tiles: 2 workgroups per CU on the N = 256 layers
     {128, 3, 8, 0, 0, 128, 0, 1}, {128, 4, 8, 0, 0, 128, 0, 1}, {64, 3, 8, 0, 0, 128, 0, 1}, {64, 4, 8, 0, 0, 128, 0, 1},
     {128, 3, 8, 0, 0, 64, 0, 1}, {128, 4, 8, 0, 0, 64, 0, 1}, {256, 3, 8, 0, 0, 128, 0, 1},                                          // pipelined input affine (any uniform geometry)
-    {256, 3, 8, 1, 0, 128, 0}, {256, 2, 8, 1, 0, 128, 0},                                                                           // wide tile, 4 consumer (64 x 128 each) + 4 loader waves
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -827,8 +826,6 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 36: return launch_glds<128, 3, 8, false, false, 64, false, true>(a, s);
         case 37: return launch_glds<128, 4, 8, false, false, 64, false, true>(a, s);
         case 38: return launch_glds<256, 3, 8, false, false, 128, false, true>(a, s);
-        case 39: return launch_glds<256, 3, 8, true>(a, s);
-        case 40: return launch_glds<256, 2, 8, true>(a, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -950,14 +947,15 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
         return SAT_ERR_UNSUPPORTED;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SAT_ERR_UNSUPPORTED;
-    // SAT_TUNE_COPIES=n (default 2): time every candidate as n copies in flight on n streams -- the regime of EncoderCNN.prefetch,
-    // where several batches' stacks run next to each other: rewards tiles that leave room for a neighbour (LDS, CU count) and
-    // fewer staged bytes per flop rather than the shortest solo launch (+2.6 % on the look-ahead step, the kernel alone
-    // unchanged: 0.147 of peak either way).  1 = each variant alone.  Needs GPU_MAX_HW_QUEUES > the streams in use, or the
+    // SAT_TUNE_COPIES=n (default 1 = each candidate alone): time every candidate as n copies in flight on n streams -- the regime
+    // of EncoderCNN.prefetch, where several batches' stacks run next to each other: rewards tiles that leave room for a
+    // neighbour (LDS, CU count) and fewer staged bytes per flop rather than the shortest solo launch.  n = 2: +2 % on the
+    // look-ahead step, but the kernel ALONE loses 3-4 % (0.142 against 0.149 of peak) and the choice gets noisier (and arbitrary
+    // under a profiler that serialises the streams), so it is opt-in.  Needs GPU_MAX_HW_QUEUES > the streams in use, or the
     // extra streams alias the caller's hardware queue and the copies serialise.  Tuning launches write the op's own output
     // buffer with identical values from every copy and touch no statistics.
     const char* copies_env = getenv("SAT_TUNE_COPIES");
-    int copies = copies_env ? atoi(copies_env) : 2;
+    int copies = copies_env ? atoi(copies_env) : 1;
     if (const char* pe = getenv("SAT_TUNE_PAIRED")) copies = pe[0] == '1' ? 2 : 1;      // older switch
     if (copies < 1) copies = 1;
     if (copies > 4) copies = 4;
