@@ -345,3 +345,31 @@ def test_residual_fusion_into_next_conv1_matches_separate_bn_add(monkeypatch):
     bufs = {k: v.clone() for k, v in buffers.items()}
     ref_bf = OE.resnet_forward_bf16_storage(params, xs[0].cpu(), arch)
     assert _rel(out[0].cpu(), ref_bf) < 0.02
+
+
+def test_lookahead_is_bitwise_identical_at_the_benchmarked_configuration():
+    """BASELINE configs[1] itself (batch 64, 224x224, E=256 / H=512 / V=10000, bf16 stack, autotuned variants, hipGraph replay): five
+    steps with the next three batches' conv stacks running ahead on side streams give the same losses, parameters and BatchNorm
+    running statistics, bit for bit, as five strictly sequential steps."""
+    def run(lookahead):
+        torch.manual_seed(123)
+        model = sat.ShowAndTell(256, 512, 10000, 1, compute_dtype="bf16").cuda().train()
+        ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+        g = torch.Generator().manual_seed(77)
+        batches = [torch.randn(64, 3, 224, 224, generator=g).cuda() for _ in range(4)]
+        caps = torch.randint(4, 10000, (64, 20), generator=g)
+        caps[:, 0], caps[:, -1] = 1, 2
+        caps = caps.cuda()
+        lengths = [20] * 64
+        losses = []
+        n = 5
+        for i in range(n):
+            nxt = [batches[j % 4] for j in range(i + 1, i + 1 + model.encoder.lookahead_depth) if j < n] if lookahead else None
+            losses.append(ts.step(batches[i % 4], caps, lengths, next_images=nxt or None))
+        torch.cuda.synchronize()
+        rs = torch.cat([torch.cat([bn.running_mean, bn.running_var]) for bn in model.encoder.resnet.bns()])
+        return torch.cat(losses).cpu(), ts.flat.params.clone().cpu(), rs.cpu()
+    a, b = run(False), run(True)
+    assert torch.isfinite(a[0]).all() and abs(float(a[0][0]) - 9.21) < 0.3          # ln(10000) = 9.21 at initialisation
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
