@@ -517,7 +517,7 @@ class ConvStackProgram:
     def defer_running_stats(self):
         """Aim every running-statistics update of this (train-mode) program at private zeroed buffers with momentum 1, so that a
         run leaves each layer's batch (mean, unbiased var) there and touches NO model state; `apply_running_stats()` then does
-        the real momentum update in one launch.  Lets two batches' frozen stacks be in flight at once while the model's
+        the real momentum update in one launch.  Lets several batches' frozen stacks be in flight at once while the model's
         running statistics still advance in batch order (TrainStep.prefetch_encoder).  Call before the first run."""
         if not self.training or self._running_items is not None:
             return

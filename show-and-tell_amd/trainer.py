@@ -101,7 +101,7 @@ class TrainStep:
 
     # -- encoder look-ahead ---------------------------------------------------------------------------
     def prefetch_encoder(self, images):
-        """Start the frozen conv stack of a LATER batch on a side stream (`EncoderCNN.prefetch`: up to two batches' stacks in
+        """Start the frozen conv stack of a LATER batch on a side stream (`EncoderCNN.prefetch`: up to three batches' stacks in
         flight next to each other and under this batch's decoder work; bitwise identical results)."""
         return self.model.encoder.prefetch(images)
 
