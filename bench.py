@@ -139,22 +139,30 @@ def cpu_baseline(torch, seed):
                       % (B, n, default_threads, pb, best[0])}
 
 
-def f32_mode_rate(torch, sat, dev, images, caps, lengths, steps=4):
+def f32_mode_rate(torch, sat, dev, images, caps, lengths, steps=6, lookahead=True):
     """Secondary figure: the same step with the conv stack in the f32 PARITY mode (exact-f32 MFMA everywhere; the mode
     whose CE matches the CPU oracle to 1e-4, tests/test_gpu_parity.py)."""
     torch.manual_seed(123)
     model = sat.ShowAndTell(CFG["embed"], CFG["hidden"], CFG["vocab"], CFG["layers"], compute_dtype="f32").to(dev).train()
     ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
-    for _ in range(2):
-        loss = ts.step(images, caps, lengths)
+    depth = model.encoder.lookahead_depth if lookahead else 0
+    batches = [images] + [images.clone() for _ in range(depth)]
+
+    def run(n):
+        out = None
+        for i in range(n):
+            nxt = [batches[j % (depth + 1)] for j in range(i + 1, i + 1 + depth) if j < n]
+            out = ts.step(batches[i % (depth + 1)], caps, lengths, next_images=nxt or None)
+        return out
+
+    run(2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = ts.step(images, caps, lengths)
+    loss = run(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"value": round(CFG["batch"] * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
-            "steps": steps, "final_loss": round(float(loss.item()), 4),
+            "steps": steps, "final_loss": round(float(loss.item()), 4), "lookahead_depth": depth,
             "note": "conv stack f32 (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak): the oracle-parity mode, not the headline"}
 
 
@@ -304,7 +312,7 @@ def main():
         if world == 1 and not args.no_f32_mode:
             del dp, ts, model
             torch.cuda.empty_cache()
-            out["f32_parity_mode"] = f32_mode_rate(torch, sat, dev, images, caps, lengths)
+            out["f32_parity_mode"] = f32_mode_rate(torch, sat, dev, images, caps, lengths, lookahead=args.lookahead)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch, 123)
         print(json.dumps(out), flush=True)
