@@ -64,38 +64,54 @@ def collate_on_device(images, flat_captions, lengths, image_ids=None):
 
 class DevicePrefetcher:
     """Wraps an iterable of (images, captions, lengths, ...) host batches: yields the same tuples with the two tensors
-    resident on `device`; the copy of the next batch runs on a side HIP stream while the caller works on the current
-    one.  Pinned host tensors make the copy truly asynchronous (`collate_batch(..., pin_memory=True)` or a DataLoader
-    with pin_memory)."""
+    resident on `device`; the copies of the next `depth` batches run on a side HIP stream while the caller works on the
+    current one.  Pinned host tensors make the copies truly asynchronous (`collate_batch(..., pin_memory=True)` or a
+    DataLoader with pin_memory).  `upcoming_images()` (inside the loop) returns the device image tensors of the batches
+    that follow, in order -- what `TrainStep.step(..., next_images=...)` / `EncoderCNN.prefetch` want for the encoder
+    look-ahead; the very same tensor objects are yielded later."""
 
-    def __init__(self, batches, device):
+    def __init__(self, batches, device, depth=1):
         self.batches, self.device = batches, torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DevicePrefetcher copies to the MI355X; got device %s" % (device,))
         self.stream = torch.cuda.Stream(self.device)
+        self.depth = max(1, int(depth))
+        self._queue = []          # [(staged batch tuple, copy-done event)]
 
     def _stage(self, batch):
         images, captions = batch[0], batch[1]
         with torch.cuda.stream(self.stream):
             d_images = images.to(self.device, non_blocking=True)
             d_captions = captions.to(self.device, non_blocking=True)
-        return (d_images, d_captions) + tuple(batch[2:])
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return (d_images, d_captions) + tuple(batch[2:]), ev
+
+    def upcoming_images(self):
+        """device image tensors of the staged batches that follow the one just yielded; the current stream is made to wait
+        for their copies, so work ordered behind it (a look-ahead stream's `wait_stream`) may read them"""
+        cur = torch.cuda.current_stream(self.device)
+        out = []
+        for staged, ev in self._queue:
+            cur.wait_event(ev)
+            out.append(staged[0])
+        return out
 
     def __iter__(self):
         it = iter(self.batches)
-        try:
-            staged = self._stage(next(it))
-        except StopIteration:
-            return
+        self._queue = []
+        done = False
         while True:
+            while not done and len(self._queue) < self.depth + 1:      # the batch to yield + `depth` copies in flight
+                try:
+                    self._queue.append(self._stage(next(it)))
+                except StopIteration:
+                    done = True
+            if not self._queue:
+                return
+            ready, ev = self._queue.pop(0)
             cur = torch.cuda.current_stream(self.device)
-            cur.wait_stream(self.stream)                 # the staged copy is complete before the caller's kernels read it
-            ready = staged
+            cur.wait_event(ev)                           # the staged copy is complete before the caller's kernels read it
             for t in ready[:2]:
                 t.record_stream(cur)                     # allocator: these blocks are in use on the compute stream
-            try:
-                staged = self._stage(next(it))           # next copy goes in flight now
-            except StopIteration:
-                yield ready
-                return
             yield ready

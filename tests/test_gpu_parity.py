@@ -623,3 +623,13 @@ def test_device_prefetcher_feeds_the_step_like_direct_copies():
     ts2 = sat.TrainStep(model2, lr=1e-3)
     got = [ts2.step(im, cp, ln).item() for im, cp, ln in sat.DevicePrefetcher(host, "cuda")]
     assert got == ref
+    # depth 3 + the encoder look-ahead fed from the prefetcher's upcoming batches: still the same losses, bit for bit
+    model3, _, _ = _small_model_and_batch(71)
+    ts3 = sat.TrainStep(model3, lr=1e-3)
+    pf = sat.DevicePrefetcher(host, "cuda", depth=3)
+    got3 = []
+    for im, cp, ln in pf:
+        ahead = pf.upcoming_images()
+        assert len(ahead) <= 3 and all(t.is_cuda for t in ahead)
+        got3.append(ts3.step(im, cp, ln, next_images=ahead or None).item())
+    assert got3 == ref and not model3.encoder._inflight
