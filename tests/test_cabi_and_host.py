@@ -187,3 +187,20 @@ def test_inception_mac_constant_of_the_bench_tool_matches_the_oracle():
     from oracle import inception as OI
     src = open(os.path.join(ROOT, "tools", "bench_configs.py")).read()
     assert int(re.search(r"INCEPTION_V3_CONV_MACS = (\d+)", src).group(1)) == OI.conv_macs()
+
+
+def test_packinfo_prev_rows_index_the_h_prev_table():
+    """PackInfo.prev_rows(): row of [h_0 (B rows) ; packed h (N rows)] holding h_{t-1} for every packed row (one gather builds
+    h_prev for the batched weight-gradient GEMMs of the Show-Attend-Tell backward, model2.py:54-62)"""
+    lengths = [5, 4, 4, 2, 1]
+    pi = sat.PackInfo(lengths, "cpu")
+    B, N = pi.B, pi.N
+    idx = pi.prev_rows().tolist()
+    assert len(idx) == N == sum(lengths)
+    # packed row (t, b) sits at prefix[t] + b; its predecessor is h_0[b] for t = 0, packed row (t-1, b) after
+    want = []
+    for t in range(pi.T):
+        for b in range(pi.batch_sizes[t]):
+            want.append(b if t == 0 else B + pi.prefix[t - 1] + b)
+    assert idx == want
+    assert pi.prev_rows() is pi.prev_rows()              # cached
