@@ -52,15 +52,36 @@ def feature_dim(arch=RESNET152):
     return arch["width"] * 8 * 4
 
 
-def init_encoder_params(embed_size, arch=RESNET152, generator=None, randomize_bn=False):
+TRAINED_LIKE_BN3 = 0.1     # mean gamma of every bottleneck's last BatchNorm in the "trained_like" initialisation
+
+
+def init_encoder_params(embed_size, arch=RESNET152, generator=None, randomize_bn=False, conditioning=None):
     """Returns (params, buffers), keys as EncoderCNN.state_dict() would have them.
-    conv: kaiming-normal fan_out (torchvision); BN gamma=1 beta=0 (or randomised to make tests sharper)."""
+    conv: kaiming-normal fan_out (torchvision); BN gamma=1 beta=0 (or randomised to make tests sharper).
+
+    conditioning="trained_like": a WELL-CONDITIONED synthetic stack for the full-depth parity tests.  With He-init
+    convolutions and unit BatchNorm gammas every bottleneck adds a residual branch as large as its identity path, and
+    the 50-block [3,8,36,3] train-mode stack is chaotic at bf16 resolution (two orderings of the same arithmetic end
+    0.16 apart in relative L2) and maps every image to nearly the same pooled vector, so nothing downstream of it can
+    be asserted tightly.  Trained ResNets are not like that: the last BatchNorm of each bottleneck carries a small
+    gamma (torchvision's `zero_init_residual` recipe starts it at 0) and the identity path dominates.  Here
+    bn3.weight ~ U(0.5, 1.5) * TRAINED_LIKE_BN3, its bias ~ N(0, 0.1 * TRAINED_LIKE_BN3), every other BatchNorm
+    gamma ~ U(0.7, 1.3), beta ~ N(0, 0.1) (downsample BNs included: they ARE the identity path of their block).
+    Measured on the CPU (B=4 and 16, 224x224, all 152 layers): bf16-storage vs f32 0.9-1.0 % at the pooled features,
+    f32- vs f64-accumulated bf16 storage 0.7 % (the floor; 16 % with the He-init stack), per-image variation of the
+    pooled vector 15-18 % of its norm, BatchNorm1d head output 6-8 % (floor 4-7 %; 140 % = uncorrelated with He init).
+    The He-init stack stays as the stress test."""
     g = generator
     params, buffers = {}, {}
     for name, bn, cin, cout, k, _, _ in conv_specs(arch):
         std = math.sqrt(2.0 / (cout * k * k))
         params["resnet." + name + ".weight"] = torch.empty(cout, cin, k, k).normal_(0, std, generator=g)
-        if randomize_bn:
+        if conditioning == "trained_like":
+            s = TRAINED_LIKE_BN3 if bn.endswith("bn3") else 1.0
+            lo, hi = (0.5 * s, 1.5 * s) if bn.endswith("bn3") else (0.7, 1.3)
+            params["resnet." + bn + ".weight"] = torch.empty(cout).uniform_(lo, hi, generator=g)
+            params["resnet." + bn + ".bias"] = torch.empty(cout).normal_(0, 0.1 * s, generator=g)
+        elif randomize_bn:
             params["resnet." + bn + ".weight"] = torch.empty(cout).uniform_(0.5, 1.5, generator=g)
             params["resnet." + bn + ".bias"] = torch.empty(cout).normal_(0, 0.1, generator=g)
         else:
@@ -72,7 +93,9 @@ def init_encoder_params(embed_size, arch=RESNET152, generator=None, randomize_bn
     fd = feature_dim(arch)
     params["resnet.fc.weight"] = torch.empty(embed_size, fd).normal_(0.0, 0.02, generator=g)   # models.py:22
     params["resnet.fc.bias"] = torch.zeros(embed_size)                                           # models.py:23
-    if randomize_bn:
+    if conditioning not in (None, "trained_like"):
+        raise ValueError("unknown conditioning %r" % (conditioning,))
+    if randomize_bn or conditioning == "trained_like":
         params["bn.weight"] = torch.empty(embed_size).uniform_(0.5, 1.5, generator=g)
         params["bn.bias"] = torch.empty(embed_size).normal_(0, 0.1, generator=g)
     else:

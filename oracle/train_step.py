@@ -74,12 +74,21 @@ def decoder_loss_and_grads(params, features, captions, lengths, num_layers=1, de
 
 
 def full_step(enc_params, enc_buffers, dec_params, images, captions, lengths, opt_state,
-              arch=E.RESNET152, num_layers=1, lr=1e-3, grad_clip=0.1, denom=None, do_update=True):
+              arch=E.RESNET152, num_layers=1, lr=1e-3, grad_clip=0.1, denom=None, do_update=True,
+              encoder_storage="f32", out=None):
     """One whole train.py:126-146 iteration for the Show-and-Tell model (models.py:9-67).
     Trainable: encoder fc + bn (enc_params keys 'resnet.fc.*', 'bn.*') and all decoder params.
+    `encoder_storage="bf16"`: the frozen conv stack with bf16 STORAGE emulated (`resnet_forward_bf16_storage`: the
+    oracle of the library's bf16 mode); head, decoder, loss and optimizer stay f32 as they do there.
+    `out`: optional dict that receives the step's `pooled` and `features` (head output).
     Returns (loss, grads dict) -- grads are post-clamp when do_update."""
-    pooled, _ = E.resnet_forward(enc_params, enc_buffers, images, arch, training=True)
+    if encoder_storage == "bf16":
+        pooled = E.resnet_forward_bf16_storage(enc_params, images, arch)
+    else:
+        pooled, _ = E.resnet_forward(enc_params, enc_buffers, images, arch, training=True)
     feats, tape = E.head_forward(enc_params, enc_buffers, pooled, training=True)
+    if out is not None:
+        out["pooled"], out["features"] = pooled, feats
     loss, grads, d_feat, _ = decoder_loss_and_grads(dec_params, feats, captions, lengths, num_layers, denom)
     hg = E.head_backward(enc_params, tape, d_feat)
     grads = dict(grads)

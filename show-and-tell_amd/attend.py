@@ -86,6 +86,7 @@ class VggProgram:
         x, h, w, c = self.img_pad, H, W, cpad
         first = True
         self.layers, self.run_id = [], 0            # (kind, ...) in forward order: the tapes of the backward
+        self.wcopies = []                           # (conv, kernel-layout weight copy, bias copy, Cin): refresh_weights()
         ones = {}
         convs = iter(stack.convs())
         for v in stack.cfg:
@@ -106,8 +107,9 @@ class VggProgram:
                 wp[:, :3] = wt
                 wt = wp
             wk = wt.permute(0, 2, 3, 1).contiguous().to(td).reshape(v, -1)
-            bias = conv.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+            bias = conv.bias.detach().to(device=device, dtype=torch.float32).clone()     # a copy: never an alias of the live parameter
             self.keep += [wk, bias]
+            self.wcopies.append((conv, wk, bias, 3 if first else c))
             out = alloc((N, h, w, v))
             o = L.SatOp()
             o.kind, o.dtype = L.OP_CONV, dtype
@@ -153,6 +155,17 @@ class VggProgram:
             L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 3, scratch.data_ptr(), scratch.numel() * 4, L.stream()),
                     "sat_conv_autotune")
             torch.cuda.synchronize()
+
+    @torch.no_grad()
+    def refresh_weights(self):
+        """Re-derive the kernel-layout copies ([Cout][KH][KW][Cin], the stack's dtype) and the bias copies from the live
+        parameters IN PLACE: one strided cast-copy per conv, no rebuild, no re-tune.  Fine-tuning (model2.py:87-89) calls this
+        before every forward: an optimizer that updates the parameters through raw pointers (`FusedClampAdam`) or in place
+        (`torch.optim.Adam`) is then always seen, and forward and backward use the same weights."""
+        for conv, wk, bias, cin in self.wcopies:
+            v = wk.shape[0]
+            wk.view(v, 3, 3, -1)[..., :cin].copy_(conv.weight.detach().permute(0, 2, 3, 1))
+            bias.copy_(conv.bias.detach())
 
     def run(self, images):
         L.require_gpu(images, "images")
@@ -461,6 +474,11 @@ class ShowAttendTellModel(nn.Module):
         return True
 
     def _encoder_sig(self):
+        """Frozen stack: changes when a weight is replaced or written in place (the program's kernel-layout copies are then
+        rebuilt).  While fine-tuning the weights change EVERY step, so the program is keyed on the storage only and its copies
+        are refreshed in place before each forward (`VggProgram.refresh_weights`)."""
+        if any(p.requires_grad for p in self.encoder.parameters()):
+            return -1 - (sum(p.data_ptr() & 0xffffffff for p in self.encoder.parameters()) & ((1 << 40) - 1))
         return sum(p._version * 7 + (p.data_ptr() & 0xffffffff) for p in self.encoder.parameters())
 
     def _program_for(self, images, instance=None):
@@ -488,6 +506,8 @@ class ShowAttendTellModel(nn.Module):
                 break                                  # weights changed meanwhile: compute again
         prog = self._program_for(images)
         tuned = [p for p in self.encoder.parameters() if p.requires_grad]
+        if tuned:
+            prog.refresh_weights()
         if tuned and torch.is_grad_enabled():
             if len(tuned) != 2 * len(self.encoder.conv_names):
                 raise NotImplementedError("fine-tune all of the conv stack or none of it (model2.py:87-89)")

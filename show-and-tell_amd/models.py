@@ -118,8 +118,8 @@ class EncoderCNN(nn.Module):
         self.compute_dtype = compute_dtype
         env = os.environ.get("SAT_LOOKAHEAD_DEPTH")
         self.lookahead_depth = int(env) if env else self.LOOKAHEAD_DEPTH.get(arch if isinstance(arch, str) else "", 3)
-        self._programs = {}
-        self._inflight = []      # look-ahead (prefetch): [(images, instance, event, program, weights signature)]
+        self._programs = {}      # insertion-ordered: least recently used first (`_program` re-inserts on a hit)
+        self._inflight = []      # look-ahead (prefetch): [(images, instance, event, program, weights signature, images._version)]
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
         # `encoder.resnet.load_state_dict(torchvision_sd)` -- the natural way to load the pretrained ResNet-152 the
         # reference uses (models.py:13) -- does not fire the parent's hook: hook the stack too
@@ -128,6 +128,7 @@ class EncoderCNN(nn.Module):
     def _invalidate(self):
         """cached op programs AND batches in flight belong to the old weights / device / mode"""
         self._programs.clear()
+        self.resnet.__dict__.pop("_sig_params", None)       # weights_signature's cached parameter list
         if self._inflight:
             self.drop_lookahead()
 
@@ -152,10 +153,19 @@ class EncoderCNN(nn.Module):
         N, _, H, W = images.shape
         dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
         key = (N, H, W, dt, self.training, str(images.device), weights_signature(self.resnet), instance)
-        prog = self._programs.get(key)
-        if prog is None:
-            if len(self._programs) >= 6:
-                self._programs.clear()
+        prog = self._programs.pop(key, None)
+        if prog is not None:
+            self._programs[key] = prog                      # most recently used last
+        else:
+            # room for BOTH modes of one shape with every look-ahead instance (the reference alternates train and eval,
+            # train.py:157-159: None + depth instances each), plus a partial last batch; evict the least recently used one
+            # program at a time -- a program is ~0.9 GB of activations and its captured graphs at cfg 2
+            cap = 2 * (self.lookahead_depth + 1) + 2
+            while len(self._programs) >= cap:
+                old = next(iter(self._programs))
+                if any(e[3] is self._programs[old] for e in self._inflight):
+                    break                                   # never evict a program with a batch in flight
+                del self._programs[old]
             make = getattr(self.resnet, "program", None)
             prog = self._programs[key] = (make(N, H, W, dt, self.training, images.device) if make is not None else
                                           ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device))
@@ -192,18 +202,20 @@ class EncoderCNN(nn.Module):
             prog.run(images)
             ev = torch.cuda.Event()
             ev.record(stream)
-        self._inflight.append((images, inst, ev, prog, weights_signature(self.resnet)))
+        self._inflight.append((images, inst, ev, prog, weights_signature(self.resnet), images._version))
         return True
 
     def _take_prefetched(self, images):
         """The finished program instance of a prefetched `images` (the current stream now waits for it), or None.  The caller
         reads `prog.pooled` and then calls `prog.apply_running_stats()` -- both on the current stream."""
-        for k, (im, inst, ev, prog, sig) in enumerate(self._inflight):
+        for k, (im, inst, ev, prog, sig, ver) in enumerate(self._inflight):
             if im is images:
                 del self._inflight[k]
                 torch.cuda.current_stream(images.device).wait_event(ev)
-                # conv weights rewritten since (version counters): the stack in flight used the old ones -> recompute
-                return prog if sig == weights_signature(self.resnet) else None
+                # conv weights rewritten since (version counters): the stack in flight used the old ones -> recompute;
+                # the same for the IMAGES: a staging buffer refilled in place (copy_, normal_, ...) between prefetch and
+                # forward is the same tensor object with other contents (its version counter moved)
+                return prog if (sig == weights_signature(self.resnet) and ver == images._version) else None
         return None
 
     def drop_lookahead(self):

@@ -82,6 +82,9 @@ class FusedClampAdam(torch.optim.Optimizer):
                                                  self.exp_avg.data_ptr() + a * 4, self.exp_avg_sq.data_ptr() + a * 4, b - a,
                                                  float(g["lr"]), g["betas"][0], g["betas"][1], float(g["eps"]), clip,
                                                  self.step_count, L.stream()), "sat_clamp_adam_step")
+        # the kernel wrote the parameters through raw pointers: move their version counters as an in-place torch update
+        # would, so that caches keyed on `_version` (kernel-layout weight copies of a conv stack) see the step
+        torch.autograd.graph.increment_version(self._params)
         return loss
 
     def state_dict(self):

@@ -110,11 +110,15 @@ def weights_signature(stack):
     """Changes whenever a frozen conv weight is replaced or written in place through the Parameter (load_state_dict,
     copy_): the op program keeps permuted (bf16) copies of the conv weights and must be rebuilt then.  Writes through
     `.data` bypass the version counter -- call `EncoderCNN.refresh_weights()` after those."""
+    # the walk over the module tree is cached (155 convs on ResNet-152, 3-4 signatures per step): `_sig_params` is dropped
+    # by EncoderCNN._invalidate (load_state_dict, device / dtype moves, refresh_weights)
+    ws = stack.__dict__.get("_sig_params")
+    if ws is None:
+        ws = [m.weight for m in stack.modules() if isinstance(m, _Conv)]
+        stack.__dict__["_sig_params"] = ws
     sig = 0
-    for m in stack.modules():
-        if isinstance(m, _Conv):
-            sig = sig * 1000003 + m.weight._version * 7 + (m.weight.data_ptr() & 0xffffffff)
-            sig &= (1 << 61) - 1
+    for w in ws:
+        sig = (sig * 1000003 + w._version * 7 + (w.data_ptr() & 0xffffffff)) & ((1 << 61) - 1)
     return sig
 
 

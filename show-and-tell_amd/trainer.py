@@ -98,6 +98,7 @@ class TrainStep:
         self.buckets = self.flat.buckets
         self.flat_grad = self.flat.grads
         self._bufs = {}
+        self._params_list = [p for _, p in self._trainable()]
 
     # -- encoder look-ahead ---------------------------------------------------------------------------
     def prefetch_encoder(self, images):
@@ -211,6 +212,9 @@ class TrainStep:
                                         L.ptr(flat.grad("encoder.bn.bias")), L.ptr(bufs["head_ws"]),
                                         bufs["head_ws"].numel() * 4, st), "sat_fc_bn1d_bwd")
         self.last_d_features = bufs["d_feat"]
+        # this step's encoder outputs (views of step-owned buffers, overwritten by the next step): the parity tests at the
+        # benchmarked configuration read them
+        self.last_pooled, self.last_features = pooled, feats_in
         if on_bucket_ready is not None:
             on_bucket_ready(2)   # encoder head + embedding gradients (and the loss slot) are final
         return loss_slot
@@ -227,6 +231,7 @@ class TrainStep:
                                              float(self.lr if lr is None else lr), self.betas[0], self.betas[1],
                                              self.eps, float(self.grad_clip), self.step_count, L.stream()),
                 "sat_clamp_adam_step")
+        torch.autograd.graph.increment_version(self._params_list)     # written through raw pointers: bump `_version` like torch would
 
     # -- optimizer checkpoint interchange (the reference's load_optimizer is an empty stub, ------
     #    train.py:60-64, and only model.state_dict() is saved, train.py:191-193) ---------------------------

@@ -81,9 +81,9 @@ def test_resnet152_bf16_train_mode_cfg1_vs_bf16_storage_oracle():
         assert torch.equal(g, got[0])
 
 
-def _cfg2_models(dtype, seed=123, B=64):
+def _cfg2_models(dtype, seed=123, B=64, conditioning=None):
     gen = torch.Generator().manual_seed(seed)
-    ep, eb = OE.init_encoder_params(256, OE.RESNET152, generator=gen)
+    ep, eb = OE.init_encoder_params(256, OE.RESNET152, generator=gen, conditioning=conditioning)
     dp = OD.init_decoder_params(256, 512, 10000, 1, generator=gen)
     images = torch.randn(B, 3, 224, 224, generator=gen)
     caps = torch.randint(4, 10000, (B, 20), generator=gen)
@@ -373,3 +373,111 @@ def test_lookahead_is_bitwise_identical_at_the_benchmarked_configuration():
     assert torch.isfinite(a[0]).all() and abs(float(a[0][0]) - 9.21) < 0.3          # ln(10000) = 9.21 at initialisation
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Full depth, WELL-CONDITIONED stack (`conditioning="trained_like"`, oracle/encoder.py): the He-init stack above is
+# chaotic at bf16 resolution and maps every image to nearly the same pooled vector, so the tests above cannot see the
+# encoder through the head or the loss.  With the last BatchNorm gamma of every bottleneck small (as in trained nets) the
+# 152-layer map is stable (bf16-storage floor 0.7 % instead of 16 %) and the pooled vectors differ per image by 15-18 %
+# of their norm, so the head output, the CE and the post-Adam parameters all depend measurably on the conv stack: a
+# wrong residual wiring, statistics path or layer order now fails these tests.
+def _floor_f64(params, x, arch):
+    """noise floor of the bf16-storage arithmetic: the same emulation with every conv accumulated in f64"""
+    import torch.nn.functional as F
+    conv2d = F.conv2d
+    try:
+        F.conv2d = lambda a, w, b=None, stride=1, padding=0: conv2d(a.double(), w.double(), None, stride, padding).float()
+        return OE.resnet_forward_bf16_storage(params, x, arch)
+    finally:
+        F.conv2d = conv2d
+
+
+@pytest.mark.timeout(900)
+def test_cfg1_trained_like_stack_pooled_and_head_f32_tight_bf16_within_measured_floor():
+    """BASELINE cfg-1 shape (batch 4, 224x224, all 152 layers, train-mode statistics), models.py:25-29: f32 mode against the
+    f32 oracle (pooled 1e-4, head output 1e-3 relative L2), bf16 mode against the bf16-storage oracle with bounds taken
+    from the floor measured in the same test (two summation orders of the oracle itself)."""
+    arch, E, B = OE.RESNET152, 256, 4
+    gen = torch.Generator().manual_seed(41)
+    params, buffers = OE.init_encoder_params(E, arch, generator=gen, conditioning="trained_like")
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(42))
+    bufs = {k: v.clone() for k, v in buffers.items()}
+    ref32, _ = OE.resnet_forward(params, bufs, x, arch, training=True)
+    head32, _ = OE.head_forward(params, {k: v.clone() for k, v in buffers.items()}, ref32, True)
+    ref_bf = OE.resnet_forward_bf16_storage(params, x, arch)
+    head_bf, _ = OE.head_forward(params, {k: v.clone() for k, v in buffers.items()}, ref_bf, True)
+    ref_bf64 = _floor_f64(params, x, arch)
+    head_bf64, _ = OE.head_forward(params, {k: v.clone() for k, v in buffers.items()}, ref_bf64, True)
+    floor_p, floor_h = _rel(ref_bf64, ref_bf), _rel(head_bf64, head_bf)
+    var = ((ref32 - ref32.mean(0, keepdim=True)).norm() / ref32.norm()).item()
+    assert var > 0.10, var                                   # the images are told apart at the pooled features
+    e32 = _encoder(arch, E, params, buffers, "f32").train()
+    e16 = _encoder(arch, E, params, buffers, "bf16").train()
+    with torch.no_grad():
+        p32 = e32.pooled_features(x.cuda()).cpu()
+        rv32 = e32.state_dict()["resnet.layer4.2.bn3.running_var"].cpu().clone()       # after exactly one training pass
+        h32 = e32(x.cuda()).cpu()
+        p16 = e16.pooled_features(x.cuda()).cpu()
+        h16 = e16(x.cuda()).cpu()
+    print("cfg1 trained-like: per-image variation %.3f | f32 pooled %.2e head %.2e | bf16 pooled %.4f (floor %.4f) head %.4f "
+          "(floor %.4f) | bf16 vs f32 oracle pooled %.4f head %.4f"
+          % (var, _rel(p32, ref32), _rel(h32, head32), _rel(p16, ref_bf), floor_p, _rel(h16, head_bf), floor_h,
+             _rel(p16, ref32), _rel(h16, head32)))
+    assert _rel(p32, ref32) < 1e-5 and _rel(h32, head32) < 1e-4          # measured 7e-7 and 6e-6
+    assert _rel(p16, ref_bf) < 1.5 * floor_p + 0.003, (_rel(p16, ref_bf), floor_p)
+    assert _rel(h16, head_bf) < 1.5 * floor_h + 0.02, (_rel(h16, head_bf), floor_h)
+    assert _rel(p16, ref_bf) < 0.03 and _rel(h16, head_bf) < 0.25         # absolute caps (He init: 0.16 and 1.4)
+    # the running statistics of the deepest BatchNorm after the f32 pass (every layer's batch statistics fed it)
+    assert torch.allclose(rv32, bufs["resnet.layer4.2.bn3.running_var"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.timeout(1800)
+def test_cfg2_trained_like_whole_train_steps_are_sensitive_to_the_encoder():
+    """BASELINE configs[1] (batch 64, 224x224, E=256 H=512 V=10000), three train.py:126-146 iterations on the
+    well-conditioned stack.  f32 mode vs `oracle.train_step.full_step`: pooled, head output, CE (1e-4, north_star) and the
+    parameters after three clamp+Adam steps (<= 5e-3 of the elements of ANY tensor beyond 1e-5, the LSTM and fc included).
+    bf16 mode vs the same oracle with bf16 storage emulated in the conv stack: head output and CE."""
+    model32, ep, eb, dp, images, caps, lengths = _cfg2_models("f32", conditioning="trained_like")
+    model16, _, _, _, _, _, _ = _cfg2_models("bf16", conditioning="trained_like")
+    ts32, ts16 = sat.TrainStep(model32), sat.TrainStep(model16)
+    di, dc = images.cuda(), caps.cuda()
+    o32 = dict(ep={k: v.clone() for k, v in ep.items()}, eb={k: v.clone() for k, v in eb.items()},
+               dp={k: v.clone() for k, v in dp.items()}, st={})
+    o16 = dict(ep={k: v.clone() for k, v in ep.items()}, eb={k: v.clone() for k, v in eb.items()},
+               dp={k: v.clone() for k, v in dp.items()}, st={})
+    r32, r16, l32, l16 = [], [], [], []
+    for step in range(3):
+        out32, out16 = {}, {}
+        r32.append(OT.full_step(o32["ep"], o32["eb"], o32["dp"], images, caps, lengths, o32["st"], out=out32)[0].item())
+        r16.append(OT.full_step(o16["ep"], o16["eb"], o16["dp"], images, caps, lengths, o16["st"], encoder_storage="bf16",
+                                out=out16)[0].item())
+        l32.append(ts32.step(di, dc, lengths).item())
+        p32, f32 = ts32.last_pooled.cpu(), ts32.last_features.cpu()
+        l16.append(ts16.step(di, dc, lengths).item())
+        p16, f16 = ts16.last_pooled.cpu(), ts16.last_features.cpu()
+        print("cfg2 trained-like step %d: f32 pooled %.2e head %.2e dCE %.2e | bf16 vs bf16-storage oracle pooled %.4f head %.4f "
+              "dCE %.2e | bf16 vs f32 oracle head %.4f dCE %.2e"
+              % (step, _rel(p32, out32["pooled"]), _rel(f32, out32["features"]), abs(l32[-1] - r32[-1]),
+                 _rel(p16, out16["pooled"]), _rel(f16, out16["features"]), abs(l16[-1] - r16[-1]),
+                 _rel(f16, out32["features"]), abs(l16[-1] - r32[-1])))
+        assert _rel(p32, out32["pooled"]) < 1e-5 and _rel(f32, out32["features"]) < 2e-4
+        assert abs(l32[-1] - r32[-1]) < 1e-4                                # north_star: CE within 1e-4 fp32
+        # bf16: measured floor of the emulation itself 0.7 % (pooled) / 4-7 % (head, batch 4-16); 16 % / 140 % with He init.
+        # Measured here: pooled 0.73 %, head 4.1 %, |dCE| 4e-6 vs the bf16-storage oracle and 6e-5 vs the f32 oracle
+        assert _rel(p16, out16["pooled"]) < 0.015 and _rel(f16, out16["features"]) < 0.08
+        assert abs(l16[-1] - r16[-1]) < 1e-4 and abs(l16[-1] - r32[-1]) < 5e-4
+    var = ((out32["pooled"] - out32["pooled"].mean(0, keepdim=True)).norm() / out32["pooled"].norm()).item()
+    assert var > 0.10, var
+    got = {k: v.detach().cpu() for k, v in model32.decoder.state_dict().items()}
+    got["resnet.fc.weight"] = model32.encoder.resnet.fc.weight.detach().cpu()
+    got["bn.weight"], got["bn.bias"] = model32.encoder.bn.weight.detach().cpu(), model32.encoder.bn.bias.detach().cpu()
+    want = dict(o32["dp"])
+    for k in ("resnet.fc.weight", "bn.weight", "bn.bias"):
+        want[k] = o32["ep"][k]
+    for k in want:
+        d = (got[k] - want[k]).abs()
+        frac = (d > 1e-5).float().mean().item()
+        print("cfg2 trained-like params after 3 steps %-22s max|d| %.2e, fraction beyond 1e-5: %.2e" % (k, d.max().item(), frac))
+        assert d.max().item() <= 3 * 2e-3 + 1e-6, (k, d.max().item())
+        assert frac < 1e-3, (k, frac)                        # measured <= 9.2e-5 (resnet.fc.weight); VERDICT r2 asked <= 5e-3
