@@ -100,3 +100,26 @@ def full_step(enc_params, enc_buffers, dec_params, images, captions, lengths, op
         allp.update(dec_params)
         adam_step_(allp, grads, opt_state, lr=lr)
     return loss, grads
+
+
+def validation_loss(dec_params, features, captions, lengths, num_layers=1):
+    """The validation forward of `evaluation` (eval.py:91-95): `targets = pack(captions, lengths)` with the captions NOT
+    shifted and the lengths NOT decremented, `outputs = model(images, captions, lengths)`, mean CE.  (The decoder then
+    consumes [feature, captions[:, :l-1]] -- models.py:49-51 -- so output row t is scored against caption token t.)
+    Returns (loss, logits).  Pinned by tests/golden/G8 (the imported reference decoder)."""
+    targets = D.pack_time_major(captions, [int(l) for l in lengths])
+    logits = D.decoder_forward(dec_params, features, captions, [int(l) for l in lengths], num_layers)
+    return D.cross_entropy(logits, targets), logits
+
+
+def kept_tokens(ids, end_id):
+    """eval.py:103-109: the id -> word loop breaks at '<end>': per row, the number of ids in front of the first end_id."""
+    out = []
+    for row in ids.tolist():
+        n = 0
+        for w in row:
+            if w == end_id:
+                break
+            n += 1
+        out.append(n)
+    return out

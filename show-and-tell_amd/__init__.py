@@ -16,6 +16,7 @@ from . import _lib  # noqa: F401,E402
 from .models import (CaptionModel, Decoder, DecoderRNN, Encoder, EncoderCNN, ShowAndTell)  # noqa: F401
 from .attend import ShowAttendTellModel, VggFeatures  # noqa: F401
 from .input import DevicePrefetcher, collate_batch, collate_on_device  # noqa: F401
+from .evaluate import kept_tokens, mean_cross_entropy, pack_validation_targets, sentences, validation_step  # noqa: F401
 from .optim import FusedClampAdam  # noqa: F401
 from .pack import PackInfo, pack_targets  # noqa: F401
 from .resnet import RESNET152, conv_flops  # noqa: F401

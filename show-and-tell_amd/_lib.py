@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -78,6 +78,8 @@ SIGNATURES = {
     "sat_pack_targets": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
     "sat_lstm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_lstm_fwd_ws_bytes": (_i64, [_i, _i]),
+    "sat_lstm_fwd_status_offset": (_i64, [_i, _i]),
+    "sat_lstm_persist_enable": (_i, [_i]),
     "sat_lstm_bwd_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_bwd_ws_bytes_full": (_i64, [_i, _i, _i, _i]),
     "sat_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i,
@@ -119,6 +121,7 @@ SIGNATURES = {
     "sat_beam_step_ws_bytes": (_i64, [_i, _i]),
     "sat_beam_gather_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_beam_backtrack": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sat_kept_tokens": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp]),
     "sat_clamp_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
     "sat_colsum_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "sat_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),

@@ -236,7 +236,28 @@ __global__ __launch_bounds__(256) void beam_backtrack_kernel(const int* __restri
     }
 }
 
+// eval.py:103-109: the id -> word loop of `evaluation` stops at the first '<end>'.  One thread per caption row: the number of
+// ids in front of the first end_id (T when there is none) -- the host then reads ids[b][:kept[b]] only.
+__global__ __launch_bounds__(256) void kept_tokens_kernel(const int64_t* __restrict__ ids, long stride, int B, int T, int64_t end_id,
+                                                          int32_t* __restrict__ kept) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int64_t* row = ids + (long)b * stride;
+    int n = 0;
+    while (n < T && row[n] != end_id) ++n;
+    kept[b] = n;
+}
+
 }  // namespace
+
+extern "C" int sat_kept_tokens(const int64_t* ids, int64_t stride, int B, int T, int64_t end_id, int32_t* kept,
+                               sat_stream_t stream) {
+    if (!ids || !kept || B <= 0 || T <= 0 || stride < T) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(kept_tokens_kernel, dim3(sat_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, ids, (long)stride, B, T,
+                       end_id, kept);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
 
 extern "C" int64_t sat_beam_step_ws_bytes(int B, int K) { return (int64_t)B * K * K * 8; }
 

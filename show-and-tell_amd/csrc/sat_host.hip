@@ -225,6 +225,12 @@ extern "C" int sat_lstm_fwd(const float* X, const float* w_ih, const float* w_hh
     static const int persist_env = getenv("SAT_LSTM_PERSIST") ? atoi(getenv("SAT_LSTM_PERSIST")) : 1;
     if (persist_env && workspace && ws_bytes >= sat_lstm_fwd_ws_bytes(B, H) && sat_lstm_persist_ok(B, H, T, device_cu_count()))
         return sat_lstm_persist_launch(GA, w_hh, CS, HS, HP, batch_sizes, T, H, workspace, ws_bytes, s);
+    // one launch per step: the status word the caller reads back (sat_lstm_fwd_status_offset) reports a clean run
+    const int64_t soff = sat_lstm_fwd_status_offset(B, H);
+    if (workspace && soff >= 0 && ws_bytes >= soff + 64) {
+        e = hipMemsetAsync((char*)workspace + soff, 0, 64, s);
+        if (e != hipSuccess) return (int)e;
+    }
     e = hipMemsetAsync(c_state, 0, (size_t)B * H * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
     long off = 0;

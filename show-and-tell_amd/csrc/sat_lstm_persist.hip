@@ -20,13 +20,14 @@
 // Needs groups * members <= CUs (all workgroups co-resident); the host falls back to one launch per step otherwise.
 #include "sat_internal.h"
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 namespace {
 
 constexpr int kMaxT = 64;
 constexpr int kRows = 8;          // batch rows per group
 constexpr int kUnits = 16;        // hidden units per member workgroup (4 waves x 4 units)
-constexpr unsigned kSpinLimit = 1u << 22;
+constexpr unsigned kSpinLimit = 1u << 22;   // default bound of one hand-off wait, in sweeps (SAT_LSTM_SPIN_LIMIT overrides)
 
 struct PersistArgs {
     float* GA;            // [N][4H] in: x-gates (+ both biases); out: activated gates i,f,g,o
@@ -35,7 +36,9 @@ struct PersistArgs {
     float* HS;            // [N][H]
     float* HP;            // [N][H]  (rows of step 0 pre-zeroed by the host)
     unsigned long long* xch;   // [2 parities][groups][members][8 rows][16 units] granules, zeroed per call
-    unsigned* err;        // sticky timeout word (zeroed per call)
+    unsigned* err;        // sticky timeout word (zeroed per call; the CALLER reads it back: sat_lstm_fwd_status_offset)
+    unsigned spin_limit;  // sweeps a workgroup waits for its group before it gives up
+    int dbg_stall;        // diagnostics (SAT_LSTM_DEBUG_STALL=1): workgroup 0 never publishes -> its group times out
     int H, T, B, members;
     int prefix[kMaxT + 1];
 };
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
                 }
                 if (__syncthreads_and(ok ? 1 : 0)) break;
                 if ((++spins & 63u) == 0) {            // every 64 sweeps: bounded spin + another workgroup's verdict
-                    if (tid == 0 && (spins > kSpinLimit ||
+                    if (tid == 0 && (spins > p.spin_limit ||
                                      __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
                         s_abort = 1;
                     __syncthreads();
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
                 if (row0 + erow < bs_next) p.HP[((long)p.prefix[t + 1] + row0 + erow) * H + eu] = h_new;
             }
             // publish h_t of (row, unit) for the group: tag = t + 1 (never 0), parity t & 1
-            if (t + 1 < p.T) {
+            if (t + 1 < p.T && !(p.dbg_stall && blockIdx.x == 0)) {
                 gu64* dst = xch + ((long)(t & 1) * groups + group) * slab +
                             ((long)member * kRows + erow) * kUnits + wave * 4 + (lane & 3);
                 __hip_atomic_store(dst, ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(h_new),
@@ -201,8 +204,26 @@ extern "C" int64_t sat_lstm_fwd_ws_bytes(int B, int H) {
     return 2 * groups * members * kRows * kUnits * 8 + 64;
 }
 
+// Byte offset of the recurrence's STATUS WORD (u32) inside the sat_lstm_fwd workspace: 0 after a clean run, non-zero when a
+// workgroup of the persistent launch gave up waiting for its group (the tapes / HS of that call are then INVALID).  The word is
+// zeroed by every call; the caller copies it out behind the call and raises -- it must never be ignored.
+extern "C" int64_t sat_lstm_fwd_status_offset(int B, int H) {
+    const int64_t n = sat_lstm_fwd_ws_bytes(B, H);
+    return n > 0 ? n - 64 : -1;
+}
+
+// process-wide switch of the persistent recurrence (returns the previous setting): after a timeout the host side turns it off,
+// so later calls take the one-launch-per-step path, which needs no co-residency
+static int g_persist_enabled = 1;
+extern "C" int sat_lstm_persist_enable(int on) {
+    const int prev = g_persist_enabled;
+    g_persist_enabled = on ? 1 : 0;
+    return prev;
+}
+
 // can the persistent kernel run this layer?  (all workgroups must be co-resident: one per CU)
 bool sat_lstm_persist_ok(int B, int H, int T, int n_cu) {
+    if (!g_persist_enabled) return false;
     if (!sat_lstm_persist_has(H) || T > kMaxT || T < 1) return false;
     const int groups = (B + kRows - 1) / kRows, members = H / kUnits;
     return groups * members <= n_cu;
@@ -219,6 +240,10 @@ int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, flo
     a.xch = (unsigned long long*)workspace;
     a.err = (unsigned*)((char*)workspace + (need - 64));
     a.H = H; a.T = T; a.B = B; a.members = members;
+    const char* sl = getenv("SAT_LSTM_SPIN_LIMIT");
+    a.spin_limit = (sl && atol(sl) > 0) ? (unsigned)atol(sl) : kSpinLimit;
+    const char* ds = getenv("SAT_LSTM_DEBUG_STALL");
+    a.dbg_stall = (ds && ds[0] == '1') ? 1 : 0;
     a.prefix[0] = 0;
     for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
     hipError_t e = hipMemsetAsync(workspace, 0, (size_t)need, s);

@@ -260,6 +260,64 @@ class EncoderCNN(nn.Module):
 
 # ------------------------------------------------------------------------------------------------------
 # decoder
+class LstmWatch:
+    """The persistent LSTM recurrence (`sat_lstm_persist.hip`) needs all its workgroups resident at once and bounds every
+    hand-off wait; when a wait runs out (co-tenants on the device kept part of the grid from being scheduled) the kernel sets
+    the STATUS WORD of its workspace and drains -- the tapes and `HS` of that call are garbage.  That must never pass
+    silently: the word is copied to pinned host memory behind every call and looked at when the next call is
+    submitted (or at once with `poll(block=True)`; `TrainStep.check_ids()` does); non-zero raises RuntimeError and switches
+    the process to one launch per step (`sat_lstm_persist_enable(0)`), which needs no co-residency."""
+
+    DEPTH = 8
+    _by_device = {}
+
+    @classmethod
+    def get(cls, device):
+        key = str(device)
+        w = cls._by_device.get(key)
+        if w is None:
+            w = cls._by_device[key] = cls()
+        return w
+
+    def __init__(self):
+        self.host = torch.zeros(self.DEPTH, dtype=torch.int32).pin_memory()
+        self.pending = []           # (slot, event), oldest first
+        self.slot = 0
+
+    def submit(self, ws, offset):
+        """ws: the uint8 workspace tensor sat_lstm_fwd just ran with; offset: sat_lstm_fwd_status_offset"""
+        self.poll(block=False)
+        while len(self.pending) >= self.DEPTH:
+            self._retire(block=True)
+        slot = self.slot
+        self.slot = (slot + 1) % self.DEPTH
+        self.host[slot:slot + 1].copy_(ws[offset:offset + 4].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((slot, ev))
+
+    def _retire(self, block):
+        slot, ev = self.pending[0]
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return False
+        self.pending.pop(0)
+        if int(self.host[slot]) != 0:
+            torch.cuda.current_stream().synchronize()
+            self.host.zero_()
+            self.pending.clear()
+            L.load().sat_lstm_persist_enable(0)
+            raise RuntimeError("show-and-tell_amd: the persistent LSTM recurrence timed out waiting for its group (its workgroups "
+                               "were not all resident: other work shares the device); the outputs of that call are invalid.  "
+                               "Later calls run one launch per step (SAT_LSTM_PERSIST=0 selects that from the start)")
+        return True
+
+    def poll(self, block=False):
+        while self.pending and self._retire(block):
+            pass
+
+
 class IdGuard:
     """Out-of-range caption ids.  `nn.Embedding` (models.py:49) and `nn.CrossEntropyLoss` (train.py:143) raise on an id
     outside [0, V); the gather / CE kernels here clamp such ids for memory safety only, so every batch is range-checked
@@ -369,6 +427,9 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         L.check(lib.sat_lstm_fwd(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), pi.bs_c, T, In, H,
                                  L.ptr(GA), L.ptr(CS), L.ptr(HS), L.ptr(HP), L.ptr(cst), L.ptr(ws), wsb, st), "sat_lstm_fwd")
+        soff = lib.sat_lstm_fwd_status_offset(B, H)
+        if soff >= 0 and wsb > 0:
+            LstmWatch.get(dev).submit(ws, soff)          # the recurrence's status word: raises (at the latest one call later)
         tapes["layers"].append((GA, CS, HP))
         tapes["X"].append(HS)
         inp = HS

@@ -2,7 +2,7 @@
 """Generate tests/golden/G*.npz by running the REFERENCE's own `models.DecoderRNN` (imported from
 /root/reference, build container only) plus train.py's loss / clamp / Adam arithmetic.
 
-    python tests/golden/make_goldens.py            # rewrites tests/golden/G1..G5
+    python tests/golden/make_goldens.py            # rewrites tests/golden/G1..G5, G8
 
 The reference never travels: only these data files (inputs + expected outputs) are committed.
 `torchvision` is absent offline; `models.py:3` imports it at top level only for the encoder, so an empty
@@ -102,6 +102,42 @@ def greedy_reference(dec, feats):
             ids.append(predicted)
             inputs = dec.embed(predicted)
         return torch.cat(ids, 1)
+
+
+def eval_case(models, name, seed, B, T, E, H, V, L, lengths, end_id=2):
+    """The validation half of `evaluation` (eval.py:91-93) on the reference decoder: UNSHIFTED captions and FULL lengths --
+    `targets = pack(captions, lengths)`, `outputs = model(images, captions, lengths)`, `loss = crit(outputs, targets)` --
+    plus the greedy ids of `model.sample` (eval.py:99) and, per row, the number of tokens the id->word loop of
+    eval.py:103-109 keeps (everything before the first `<end>`)."""
+    from torch.nn.utils.rnn import pack_padded_sequence
+    dec = models_reload(models, E, H, V, L, seed)
+    feats, caps = synth_batch(B, T, V, E, lengths, seed + 1)
+    with torch.no_grad():
+        logits = dec(feats, caps, lengths)                      # eval.py:93: captions NOT shifted, lengths NOT decremented
+        targets = pack_padded_sequence(caps, lengths, batch_first=True)[0]      # eval.py:91
+        loss = torch.nn.CrossEntropyLoss()(logits, targets)     # eval.py:95
+    ids = greedy_reference(dec, feats)
+    # rows with <end> at chosen places (the truncation rule does not care how the ids were produced): first column, middle,
+    # last column, never
+    ids_planted = ids.clone()
+    ids_planted[ids_planted == end_id] = end_id + 1
+    ids_planted[0, 5] = end_id
+    ids_planted[0, 9] = end_id
+    ids_planted[1, 0] = end_id
+    ids_planted[2, 19] = end_id
+    keep = []
+    for row in ids_planted.tolist():
+        n = 0
+        for w in row:                                           # eval.py:103-109: break at '<end>'
+            if w == end_id:
+                break
+            n += 1
+        keep.append(n)
+    out = dict(seed=seed, dims=np.array([E, H, V, L, B, T]), lengths=np.array(lengths), features=feats.numpy(),
+               captions=caps.numpy(), logits=logits.numpy(), targets=targets.numpy(), loss=np.float32(loss.item()),
+               greedy_ids=ids.numpy(), ids_planted=ids_planted.numpy(), kept_tokens=np.array(keep), end_id=np.array(end_id))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", loss.item(), "kept", keep)
 
 
 def main():

@@ -34,3 +34,11 @@ def test_under_torchrun_env_it_is_one_rank_and_rejects_a_world_mismatch():
 def test_single_rank_needs_no_launcher():
     r = _run(["--selftest-launch"])
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_a_failing_rank_makes_the_launcher_exit_non_zero_and_print_no_result_line():
+    """`python bench.py --gpus 2`: the parent hands the ranks' exit status on (the driver reads it) -- a rank that dies must
+    not leave a zero exit code or a JSON line behind"""
+    r = _run(["--gpus", "2", "--selftest-launch", "--selftest-fail-rank", "1"])
+    assert r.returncode != 0, (r.returncode, r.stdout, r.stderr[-500:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -204,3 +204,26 @@ def test_packinfo_prev_rows_index_the_h_prev_table():
             want.append(b if t == 0 else B + pi.prefix[t - 1] + b)
     assert idx == want
     assert pi.prev_rows() is pi.prev_rows()              # cached
+
+
+def test_write_through_store_keeps_its_wait_states(tmp_path):
+    """Static half of the `store16_wt` regression pin (robustness 13): the inline-asm write-through store
+    (`global_store_dwordx4 ... sc0 sc1`, sat_common.h) must carry its own `s_nop 1` -- a VMEM store of more than 64 bits needs
+    wait states before its data VGPRs may be overwritten and the compiler's hazard recognizer does not look inside asm.  A tiny
+    kernel that overwrites the stored registers at once is compiled to gfx950 assembly; every such store is followed by the nop."""
+    src = tmp_path / "wt.hip"
+    src.write_text('#include "sat_common.h"\n'
+                   '__global__ void k(u32x4* dst, const u32x4* src, int n) {\n'
+                   '    u32x4 v = src[threadIdx.x];\n'
+                   '    for (int i = 0; i < n; ++i) { store16_wt(dst + i * 64 + threadIdx.x, v); v = v * 3u + 1u; }\n'
+                   '}\n')
+    asm = tmp_path / "wt.s"
+    inc = os.path.join(ROOT, "show-and-tell_amd", "csrc")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-I", inc,
+                        "-I", os.path.join(ROOT, "include"), str(src), "-o", str(asm)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l.strip() for l in asm.read_text().splitlines() if l.strip() and not l.strip().startswith((";", ".", "//"))]
+    stores = [i for i, l in enumerate(lines) if l.startswith("global_store_dwordx4") and "sc0 sc1" in l]
+    assert stores, "the write-through store disappeared from the generated code"
+    for i in stores:
+        assert lines[i + 1].startswith("s_nop 1"), (lines[i], lines[i + 1])

@@ -384,3 +384,50 @@ def test_fused_clamp_adam_equals_torch_clamp_plus_adam(model_zero_grad):
     ob2 = sat.FusedClampAdam([p for p in build().parameters() if p.requires_grad], lr=5e-4, clip=0.1)
     ob2.load_state_dict(sd)
     assert ob2.step_count == 3 and ob2.param_groups[0]["lr"] == 1e-3 and torch.equal(ob2.exp_avg, ob.exp_avg)
+
+
+def test_finetune_with_fused_clamp_adam_sees_every_weight_update():
+    """`finetune(allow=True)` + `FusedClampAdam` (parameters re-homed, updated through raw pointers, version counters
+    once untouched) trained against the FIRST step's kernel-layout conv weights.  Three steps of the drop-in loop with the fused
+    optimizer equal three steps with torch's clamp_ + Adam: losses, conv weights, biases (model2.py:87-89, train.py:145-146)."""
+    def build():
+        torch.manual_seed(12)
+        m = sat.ShowAttendTellModel(96, 64, 50, 32, None, feature_size=(16, 64), compute_dtype="f32", vgg_cfg=SMALL_VGG).cuda()
+        m.finetune(allow=True)
+        return m
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(4, 3, 32, 32, generator=g).cuda()
+    caps = torch.randint(1, 50, (4, 7), generator=g).cuda()
+    lengths = [7, 6, 4, 3]
+    targets, l1 = sat.pack_targets(caps, lengths)
+    crit = torch.nn.CrossEntropyLoss()
+    ma, mb = build(), build()
+    oa = sat.FusedClampAdam(ma.parameters(), lr=1e-3, clip=0.1)
+    ob = torch.optim.Adam(mb.parameters(), lr=1e-3)
+    la, lb = [], []
+    progs = set()
+    for step in range(3):
+        oa.zero_grad()
+        loss = crit(ma(x, caps[:, :-1], l1), targets)
+        loss.backward()
+        oa.step()
+        la.append(loss.item())
+        progs.add(id(ma._program_for(x)))
+        mb.zero_grad()
+        loss = crit(mb(x, caps[:, :-1], l1), targets)
+        loss.backward()
+        for p in mb.parameters():
+            p.grad.clamp_(-0.1, 0.1)
+        ob.step()
+        lb.append(loss.item())
+    assert len(progs) == 1                                      # the op program is refreshed in place, not rebuilt per step
+    assert la[0] == lb[0] and la[2] != la[0]
+    for a, b in zip(la, lb):
+        assert abs(a - b) < 2e-5, (la, lb)
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=0, atol=3e-6), (k, (pa - pb).abs().max().item())
+    # the stale-weights failure mode itself: a forward after the steps uses the CURRENT weights
+    with torch.no_grad():
+        fresh = build()
+        fresh.load_state_dict(ma.state_dict())
+        assert torch.allclose(ma(x, caps[:, :-1], l1), fresh(x, caps[:, :-1], l1), rtol=1e-5, atol=1e-6)

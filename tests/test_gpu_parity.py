@@ -633,3 +633,68 @@ def test_device_prefetcher_feeds_the_step_like_direct_copies():
         assert len(ahead) <= 3 and all(t.is_cuda for t in ahead)
         got3.append(ts3.step(im, cp, ln, next_images=ahead or None).item())
     assert got3 == ref and not model3.encoder._inflight
+
+
+def test_validation_forward_unshifted_captions_and_end_truncation_golden(golden_dir):
+    """The validation half of `evaluation` (eval.py:91-109) against G8 (the imported reference decoder): the drop-in
+    forward with UNSHIFTED captions and FULL lengths, its mean CE against `pack(captions, lengths)`, the greedy ids, and the
+    device-side '<end>' truncation counts (`sat_kept_tokens`)."""
+    g = load(golden_dir, "G8_dec_eval_unshifted.npz")
+    dec, params, (E, H, V, Lh, B, T) = golden_setup(g)
+    dec.eval()
+    feats, caps = torch.from_numpy(g["features"]).cuda(), torch.from_numpy(g["captions"]).cuda()
+    lengths = [int(x) for x in g["lengths"]]
+    with torch.no_grad():
+        logits = dec(feats, caps, lengths)                                    # eval.py:93
+        targets, pi = sat.pack_validation_targets(caps, lengths)             # eval.py:91
+        loss = sat.mean_cross_entropy(logits.contiguous(), targets)          # eval.py:95
+        ids = dec.sample(feats, None)                                         # eval.py:99
+    assert logits.shape == (sum(lengths), V)
+    assert np.array_equal(targets.cpu().numpy(), g["targets"])
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])
+    planted = torch.from_numpy(g["ids_planted"]).cuda()
+    kept = sat.kept_tokens(planted, int(g["end_id"]))
+    assert kept.dtype == torch.int32 and kept.cpu().tolist() == [int(x) for x in g["kept_tokens"]]
+    # a strided view (one hypothesis plane of beam ids [B,K,T]) and the host-side join of eval.py:101-110
+    beams = torch.stack([planted, planted.flip(1)], 1)
+    assert sat.kept_tokens(beams[:, 0], int(g["end_id"])).cpu().tolist() == [int(x) for x in g["kept_tokens"]]
+    words = {i: "w%d" % i for i in range(V)}
+    sents = sat.sentences(planted.cpu(), kept.cpu(), words)
+    assert sents[1] == "" and len(sents[0].split()) == 5 and len(sents[3].split()) == 20
+
+
+def test_validation_step_whole_model_eval_mode_vs_oracle():
+    """`validation_step` on the whole Show-and-Tell model in eval mode (eval.py:65: running statistics in every BatchNorm):
+    loss and greedy ids against the oracle (encoder f32 eval + `validation_loss` + `greedy_sample`)"""
+    E, H, V, Lh, B, T = 32, 64, 120, 1, 5, 9
+    gen = torch.Generator().manual_seed(77)
+    ep, eb = OE.init_encoder_params(E, TINY, generator=gen, randomize_bn=True)
+    for k in eb:                                         # non-trivial running statistics
+        if k.endswith("running_mean"):
+            eb[k] = torch.randn(eb[k].shape, generator=gen) * 0.1
+        elif k.endswith("running_var"):
+            eb[k] = torch.rand(eb[k].shape, generator=gen) + 0.5
+    dp = OD.init_decoder_params(E, H, V, Lh, generator=gen)
+    model = sat.ShowAndTell(E, H, V, Lh, arch=TINY, compute_dtype="f32")
+    model.encoder.load_state_dict({**ep, **eb})
+    model.decoder.load_state_dict(dp)
+    model.cuda().eval()
+    images = torch.randn(B, 3, 64, 64, generator=gen)
+    lengths = [9, 9, 7, 4, 2]
+    caps = torch.zeros(B, T, dtype=torch.long)
+    for b, l in enumerate(lengths):
+        caps[b, 0] = 1
+        caps[b, 1:l - 1] = torch.randint(4, V, (max(l - 2, 0),), generator=gen)
+        caps[b, l - 1] = 2
+    out = sat.validation_step(model, images.cuda(), caps.cuda(), lengths, end_id=2)
+    bufs = {k: v.clone() for k, v in eb.items()}
+    feats = OE.encoder_forward(ep, bufs, images, TINY, training=False)
+    ref_loss, _ = OT.validation_loss(dp, feats, caps, lengths, Lh)
+    ref_ids = OD.greedy_sample(dp, feats, Lh)
+    assert abs(out["loss"].item() - ref_loss.item()) < 1e-4
+    assert torch.equal(out["ids"].cpu(), ref_ids)
+    assert out["kept"].cpu().tolist() == OT.kept_tokens(ref_ids, 2)
+    with pytest.raises(RuntimeError):
+        sat.validation_step(model.train(), images.cuda(), caps.cuda(), lengths)

@@ -126,3 +126,18 @@ def test_batch_sizes_and_errors():
     assert OD.batch_sizes([5, 3, 3, 1]) == [4, 3, 3, 1, 1]
     with pytest.raises(AssertionError):
         OD.batch_sizes([3, 5])
+
+
+def test_validation_forward_unshifted_captions_and_end_truncation(golden_dir):
+    """eval.py:91-109 (G8, from the imported reference decoder): CE of `model(images, captions, lengths)` against
+    `pack(captions, lengths)` -- captions unshifted, lengths full -- greedy ids, and the '<end>' truncation counts"""
+    g = load(golden_dir, "G8_dec_eval_unshifted.npz")
+    params, (E, H, V, L, B, T) = params_from_seed(g)
+    feats, caps = torch.from_numpy(g["features"]), torch.from_numpy(g["captions"])
+    lengths = [int(x) for x in g["lengths"]]
+    loss, logits = OT.validation_loss(params, feats, caps, lengths, L)
+    assert logits.shape[0] == sum(lengths)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=2e-6)
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    assert np.array_equal(OD.greedy_sample(params, feats, L).numpy(), g["greedy_ids"])
+    assert OT.kept_tokens(torch.from_numpy(g["ids_planted"]), int(g["end_id"])) == [int(x) for x in g["kept_tokens"]]

@@ -39,7 +39,10 @@ def last_step(d, counter):
 
 def main():
     f, w = last_step(sys.argv[1], "FETCH_SIZE"), last_step(sys.argv[2], "WRITE_SIZE")
-    out = {"_note": "one training step of bench.py (cfg2); bytes = FETCH_SIZE_KB x 1024 x 2 (gfx950 correction) + WRITE_SIZE_KB x 1024",
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "show-and-tell_amd", "libsat_hip.so")
+    out = {"libsat_hip_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],      # bench.py quotes the file only for this build
+           "_note": "one training step of bench.py (cfg2); bytes = FETCH_SIZE_KB x 1024 x 2 (gfx950 correction) + WRITE_SIZE_KB x 1024",
            "kernels": {}}
     tot = 0.0
     for k in sorted(f, key=lambda k: -(f[k][1] * 2 + w.get(k, [0, 0.0])[1])):

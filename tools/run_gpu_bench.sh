@@ -13,12 +13,12 @@ cat gpurun_out/bench.json; tail -n 5 gpurun_out/bench.err
 if [ $rc -ne 0 ]; then echo "bench failed rc=$rc"; exit $rc; fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 14 --warmup 3 --no-cpu-baseline --no-f32-mode > $R/gpurun_out/prof_run.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 14 --warmup 3 --no-cpu-baseline --no-f32-mode --repeats 1 > $R/gpurun_out/prof_run.log 2>&1
 rc=$?
 tail -n 3 $R/gpurun_out/prof_run.log
 # the same command with strictly sequential steps (--no-lookahead): per-launch spans there are the kernels alone
 rm -rf $R/gpurun_out/prof_seq
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_seq -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-mode --no-lookahead > $R/gpurun_out/prof_seq_run.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_seq -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-mode --no-lookahead --repeats 1 > $R/gpurun_out/prof_seq_run.log 2>&1
 tail -n 1 $R/gpurun_out/prof_seq_run.log | cut -c1-200
 ft=$(find $R/gpurun_out/prof -name "*kernel_trace.csv" | head -1)
 [ -n "$ft" ] && python3 $R/tools/overlap_summary.py "$ft" > $R/gpurun_out/overlap_summary.txt 2>&1; cat $R/gpurun_out/overlap_summary.txt
