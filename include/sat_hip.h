@@ -264,6 +264,25 @@ int sat_vocab_logits_fwd(const float* Hs /*[N,H]*/, const float* w /*[V,H]*/, co
  * d(loss)/d(logits) = (softmax - onehot) * inv_denom. */
 int sat_ce_rows(float* logits /*[N,ldl]*/, int64_t ldl, const int64_t* targets /*[N]*/, int N, int V, float inv_denom,
                 int write_grad, float* row_loss /*[N]*/, float* loss_out /*[1]*/, sat_stream_t stream);
+/* ---- bf16 THROUGHPUT mode of the vocab projection and its backward (models.py:53, train.py:143-144; BASELINE configs[1]
+ * names bf16): the three GEMMs run on v_mfma_f32_32x32x16_bf16 with f32 accumulate from bf16 COPIES of Hs / W / d(logits)
+ * made per step inside `workspace`; logits, CE arithmetic, bias gradient, all outputs and the master weights stay f32.
+ * d(loss)/d(logits) exists only as bf16, in the workspace, between the two calls.  Needs H % 64 == 0, V % 4 == 0,
+ * V <= 12288 (SAT_ERR_UNSUPPORTED otherwise: use sat_vocab_logits_fwd / sat_ce_rows / sat_vocab_ce_bwd).
+ * sat_vocab_ce_fwd_bf16: logits[N,ldl] = Hs W^T + b; row_loss[n] = lse - logit[target]; loss_out[0] = inv_denom * sum.
+ * sat_vocab_ce_bwd_bf16: dw[V,H] = G^T Hs, db[V] = colsum(G), dHs[N,H] = G W with G = (softmax - onehot) * inv_denom. */
+int64_t sat_vocab_bf16_ws_bytes(int N, int H, int V);     /* 0: shape unsupported */
+int sat_vocab_ce_fwd_bf16(const float* Hs /*[N,H]*/, const float* w /*[V,H]*/, const float* b /*[V]*/, const int64_t* targets /*[N]*/,
+                          int N, int H, int V, float inv_denom, float* logits /*[N,ldl]*/, int64_t ldl, float* row_loss /*[N]*/,
+                          float* loss_out /*[1] or NULL*/, void* workspace /*256-byte aligned*/, int64_t ws_bytes, sat_stream_t stream);
+int sat_vocab_ce_bwd_bf16(int N, int H, int V, float* dw /*[V,H]*/, float* db /*[V]*/, float* dHs /*[N,H]*/, void* workspace,
+                          int64_t ws_bytes, sat_stream_t stream);
+/* the kernel under them: C[M,N] f32 = A[M,K] B[N,K]^T (+ bias[N]); A, B bf16 with K contiguous, K % 64 == 0 (zero padded),
+ * N % 4 == 0, lda / ldb % 8 == 0.  ksplit > 1: K slice z writes C + z * slab_stride, no bias (sum with sat_sum_slabs_f32). */
+int sat_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                     int M, int N, int K, int ksplit, int64_t slab_stride, sat_stream_t stream);
+/* out bf16 [C][ldo] = in^T for in f32 [R][ldi]; columns [R, ldo) zero (ldo % 4 == 0) */
+int sat_transpose_f32_bf16(const float* in, int64_t ldi, int R, int C, void* out, int64_t ldo, sat_stream_t stream);
 /* FUSED vocab projection + cross entropy (models.py:53 + train.py:53,143): the projection GEMM's epilogue emits per-row
  * (max, sum exp) partials next to the logits, a small combine kernel turns them into lse[n] and row_loss[n] = lse - logit[target]
  * (it reads ONE logit per row), loss_out[0] = inv_denom * sum(row_loss).  The logits are written once and never re-read by

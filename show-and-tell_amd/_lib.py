@@ -90,6 +90,11 @@ SIGNATURES = {
     "sat_vocab_ce_fwd_ws_bytes": (_i64, [_i, _i]),
     "sat_vocab_ce_bwd_fused": (_i, [_vp, _i64, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_vocab_ce_bwd_fused_ws_bytes": (_i64, [_i, _i, _i]),
+    "sat_vocab_bf16_ws_bytes": (_i64, [_i, _i, _i]),
+    "sat_vocab_ce_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "sat_vocab_ce_bwd_bf16": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sat_gemm_bf16_nt": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i64, _vp]),
+    "sat_transpose_f32_bf16": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp]),
     "sat_vocab_ce_bwd": (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_vocab_ce_bwd_ws_bytes": (_i64, [_i, _i, _i]),
     "sat_gemm_f32_splitk": (_i, [_i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i64, _vp]),

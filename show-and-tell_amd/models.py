@@ -435,6 +435,13 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
         inp = HS
     if logits is None:
         logits = torch.zeros(N, (V + 3) // 4 * 4, device=dev) if V % 4 else torch.empty(N, V, device=dev)
+    if ce is not None and ce.get("kind") == "bf16":
+        # bf16 throughput mode: the projection on the bf16 matrix pipe (f32 accumulate, f32 logits), CE in f32 from them,
+        # d(loss)/d(logits) left as bf16 in the workspace for decoder_backward_tapes
+        L.check(lib.sat_vocab_ce_fwd_bf16(L.ptr(inp), L.ptr(lin_w), L.ptr(lin_b), L.ptr(ce["targets"]), N, lin_w.shape[1], V,
+                                          float(ce["inv_denom"]), L.ptr(logits), logits.stride(0), L.ptr(ce["row_loss"]),
+                                          L.ptr(ce["loss_out"]), L.ptr(ce["ws"]), ce["ws"].numel(), st), "sat_vocab_ce_fwd_bf16")
+        return logits, tapes
     if ce is not None:
         L.check(lib.sat_vocab_ce_fwd(L.ptr(inp), L.ptr(lin_w), L.ptr(lin_b), L.ptr(ce["targets"]), N, lin_w.shape[1], V,
                                      float(ce["inv_denom"]), L.ptr(logits), logits.stride(0), L.ptr(ce["lse"]), L.ptr(ce["row_loss"]),
@@ -456,7 +463,10 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
     V, Hl = lin_w.shape
     Xtop = tapes["X"][-1]
     dH = torch.empty(N, Hl, device=dev)
-    if ce is not None:
+    if ce is not None and ce.get("kind") == "bf16":
+        L.check(lib.sat_vocab_ce_bwd_bf16(N, Hl, V, L.ptr(grads_out["lin_w"]), L.ptr(grads_out["lin_b"]), L.ptr(dH), L.ptr(ce["ws"]),
+                                          ce["ws"].numel(), st), "sat_vocab_ce_bwd_bf16")
+    elif ce is not None:
         # `dlogits` holds the LOGITS: d(loss)/d(logits) is formed inside the two gradient GEMMs' operand loads (never stored)
         vwsb = lib.sat_vocab_ce_bwd_fused_ws_bytes(N, Hl, V)
         vws = torch.empty(max(vwsb // 4, 4), device=dev)

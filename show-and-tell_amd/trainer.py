@@ -28,6 +28,10 @@ import os as _os
 # colsum 15 us), while exp() in the epilogue / operand path costs the three GEMMs +65 / +113 / +49 us (6.94 vs 6.70 ms/step,
 # profiles/r02_fused_ce_ab.txt).  Default: logits -> sat_ce_rows (gradient in place) -> sat_vocab_ce_bwd.
 _FUSED_CE = _os.environ.get("SAT_FUSED_CE", "0") == "1"
+# bf16 throughput mode (compute_dtype="bf16", BASELINE configs[1]): the vocab projection and its two gradient GEMMs run on the
+# bf16 matrix pipe from per-step bf16 operand copies (sat_gemm_bf16.hip; f32 accumulate, f32 logits / CE / outputs / master
+# weights).  SAT_DECODER_BF16=0 keeps them exact-f32 as in the parity mode (round 2's behaviour: 0.39 ms/step instead of ~0.1).
+_DECODER_BF16 = _os.environ.get("SAT_DECODER_BF16", "1") != "0"
 
 
 def lr_for_epoch(epoch, learning_rate=1e-3, decay_start=1, decay_every=3, decay_rate=0.8):
@@ -98,6 +102,8 @@ class TrainStep:
         self.buckets = self.flat.buckets
         self.flat_grad = self.flat.grads
         self._bufs = {}
+        # "bf16": vocab projection + its gradient GEMMs on the bf16 matrix pipe (the throughput mode); "f32": exact-f32 MFMA
+        self.decoder_gemm_dtype = "bf16" if (_DECODER_BF16 and model.encoder.compute_dtype == "bf16") else "f32"
         self._params_list = [p for _, p in self._trainable()]
 
     # -- encoder look-ahead ---------------------------------------------------------------------------
@@ -187,8 +193,15 @@ class TrainStep:
         layers = [dec.lstm.layer(l) for l in range(dec.num_layers)]
         loss_slot = flat.grads[flat.loss_slot:flat.loss_slot + 1]
         ce = None
-        if _FUSED_CE:          # projection + CE as one op; the backward forms d(loss)/d(logits) inside its GEMMs
-            ce = dict(targets=bufs["targets"], inv_denom=inv_denom, lse=bufs["lse"], row_loss=bufs["row_loss"], loss_out=loss_slot,
+        if self.decoder_gemm_dtype == "bf16":
+            wsb = lib.sat_vocab_bf16_ws_bytes(N, dec.hidden_size, V)
+            if wsb > 0:
+                if "vocab_bf16_ws" not in bufs:
+                    bufs["vocab_bf16_ws"] = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                ce = dict(kind="bf16", targets=bufs["targets"], inv_denom=inv_denom, row_loss=bufs["row_loss"], loss_out=loss_slot,
+                          ws=bufs["vocab_bf16_ws"])
+        if ce is None and _FUSED_CE:          # projection + CE as one op; the backward forms d(loss)/d(logits) inside its GEMMs
+            ce = dict(kind="fused", targets=bufs["targets"], inv_denom=inv_denom, lse=bufs["lse"], row_loss=bufs["row_loss"], loss_out=loss_slot,
                       ws=bufs["ce_ws"])
         logits, tapes = decoder_forward_tapes(lib, feats_in, dec.embed.weight, layers, dec.linear.weight,
                                               dec.linear.bias, captions[:, :-1], pi, logits=bufs["logits"], ce=ce)

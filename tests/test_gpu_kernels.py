@@ -945,3 +945,76 @@ def test_wide_tile_output_stores_are_stable_over_many_launches(lib, variant):
             assert (out.float().cpu().double() - ref).abs().max().item() < 2e-2
         else:
             assert torch.equal(out, first), rep
+
+
+@pytest.mark.parametrize("M,N,K,ks,bias", [(128, 128, 64, 1, False), (200, 260, 192, 1, True), (1216, 1000, 512, 1, True),
+                                           (300, 512, 1280, 3, False), (77, 64, 4096, 16, False)])
+def test_gemm_bf16_nt_vs_f64_of_the_same_bf16_operands(lib, M, N, K, ks, bias):
+    """`sat_gemm_bf16_nt` (the bf16-mode vocab GEMMs, models.py:53): C = A B^T (+ bias), f32 accumulate of exact bf16 products --
+    tile tails in M and N, short and long K, split-K slabs"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    B = torch.randn(N, K, generator=g).bfloat16()
+    b = torch.randn(N, generator=g) if bias else None
+    ref = A.double() @ B.double().t() + (b.double() if bias else 0.0)
+    Ad, Bd = cu(A), cu(B)
+    nsl = -(-(K // 64) // (-(-(K // 64) // ks)))
+    out = torch.full((nsl, M, N), float("nan"), device="cuda")
+    bd = cu(b) if bias else None
+    L.check(lib.sat_gemm_bf16_nt(Ad.data_ptr(), K, Bd.data_ptr(), K, out.data_ptr(), N, L.ptr(bd), M, N, K, ks, M * N, st()))
+    sync()
+    got = out.double().sum(0).cpu() if ks > 1 else out[0].double().cpu()
+    assert torch.isfinite(got).all()
+    tol = 2e-6 * (A.abs().double() @ B.abs().double().t()).max().item() * max(1.0, (K / 512) ** 0.5) + 1e-5
+    assert (got - ref).abs().max().item() < tol, ((got - ref).abs().max().item(), tol)
+
+
+@pytest.mark.parametrize("N,H,V", [(200, 128, 1000), (76, 64, 500), (1216, 512, 10000)])
+def test_vocab_ce_bf16_path_vs_exact_f32_path(lib, N, H, V):
+    """bf16 throughput mode of the vocab projection + CE + its backward (`sat_vocab_ce_fwd_bf16` / `_bwd_bf16`) against the
+    exact-f32 kernels of the parity mode on the same inputs: logits to bf16 operand rounding, mean CE 1e-3, gradients 1 %
+    relative L2 (train.py:143-144)"""
+    g = torch.Generator().manual_seed(N + V)
+    Hs = cu(torch.tanh(torch.randn(N, H, generator=g)))
+    W = cu(torch.empty(V, H).uniform_(-0.1, 0.1, generator=g))
+    b = cu(torch.randn(V, generator=g) * 0.01)
+    tg = cu(torch.randint(0, V, (N,), generator=g))
+    inv = 1.0 / N
+    ldl = V
+    # exact-f32 reference path
+    lg32 = torch.empty(N, ldl, device="cuda")
+    L.check(lib.sat_vocab_logits_fwd(Hs.data_ptr(), W.data_ptr(), b.data_ptr(), N, H, V, lg32.data_ptr(), ldl, st()))
+    rl32, loss32 = torch.empty(N, device="cuda"), torch.zeros(1, device="cuda")
+    logits32 = lg32.clone()
+    L.check(lib.sat_ce_rows(lg32.data_ptr(), ldl, tg.data_ptr(), N, V, inv, 1, rl32.data_ptr(), loss32.data_ptr(), st()))
+    wsb = lib.sat_vocab_ce_bwd_ws_bytes(N, H, V)
+    ws = torch.empty(max(wsb // 4, 4), device="cuda")
+    dW32, db32, dH32 = torch.empty(V, H, device="cuda"), torch.empty(V, device="cuda"), torch.empty(N, H, device="cuda")
+    L.check(lib.sat_vocab_ce_bwd(lg32.data_ptr(), ldl, Hs.data_ptr(), W.data_ptr(), N, H, V, dW32.data_ptr(), db32.data_ptr(), dH32.data_ptr(),
+                                 ws.data_ptr(), wsb, st()))
+    # bf16 path
+    wb = lib.sat_vocab_bf16_ws_bytes(N, H, V)
+    assert wb > 0
+    wsb16 = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    lg16 = torch.full((N, ldl), float("nan"), device="cuda")
+    rl16, loss16 = torch.empty(N, device="cuda"), torch.zeros(1, device="cuda")
+    L.check(lib.sat_vocab_ce_fwd_bf16(Hs.data_ptr(), W.data_ptr(), b.data_ptr(), tg.data_ptr(), N, H, V, inv, lg16.data_ptr(), ldl,
+                                      rl16.data_ptr(), loss16.data_ptr(), wsb16.data_ptr(), wb, st()))
+    dW16, db16, dH16 = (torch.full((V, H), float("nan"), device="cuda"), torch.full((V,), float("nan"), device="cuda"),
+                        torch.full((N, H), float("nan"), device="cuda"))
+    L.check(lib.sat_vocab_ce_bwd_bf16(N, H, V, dW16.data_ptr(), db16.data_ptr(), dH16.data_ptr(), wsb16.data_ptr(), wb, st()))
+    sync()
+    for t in (lg16, dW16, db16, dH16, loss16):
+        assert torch.isfinite(t).all()
+    # logits: bf16-rounded operands, f32 accumulate == f64 product of the rounded operands
+    ref = (Hs.bfloat16().double() @ W.bfloat16().double().t() + b.double()).cpu()
+    assert (lg16.double().cpu() - ref).abs().max().item() < 1e-5
+    assert (lg16 - logits32).abs().max().item() < 2e-2
+    assert abs(loss16.item() - loss32.item()) < 1e-3
+
+    def rel(a, c):
+        return ((a - c).norm() / c.norm()).item()
+    print("bf16 vocab path N=%d H=%d V=%d: |dCE| %.2e, rel-L2 dW %.2e db %.2e dHs %.2e"
+          % (N, H, V, abs(loss16.item() - loss32.item()), rel(dW16, dW32), rel(db16, db32), rel(dH16, dH32)))
+    assert rel(dW16, dW32) < 1e-2 and rel(db16, db32) < 1e-2 and rel(dH16, dH32) < 1e-2
+    assert lib.sat_vocab_bf16_ws_bytes(N, 100, V) == 0 and lib.sat_vocab_bf16_ws_bytes(N, H, 20000) == 0      # unsupported shapes say so
