@@ -152,6 +152,17 @@ typedef struct sat_op {
     int64_t ldc;
 } sat_op;
 #define SAT_CONV_PADW 2
+/* Two-pass conv with output-side BatchNorm (training, bf16; the expansion conv of a bottleneck, models.py:27):
+ *   pass 1, flags | SAT_CONV_STATS_ONLY: the conv runs, its BatchNorm sums leave as usual (stat_acc / stat_partial), and NO
+ *     output tile is written;
+ *   pass 2, flags | SAT_CONV_OUT_BN: the same conv again; `stat_acc` is now READ (this step's parity) and gamma / beta /
+ *     running_mean / running_var / count / momentum / eps describe the OUTPUT's BatchNorm: the epilogue derives (scale, shift)
+ *     as SAT_OP_BN_ADD_RELU would, stores out = [relu (flags bit 0)](bf16(conv) * scale + shift [+ in1]) -- bit-identical to
+ *     conv -> SAT_OP_BN_ADD_RELU -- updates the running statistics and clears the other parity.
+ * The raw conv tensor never exists in memory: one write and one read of it, and the normalise + add launch, are traded for a
+ * second pass over a short-K conv whose operands sit in the L2. */
+#define SAT_CONV_STATS_ONLY 4
+#define SAT_CONV_OUT_BN 8
 
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
 /* same, with the step parity (0/1) that selects the half of every stat_acc buffer in use */

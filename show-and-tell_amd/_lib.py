@@ -17,6 +17,7 @@ OP_BN_EVAL_BATCH = 8
 OP_MAXPOOL2 = 9
 OP_MAXPOOL3S2, OP_AVGPOOL3 = 10, 11
 CONV_PADW = 2
+CONV_STATS_ONLY, CONV_OUT_BN = 4, 8
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

@@ -67,6 +67,19 @@ struct ConvArgs {
     const float* out_shift;
     const bf16_t* residual;  // [M][ldc] like C, or NULL
     int out_relu;
+    // Output-side BatchNorm with BATCH statistics (training, second pass of a two-pass conv3: SAT_CONV_OUT_BN): the statistics
+    // of THIS conv's output were accumulated by an earlier stats-only launch of the same conv (SAT_CONV_STATS_ONLY) into
+    // out_acc; the epilogue derives (scale, shift) from them exactly as the normalise+add kernel would (bn_table_from_acc) and
+    // stores out = [relu](bf16(acc) * scale + shift [+ residual]) -- the raw conv tensor never exists in memory and the separate
+    // normalise + add + ReLU launch (one read of it, one read of the residual, one write) disappears.
+    const long long* out_acc;     // [shards][2][N], this step's parity, or NULL
+    long long* out_acc_clear;     // other parity (cleared by the tile_m == 0 workgroups) or NULL
+    int out_shards;
+    const float* out_gamma;
+    const float* out_beta;
+    float* out_running_mean;
+    float* out_running_var;
+    int stats_only;          // SAT_CONV_STATS_ONLY: the launch ends after the statistics (no output tile is staged or stored)
     // Dual-source input (1x1 convs, training): the A operand is y = relu(A*in_scale + in_shift + R) -- the previous
     // bottleneck's bn3 + residual add + ReLU (models.py:27, torchvision Bottleneck.forward's `out += identity; relu`)
     // applied to each landed LDS stage from TWO LDS-DMA sources (A = raw conv3 output, R = the block input), so the
@@ -75,7 +88,7 @@ struct ConvArgs {
     const bf16_t* R;
     bf16_t* Y;
     long ldy;
-    int dbg;                 // diagnostics only (SAT_CONV_DBG): 1 = no loads, 2 = no MFMA, 4 = no epilogue
+    int dbg;                 // diagnostics only (SAT_CONV_DBG): 1 = no loads, 2 = no MFMA, 4 = no epilogue, 8 = expansion (1x1, N = 4 Cin) convs store nothing
 };
 // fixed-point scale of the atomic statistics is SAT_STAT_SCALE (sat_internal.h)
 constexpr double kStatScale = SAT_STAT_SCALE;
@@ -679,6 +692,61 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             }
         }
     }
+    if (p.stats_only) {      // first pass of a two-pass conv: the statistics are all this launch produces
+        if (p.stat_partial) {
+            __syncthreads();
+            for (int c = tid; c < BN; c += NT) {
+                const int col = n0 + c;
+                if (col < p.N) {
+                    float s = 0.0f, q = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < WGM; ++g) {
+                        s += red[(g * 2 + 0) * BN + c];
+                        q += red[(g * 2 + 1) * BN + c];
+                    }
+                    p.stat_partial[((long)tile_m * 2 + 0) * p.N + col] = s;
+                    p.stat_partial[((long)tile_m * 2 + 1) * p.N + col] = q;
+                }
+            }
+        }
+        return;
+    }
+    // second pass of a two-pass conv: (scale, shift) of the OUTPUT's BatchNorm from the integer sums the first pass left --
+    // the arithmetic of bn_table_from_acc, one lane per column; table in LDS behind the C tile (no statistics leave this launch)
+    const bool out_bn = p.out_acc != nullptr;
+    if (out_bn && is_consumer && wm == 0 && h == 0) {
+        const double inv = 1.0 / (kStatScale * p.in_count);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int lc = wn * WN + j * 32 + r, col = n0 + lc;
+            if (col < p.N) {
+                long long s1 = 0, s2 = 0;
+                for (int sh = 0; sh < p.out_shards; ++sh) {
+                    s1 += p.out_acc[(long)sh * 2 * p.N + col];
+                    s2 += p.out_acc[(long)sh * 2 * p.N + p.N + col];
+                }
+                const double mean = (double)s1 * inv;
+                double var = (double)s2 * inv - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float invstd = 1.0f / sqrtf((float)var + p.in_eps);
+                const float sc = p.out_gamma[col] * invstd;
+                red[lc] = sc;
+                red[BN + lc] = p.out_beta[col] - (float)mean * sc;
+                if (tile_m == 0) {
+                    if (p.out_running_mean) {
+                        const double unbiased = p.in_count > 1.0 ? var * p.in_count / (p.in_count - 1.0) : var;
+                        p.out_running_mean[col] = (float)((1.0 - p.in_momentum) * p.out_running_mean[col] + p.in_momentum * (double)(float)mean);
+                        p.out_running_var[col] = (float)((1.0 - p.in_momentum) * p.out_running_var[col] + p.in_momentum * (double)(float)unbiased);
+                    }
+                    if (p.out_acc_clear)
+                        for (int sh = 0; sh < p.out_shards; ++sh) {
+                            p.out_acc_clear[(long)sh * 2 * p.N + col] = 0;
+                            p.out_acc_clear[(long)sh * 2 * p.N + p.N + col] = 0;
+                        }
+                }
+            }
+        }
+    }
     // ---- epilogue 2: bf16 C tile through LDS (C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ----
     if (is_consumer)
 #pragma unroll
@@ -715,13 +783,32 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         }
     }
     constexpr int CPR = BN / 8;                  // 16-byte chunks per C row
+    if ((p.dbg & 8) && p.KH == 1 && p.N == 4 * p.Cin) return;      // diagnostics: what a bottleneck would cost without its raw conv3 tensor
 #pragma unroll
     for (int it = 0; it < BM * CPR / NT; ++it) {
         const int qid = tid + it * NT;
         const int row = qid / CPR, cc = qid - row * CPR;
         const int grow = m0 + row, gcol = n0 + cc * 8;
         if (grow < p.M && gcol < p.N) {           // N % 8 == 0: a chunk is all in or all out
-            if (p.residual) {                     // out = [relu](affine(acc) + residual), 16 bytes of each per thread
+            if (out_bn) {
+                // the normalise (+ add) + ReLU kernel's arithmetic on the bf16-rounded conv output, from LDS: bit-identical to
+                // conv -> store -> bn_act_kernel (x * scale + shift + z, ReLU, one rounding)
+                const bf16x8 c = *(const bf16x8*)(smem + row * CROW + cc * 16);
+                const f32x4 s0 = *(const f32x4*)(red + cc * 8), s1 = *(const f32x4*)(red + cc * 8 + 4);
+                const f32x4 t0 = *(const f32x4*)(red + BN + cc * 8), t1 = *(const f32x4*)(red + BN + cc * 8 + 4);
+                bf16x8 z;
+                if (p.residual) z = *(const bf16x8*)(p.residual + (long)grow * p.ldc + gcol);
+                bf16x8 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v0 = (float)c[k] * s0[k] + t0[k], v1 = (float)c[k + 4] * s1[k] + t1[k];
+                    if (p.residual) { v0 += (float)z[k]; v1 += (float)z[k + 4]; }
+                    if (p.out_relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+                    o[k] = (bf16_t)v0;
+                    o[k + 4] = (bf16_t)v1;
+                }
+                store16_wt(p.C + (long)grow * p.ldc + gcol, *(const u32x4*)&o);
+            } else if (p.residual) {              // out = [relu](affine(acc) + residual), 16 bytes of each per thread
                 const bf16x8 c = *(const bf16x8*)(smem + row * CROW + cc * 16);
                 const bf16x8 z = *(const bf16x8*)(p.residual + (long)grow * p.ldc + gcol);
                 bf16x8 o;
@@ -847,6 +934,15 @@ ConvArgs make_args(const sat_op* op) {
         a.in_count = (double)op->count; a.in_momentum = op->momentum; a.in_eps = op->eps;
     }
     a.out_scale = op->scale1; a.out_shift = op->shift1;        // inference epilogue: affine (+ residual) (+ ReLU)
+    a.stats_only = (op->flags & SAT_CONV_STATS_ONLY) ? 1 : 0;
+    if (op->flags & SAT_CONV_OUT_BN) {                         // second pass of a two-pass conv: stat_acc is READ here
+        a.acc = nullptr; a.stat_partial = nullptr;
+        a.out_acc = (const long long*)op->stat_acc;
+        a.out_shards = op->stat_shards > 1 ? op->stat_shards : 1;
+        a.out_gamma = op->gamma; a.out_beta = op->beta;
+        a.out_running_mean = op->running_mean; a.out_running_var = op->running_var;
+        a.in_count = (double)op->count; a.in_momentum = op->momentum; a.in_eps = op->eps;
+    }
     if (op->out1) {                                            // dual-source A: in1 is the residual SOURCE, out1 the side output
         a.R = (const bf16_t*)op->in1; a.Y = (bf16_t*)op->out1; a.ldy = op->Cin;
     } else {
@@ -901,8 +997,17 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
     ConvArgs a = make_args(op);
     if ((a.acc_shards & (a.acc_shards - 1)) || a.acc_shards > 8 || (a.in_shards & (a.in_shards - 1)) || a.in_shards > 8) return SAT_ERR_ARG;
     if (a.acc) a.acc += (long)parity * a.acc_shards * 2 * a.N;          // [2 parities][shards][2][N]
+    if (a.out_acc) {
+        if (!a.out_gamma || !a.out_beta || a.in_count < 1 || a.out_scale || (a.out_shards & (a.out_shards - 1)) || a.out_shards > 8)
+            return SAT_ERR_ARG;
+        long long* base = (long long*)op->stat_acc;
+        a.out_acc = base + (long)parity * a.out_shards * 2 * a.N;
+        a.out_acc_clear = base + (long)(1 - parity) * a.out_shards * 2 * a.N;
+        if (a.residual && (const void*)a.residual == (const void*)a.C) return SAT_ERR_ARG;
+    }
+    if (a.stats_only && !(a.acc || a.stat_partial)) return SAT_ERR_ARG;
     if ((a.out_scale != nullptr) != (a.out_shift != nullptr)) return SAT_ERR_ARG;
-    if (a.residual && (!a.out_scale || (const void*)a.residual == (const void*)a.C)) return SAT_ERR_ARG;
+    if (a.residual && !a.out_acc && (!a.out_scale || (const void*)a.residual == (const void*)a.C)) return SAT_ERR_ARG;
     if (a.out_scale && (a.stat_partial || a.acc)) return SAT_ERR_ARG;     // batch statistics and a fixed affine exclude each other
     if (a.R) {
         // dual-source A: needs the input affine (the previous bn3), a dense 1x1 geometry and room for the table
@@ -971,7 +1076,8 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
         if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) continue;
         const Key key(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
                       ((op->stat_partial || op->stat_acc) ? 1 : 0) + ((op->scale0 || op->stat_acc1) ? 2 : 0) +
-                          (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0) + (op->out1 ? 16 : 0));
+                          (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0) + (op->out1 ? 16 : 0) + ((op->flags & SAT_CONV_OUT_BN) ? 32 : 0) +
+                          ((op->flags & SAT_CONV_STATS_ONLY) ? 64 : 0));
         {
             std::lock_guard<std::mutex> lk(cache_mu);
             auto it = cache.find(key);
@@ -979,6 +1085,10 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
         }
         ConvArgs a = make_args(op);
         a.acc = nullptr;             // tuning launches must not touch the statistics / running buffers
+        if (a.out_acc) {             // ... output-side BatchNorm: read this step's sums as they are, update / clear nothing
+            a.out_acc = (const long long*)op->stat_acc;
+            a.out_acc_clear = nullptr; a.out_running_mean = nullptr; a.out_running_var = nullptr;
+        }
         if (a.in_affine) {           // ... nor derive from / clear the live accumulators: the neutral table stands in
             a.in_acc = nullptr; a.in_acc_clear = nullptr; a.in_running_mean = nullptr;
             a.in_scale = scratch; a.in_shift = scratch + kTuneTab;

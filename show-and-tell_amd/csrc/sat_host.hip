@@ -25,9 +25,12 @@ extern "C" int sat_run_ops(const sat_op* ops, int n_ops, sat_stream_t stream) {
 extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_stream_t stream) {
     if (!ops || n_ops < 0 || (parity != 0 && parity != 1)) return SAT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    // diagnostics only (timing experiments; results are then garbage): SAT_DBG_SKIP_BN_ADD=1 drops every normalise + add + ReLU launch
+    static const int skip_bn_add = getenv("SAT_DBG_SKIP_BN_ADD") ? atoi(getenv("SAT_DBG_SKIP_BN_ADD")) : 0;
     for (int i = 0; i < n_ops; ++i) {
         const sat_op* op = ops + i;
         int rc;
+        if (skip_bn_add && op->kind == SAT_OP_BN_ADD_RELU) continue;
         switch (op->kind) {
             case SAT_OP_IMAGE_PREP: rc = sat_image_prep_launch(op, s); break;
             case SAT_OP_CONV: rc = sat_conv_launch(op, parity, s); break;

@@ -363,6 +363,15 @@ class ConvStackProgram:
         # separate kernel streams at 5.5 TB/s from 2048 workgroups then has to come through 196 workgroups' LDS rings
         # (2.6 TB/s: bytes in flight per CU), which costs the conv what the removed launch saved.
         fuse_resid = training and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_RESIDUAL", "0") == "1"
+        # TWO-PASS conv3 (bf16 training, identity-residual bottlenecks), OPT-IN (SAT_CONV3_TWOPASS=1): conv3 runs once for its
+        # BatchNorm statistics only (no output), then again with bn3 + residual add + ReLU in its epilogue (scale / shift derived
+        # from the sums of pass 1).  The raw conv3 tensor is never written or re-read and the normalise+add launch disappears
+        # (a layer-3 bottleneck's memory traffic drops from ~167 to ~122 MB); bit-identical to the three-launch form (tested).
+        # Built because with several stacks in flight the step is bound by memory traffic (tools/run_gpu_traffic_probe.sh: without
+        # the normalise+add launches a step takes 3.84 instead of 4.78 ms), and MEASURED A LOSS: the statistics-only pass costs
+        # 17.7 us of the conv's 22 (the store is the smaller part of a K = 256 conv with its fused input BatchNorm), the second
+        # pass 25.3, together 43 us against 22 + 16 for conv + normalise+add: 4.95 vs 4.85 ms/step (profiles/r03_twopass_ab.txt).
+        two_pass = training and dtype == L.SAT_BF16 and not fuse_resid and os.environ.get("SAT_CONV3_TWOPASS", "0") == "1"
         pending = None          # (s3, t3, resid buffer) of the previous block when its bn_add is deferred to this conv1
         blocks_geo = list(zip(stack.blocks(), geo))
         for bi, (blk, (h, w_, h2, w2, inpl, planes, stride)) in enumerate(blocks_geo):
@@ -441,8 +450,31 @@ class ConvStackProgram:
             else:
                 ops.append(act_op(L.OP_BN_RELU, self.c2, s2, t2, self.a2, N, h2, w2, planes))
                 ops.append(std_conv(blk.conv3, self.a2, self.c3, N, h2, w2, h2, w2))
+            cv3_first = ops[-1]
             f, s3, t3 = fin_op(blk.bn3, planes * 4, N * h2 * w2, tm2)
             add(f)
+            ref3 = bnref.get(s3.data_ptr())
+            if (two_pass and blk.downsample is None and ref3 is not None and cv3_first.kind == L.OP_CONV and
+                    (cv3_first.scale0 or cv3_first.stat_acc1) and fuse_in_bn):
+                # pass 1 = the conv just emitted, statistics only; pass 2 = the same conv with the output-side BatchNorm
+                cv3_first.flags |= L.CONV_STATS_ONLY
+                acc3, bn3_, count3, shards3 = ref3
+                cvb = std_conv(blk.conv3, self.c2, ynext, N, h2, w2, h2, w2)
+                cvb.w = cv3_first.w                                  # same kernel-layout weights
+                cvb.stat_partial = None
+                cvb.scale0, cvb.shift0 = cv3_first.scale0, cv3_first.shift0
+                cvb.stat_acc1, cvb.stat_shards1 = cv3_first.stat_acc1, cv3_first.stat_shards1
+                cvb.gamma1, cvb.beta1 = cv3_first.gamma1, cv3_first.beta1
+                cvb.running_mean1, cvb.running_var1 = None, None     # bn2's running statistics were updated by pass 1
+                cvb.stat_acc, cvb.stat_shards = acc3, shards3
+                cvb.gamma, cvb.beta = bn3_.weight.data_ptr(), bn3_.bias.data_ptr()
+                cvb.running_mean, cvb.running_var = bn3_.running_mean.data_ptr(), bn3_.running_var.data_ptr()
+                cvb.count, cvb.momentum, cvb.eps = count3, BN_MOMENTUM, BN_EPS
+                cvb.in1 = y.data_ptr()
+                cvb.flags |= 1 | L.CONV_OUT_BN
+                ops.append(cvb)
+                y, ynext = ynext, y
+                continue
             if blk.downsample is not None:
                 ops.append(std_conv(blk.downsample[0], y, self.cd, N, h, w_, h2, w2))
                 f, sd, td_ = fin_op(blk.downsample[1], planes * 4, N * h2 * w2, tm2)
@@ -507,7 +539,8 @@ class ConvStackProgram:
     @staticmethod
     def _tune_key(o):
         fused = (1 if (o.stat_partial or o.stat_acc) else 0) + (2 if (o.scale0 or o.stat_acc1) else 0) + \
-                (4 if o.scale1 else 0) + (8 if o.in1 else 0) + (16 if o.out1 else 0)
+                (4 if o.scale1 else 0) + (8 if o.in1 else 0) + (16 if o.out1 else 0) + (32 if (o.flags & L.CONV_OUT_BN) else 0) + \
+                (64 if (o.flags & L.CONV_STATS_ONLY) else 0)
         return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d" % (o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout, o.KH, o.KW, o.stride, fused)
 
     def __del__(self):

@@ -185,3 +185,36 @@ def test_train_eval_alternation_keeps_every_program():
         enc.eval()
         sweep()
     assert {k: id(v) for k, v in enc._programs.items()} == ids          # same objects: nothing was evicted and rebuilt
+
+
+def test_two_pass_conv3_is_bit_identical_to_conv_plus_normalise_add(monkeypatch):
+    """bf16 training, identity-residual bottlenecks: conv3 as a statistics-only pass + a pass with bn3 + residual add + ReLU in
+    its epilogue (SAT_CONV3_TWOPASS=1, opt-in) against conv3 -> SAT_OP_BN_ADD_RELU: pooled features and every running
+    statistic BITWISE equal over three training passes (both statistics parities + hipGraph replay); models.py:25-29."""
+    from oracle import encoder as OE
+    arch, E, B = dict(layers=(2, 3, 3, 2), width=16), 32, 8
+    gen = torch.Generator().manual_seed(61)
+    params, buffers = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
+    xs = [torch.randn(B, 3, 96, 96, generator=gen).cuda() for _ in range(3)]
+
+    def build(flag):
+        monkeypatch.setenv("SAT_CONV3_TWOPASS", flag)
+        enc = sat.EncoderCNN(E, arch=arch, compute_dtype="bf16")
+        enc.load_state_dict({**params, **buffers})
+        return enc.cuda().train()
+    plain = build("0")
+    ref = [plain.pooled_features(x).clone() for x in xs]
+    n_plain = next(iter(plain._programs.values())).n_ops
+    fused = build("1")
+    out = [fused.pooled_features(x).clone() for x in xs]
+    n_fused = next(iter(fused._programs.values())).n_ops
+    assert n_fused < n_plain or n_fused == n_plain          # one normalise+add launch per fused block becomes one conv pass
+    prog = next(iter(fused._programs.values()))
+    L = sat._lib
+    n_two = sum(1 for i in range(prog.n_ops) if prog.ops[i].kind == L.OP_CONV and (prog.ops[i].flags & L.CONV_OUT_BN))
+    assert n_two >= 3, n_two                                # the identity blocks of the layers with planes % 64 == 0
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    sa, sb = plain.state_dict(), fused.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
