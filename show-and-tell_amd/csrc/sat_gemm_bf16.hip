@@ -216,9 +216,11 @@ template <> __device__ __forceinline__ float ld_f<float>(const float* p) { retur
 template <> __device__ __forceinline__ float ld_f<bf16_t>(const bf16_t* p) { return (float)*p; }
 
 // in [R][ldi] (f32 or bf16) -> out bf16 [C][ldo] = in^T, columns [R, ldo) zero; 64 x 64 tiles through LDS
+// psum (optional): psum[blockIdx.y][c] = f32 sum over this tile's 64 input rows of column c (fixed order) -- summed over the
+// row tiles by the caller, that is the column sum of `in` (the bias gradient, when `in` is d loss / d logits)
 template <typename Tin>
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const Tin* __restrict__ in, long ldi, int R, int C, bf16_t* __restrict__ out,
-                                                             long ldo) {
+                                                             long ldo, float* __restrict__ psum) {
     __shared__ bf16_t tile[64][66];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, t = threadIdx.x;
     {
@@ -235,6 +237,12 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const Tin* __restri
         }
     }
     __syncthreads();
+    if (psum && t < 64 && c0 + t < C) {
+        float a = 0.0f;
+#pragma unroll 8
+        for (int rr2 = 0; rr2 < 64; ++rr2) a += (float)tile[rr2][t];
+        psum[(long)blockIdx.y * C + c0 + t] = a;
+    }
     {
         const int orr = (t & 15) * 4, oc = t >> 4;
 #pragma unroll
@@ -363,16 +371,19 @@ int launch_gemm(const bf16_t* A, long lda, const bf16_t* B, long ldb, float* C, 
     a.tiles_n = tn;
     const dim3 grid(tm * tn, sat_cdiv(nk, a.ksteps)), block(512);
     static const int force_s = getenv("SAT_GEMM_BF16_S") ? atoi(getenv("SAT_GEMM_BF16_S")) : 0;
-    const int S = force_s ? force_s : (a.ksteps <= 8 ? 3 : 4);
-    if (S == 3) hipLaunchKernelGGL((gemm_bf16_nt_kernel<128, 3>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<128, 4>), grid, block, 0, s, a);
+    // ring depth, measured at cfg 2 (tools/microbench.py gemm16): more workgroups than CUs -> 2 stages (64 KB of LDS: two
+    // workgroups per CU, one's f32 epilogue under the other's K loop: logits 29.1 vs 36.3 us, dW 26.4 vs 30.1 us); one round
+    // of long-K workgroups -> 3 stages (dHs, split-K 6: 23.5 vs 26.5 us); a 4th stage never paid
+    const int S = force_s ? force_s : ((long)grid.x * grid.y > 256 ? 2 : 3);
+    if (S == 2) hipLaunchKernelGGL((gemm_bf16_nt_kernel<128, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<128, 3>), grid, block, 0, s, a);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
 
 // workspace layout of the bf16 vocab path (all offsets 256-byte aligned)
 struct VocabWs {
-    int64_t hsb, wb, wtb, hstb, gb, gtb, slabs, total;
+    int64_t hsb, wb, wtb, hstb, gb, gtb, slabs, psum, total;
     int Npad, Vpad, ks;
 };
 VocabWs vocab_ws(int N, int H, int V) {
@@ -393,6 +404,7 @@ VocabWs vocab_ws(int N, int H, int V) {
     if (ks > nk / 8) ks = nk / 8;
     w.ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
     w.slabs = off; off = al(off + (w.ks > 1 ? (int64_t)w.ks * N * H * 4 : 0));
+    w.psum = off; off = al(off + (int64_t)(w.Npad / 64) * V * 4);  // per-row-tile column sums of G (bias gradient)
     w.total = off;
     return w;
 }
@@ -415,7 +427,7 @@ extern "C" int sat_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64
 extern "C" int sat_transpose_f32_bf16(const float* in, int64_t ldi, int R, int C, void* out, int64_t ldo, sat_stream_t stream) {
     if (!in || !out || R < 1 || C < 1 || ldo < R || (ldo % 4) || ldi < C) return SAT_ERR_ARG;
     hipLaunchKernelGGL((transpose_bf16_kernel<float>), dim3(sat_cdiv(C, 64), sat_cdiv(ldo, 64)), dim3(256), 0, (hipStream_t)stream, in,
-                       (long)ldi, R, C, (bf16_t*)out, (long)ldo);
+                       (long)ldi, R, C, (bf16_t*)out, (long)ldo, (float*)nullptr);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
@@ -442,10 +454,10 @@ extern "C" int sat_vocab_ce_fwd_bf16(const float* Hs, const float* w, const floa
     hipLaunchKernelGGL(cast_rows_bf16_kernel, egrid((long)V * H / 8), dim3(256), 0, s, w, (long)H, V, H, wb, (long)H);
     SAT_LAUNCH_CHECK();
     hipLaunchKernelGGL((transpose_bf16_kernel<float>), dim3(sat_cdiv(H, 64), sat_cdiv(L.Vpad, 64)), dim3(256), 0, s, w, (long)H, V, H, wtb,
-                       (long)L.Vpad);
+                       (long)L.Vpad, (float*)nullptr);
     SAT_LAUNCH_CHECK();
     hipLaunchKernelGGL((transpose_bf16_kernel<float>), dim3(sat_cdiv(H, 64), sat_cdiv(L.Npad, 64)), dim3(256), 0, s, Hs, (long)H, N, H, hstb,
-                       (long)L.Npad);
+                       (long)L.Npad, (float*)nullptr);
     SAT_LAUNCH_CHECK();
     SAT_TRY(launch_gemm(hsb, H, wb, H, logits, (long)ldl, b, N, V, H, 1, 0, s));
     hipLaunchKernelGGL(ce_rows_bf16grad_kernel, dim3(N), dim3(256), 0, s, logits, (long)ldl, targets, V, inv_denom, row_loss, gb,
@@ -470,11 +482,13 @@ extern "C" int sat_vocab_ce_bwd_bf16(int N, int H, int V, float* dw, float* db, 
     bf16_t* wtb = (bf16_t*)(ws + L.wtb); bf16_t* hstb = (bf16_t*)(ws + L.hstb);
     bf16_t* gb = (bf16_t*)(ws + L.gb); bf16_t* gtb = (bf16_t*)(ws + L.gtb);
     float* slabs = (float*)(ws + L.slabs);
-    hipLaunchKernelGGL((transpose_bf16_kernel<bf16_t>), dim3(sat_cdiv(V, 64), sat_cdiv(L.Npad, 64)), dim3(256), 0, s, gb, (long)L.Vpad, N, V, gtb,
-                       (long)L.Npad);
+    // G -> G^T; the same pass leaves per-row-tile column sums of G, whose sum over the tiles is the bias gradient
+    float* psum = (float*)(ws + L.psum);
+    const int rt = sat_cdiv(L.Npad, 64);
+    hipLaunchKernelGGL((transpose_bf16_kernel<bf16_t>), dim3(sat_cdiv(V, 64), rt), dim3(256), 0, s, gb, (long)L.Vpad, N, V, gtb,
+                       (long)L.Npad, psum);
     SAT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(sat_cdiv(V, 64)), dim3(256), 0, s, gb, (long)L.Vpad, N, V, db);
-    SAT_LAUNCH_CHECK();
+    SAT_TRY(sat_sum_slabs_f32(psum, rt, (int64_t)V, (int64_t)V, db, stream));
     SAT_TRY(launch_gemm(gtb, L.Npad, hstb, L.Npad, dw, H, nullptr, V, H, L.Npad, 1, 0, s));               // dW = G^T Hs
     if (L.ks == 1) return launch_gemm(gb, L.Vpad, wtb, L.Vpad, dHs, H, nullptr, N, H, L.Vpad, 1, 0, s);     // dHs = G W
     SAT_TRY(launch_gemm(gb, L.Vpad, wtb, L.Vpad, slabs, H, nullptr, N, H, L.Vpad, L.ks, (long)N * H, s));

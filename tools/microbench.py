@@ -163,3 +163,32 @@ def bench_gemm(reps=30):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gemm":
     bench_gemm()
+
+
+def bench_gemm_bf16(reps=30):
+    """the bf16-mode vocab GEMMs at cfg2 (sat_gemm_bf16_nt); SAT_GEMM_BF16_S=2/3/4 forces the ring depth"""
+    lib = L.load()
+    N, H, V = 1216, 512, 10000
+    Vp = (V + 63) // 64 * 64
+    shapes = [("logits = Hs W^T   ", N, V, H, 1), ("dW = G^T Hs       ", V, H, N, 1), ("dHs = G W (ks=6)  ", N, H, Vp, 6), ("dHs = G W (ks=12) ", N, H, Vp, 12)]
+    for name, M, Nn, K, ks in shapes:
+        A = torch.randn(M, K, device="cuda").bfloat16()
+        B = torch.randn(Nn, K, device="cuda").bfloat16()
+        Cm = torch.empty(ks, M, Nn, device="cuda")
+        def run():
+            L.check(lib.sat_gemm_bf16_nt(A.data_ptr(), K, B.data_ptr(), K, Cm.data_ptr(), Nn, None, M, Nn, K, ks, M * Nn, L.stream()))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        print("S=%s %s M=%5d N=%5d K=%5d ks=%2d: %7.1f us  %6.1f TFLOP/s" % (os.environ.get("SAT_GEMM_BF16_S", "auto"), name, M, Nn, K, ks, us, 2.0 * M * Nn * K / us / 1e6))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gemm16":
+    bench_gemm_bf16()
