@@ -167,6 +167,54 @@ def attend_sample(p, features, states=None, start_id=1, steps=20):
     return torch.stack(ids, 1)
 
 
+def attend_beam_search(p, features, beam_size=5, states=None, start_id=1, steps=20, end_id=None):
+    """Beam decode for the Show-Attend-Tell model.  The reference has only a stub (`model2.py:113-114`: `def sample_beam: pass`),
+    so this is the textbook algorithm laid over `sample`'s own loop (`model2.py:91-111`, including its habit of feeding THIS
+    step's context into the NEXT step's LSTM input) -- PARITY UNPINNED by the reference, except that beam_size=1 with
+    end_id=None must reproduce `attend_sample` (pinned by the G6/G7 greedy goldens).
+    Candidate (k, v) scores score[k] + log_softmax(logits[k])[v]; the best K of the K*V per image survive (ties: lower k*V+v);
+    h, c and the carried context follow their parent.  end_id: a finished hypothesis only repeats end_id at no cost.
+    Returns (ids [B,K,steps] best-first, scores [B,K])."""
+    B, K = features.shape[0], beam_size
+    V = p["classifier.weight"].shape[0]
+    H = p["lstmcell.weight_hh"].shape[1]
+    rep = lambda t: t.repeat_interleave(K, 0)
+    feats = rep(features)
+    context_encode = feats @ p["image_att_w"]
+    if states is None:
+        h, c = torch.zeros(B * K, H), torch.zeros(B * K, H)
+    else:
+        h, c = rep(states[0]), rep(states[1])
+    emb = p["embedding.weight"][torch.full((B * K,), start_id, dtype=torch.long)]
+    scores = torch.full((B, K), float("-inf"))
+    scores[:, 0] = 0.0
+    seqs = torch.zeros(B, K, 0, dtype=torch.int64)
+    last, rnn_input = None, None
+    for i in range(steps):
+        context, _ = attention_layer(p, feats, context_encode, h)
+        if i == 0:
+            rnn_input = torch.cat([emb, context], 1)
+        h, c = lstmcell(p, rnn_input, h, c)
+        logits = output_layer(p, context, h)
+        logp = torch.log_softmax(logits, dim=1).view(B, K, V)
+        cand = scores.unsqueeze(2) + logp
+        if end_id is not None and last is not None:
+            fin = last == end_id
+            frozen = torch.full((B, K, V), float("-inf"))
+            frozen[:, :, end_id] = scores
+            cand = torch.where(fin.unsqueeze(2), frozen, cand)
+        cand = cand.view(B, K * V)
+        order = torch.sort(cand, dim=1, descending=True, stable=True)[1][:, :K]
+        scores = torch.gather(cand, 1, order)
+        parent, token = order // V, order % V
+        rows = (torch.arange(B).unsqueeze(1) * K + parent).reshape(-1)
+        h, c, context = h[rows], c[rows], context[rows]
+        seqs = torch.cat([torch.gather(seqs, 1, parent.unsqueeze(2).expand(B, K, seqs.shape[2])), token.unsqueeze(2)], 2)
+        last = token
+        rnn_input = torch.cat([p["embedding.weight"][token.reshape(-1)], context], 1)     # model2.py:108
+    return seqs, scores
+
+
 def attend_loss_and_grads(p, features, captions, lengths, denom=None):
     """train.py:134-144 around the model: targets = pack(captions[:,1:], lengths-1), model(images, captions[:,:-1], lengths-1),
     mean CE, backward (torch autograd on this restatement -- test infrastructure).  Returns (loss, grads, logits)."""

@@ -187,11 +187,22 @@ def _vgg_backward(self, d_feats, d_fmean):
     ReLU mask), the bias gradient (`sat_colsum_f32`), nine split-K GEMMs over the flat padded pixel index for the weight
     gradient, and the forward conv kernel on flipped weights for the input gradient; `sat_maxpool2_bwd_f32` for the pools.
     Returns [dW, db] per conv in forward order (parameter layout)."""
-    if self.dtype != L.SAT_F32:
-        raise NotImplementedError("fine-tuning the conv stack runs in the f32 parity mode (compute_dtype='f32')")
     lib, st = L.load(), L.stream()
     N = self.N
     dev = d_feats.device
+    bf = self.dtype == L.SAT_BF16
+    # bf16 stack (mixed precision, f32 master weights -- the parameters themselves): the forward ran on bf16 copies of the weights
+    # and stored bf16 activations.  Backward: gradients travel between layers in f32; the input gradient runs on the bf16 matrix
+    # pipe (the forward conv kernel on flipped bf16 weights over the bf16-rounded zero-bordered d(pre-activation)); the weight
+    # gradient stays an exact-f32 split-K GEMM over f32 casts of the stored activations, so dW is accumulated in f32 from bf16
+    # activations and f32 gradients, and the optimizer updates f32 masters.
+
+    def f32_of(t):
+        if not bf:
+            return t
+        o = torch.empty(t.shape, dtype=torch.float32, device=dev)
+        L.check(lib.sat_cast_bf16_f32(t.data_ptr(), o.data_ptr(), t.numel(), st), "sat_cast_bf16_f32")
+        return o
     dY = d_feats.contiguous().clone()                     # [N, P, C] == NHWC of the last map
     if d_fmean is not None:                               # fmean = mean over positions (model2.py:68)
         L.check(lib.sat_bcast_add_f32(d_fmean.contiguous().data_ptr(), N, self.P, self.C, 1.0 / self.P, dY.data_ptr(), st), "sat_bcast_add_f32")
@@ -199,11 +210,13 @@ def _vgg_backward(self, d_feats, d_fmean):
     for layer in reversed(self.layers):
         if layer[0] == "pool":
             _, x, out, h, w, c = layer
+            x = f32_of(x)
             dX = torch.empty_like(x)
             L.check(lib.sat_maxpool2_bwd_f32(x.data_ptr(), dY.data_ptr(), N, h, w, c, dX.data_ptr(), st), "sat_maxpool2_bwd_f32")
             dY = dX
             continue
         _, conv, x, out, h, w, cin, cout, first = layer
+        x, out = f32_of(x), f32_of(out)
         hp, wp = h + 2, w + 2
         npix = N * hp * wp
         dZp = torch.empty(npix, cout, device=dev)
@@ -239,6 +252,23 @@ def _vgg_backward(self, d_feats, d_fmean):
         # input gradient = conv of the zero-bordered d(pre-activation) with the flipped, transposed weights (forward kernel)
         wflip = conv.weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous().view(cin, 9 * cout)
         dX = torch.empty(N, h, w, cin, device=dev)
+        if bf and cin % 8 == 0 and cout % 8 == 0:
+            # input gradient on the bf16 matrix pipe: bf16 copies of dZp and of the flipped weights, bf16 result cast back to f32
+            dZb = torch.empty(npix, cout, dtype=torch.bfloat16, device=dev)
+            L.check(lib.sat_cast_f32_bf16(dZp.data_ptr(), dZb.data_ptr(), dZp.numel(), st), "sat_cast_f32_bf16")
+            wfb = wflip.to(torch.bfloat16)
+            dXb = torch.empty(N, h, w, cin, dtype=torch.bfloat16, device=dev)
+            o = L.SatOp()
+            o.kind, o.dtype = L.OP_CONV, L.SAT_BF16
+            o.in0, o.w, o.out = dZb.data_ptr(), wfb.data_ptr(), dXb.data_ptr()
+            o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, hp, wp, cout, h, w, cin
+            o.KH, o.KW, o.stride, o.pad = 3, 3, 1, 0
+            o.sN, o.sH, o.sW = hp * wp * cout, wp * cout, cout
+            ops = (L.SatOp * 1)(o)
+            L.check(lib.sat_run_ops(ops, 1, st), "sat_run_ops")
+            L.check(lib.sat_cast_bf16_f32(dXb.data_ptr(), dX.data_ptr(), dX.numel(), st), "sat_cast_bf16_f32")
+            dY = dX
+            continue
         o = L.SatOp()
         o.kind, o.dtype = L.OP_CONV, L.SAT_F32
         o.in0, o.w, o.out = dZp.data_ptr(), wflip.data_ptr(), dX.data_ptr()
@@ -375,7 +405,8 @@ class _AttendFn(torch.autograd.Function):
 
 
 class _VggFn(torch.autograd.Function):
-    """the conv stack WITH a backward (fine-tuning, model2.py:87-89 `finetune(allow=True)`): f32 parity mode only"""
+    """the conv stack WITH a backward (fine-tuning, model2.py:87-89 `finetune(allow=True)`): f32 parity mode, or bf16 forward /
+    bf16 input-gradient convs with f32 master weights and f32 weight gradients (compute_dtype='bf16')"""
 
     @staticmethod
     def forward(ctx, prog, images, *params):
@@ -436,8 +467,8 @@ class ShowAttendTellModel(nn.Module):
     def finetune(self, allow=False):
         """model2.py:87-89: (un)freeze the conv stack.  Fine-tuning runs the stack with a hand-written backward (dgrad through
         the forward conv kernel on flipped weights, wgrad as split-K GEMMs, ReLU / max-pool routing) in the f32 parity mode."""
-        if allow and getattr(self, "compute_dtype", "f32") != "f32":
-            raise NotImplementedError("fine-tuning the conv stack needs compute_dtype='f32' (the bf16 stack keeps no f32 master weights)")
+        # compute_dtype='bf16': mixed precision -- the parameters ARE the f32 master weights; the stack runs on bf16 copies
+        # refreshed from them before every forward (VggProgram.refresh_weights), gradients come back in f32 (_vgg_backward)
         for p in self.encoder.parameters():
             p.requires_grad = True if allow else False
 
@@ -599,3 +630,94 @@ class ShowAttendTellModel(nn.Module):
             L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, col.data_ptr(), ids.stride(0), V, B, E, L.ptr(X), Hin, st), "sat_rows_copy")
             L.check(lib.sat_rows_copy(L.ptr(ctxb), C, None, 0, B, B, C, X.data_ptr() + E * 4, Hin, st), "sat_rows_copy")
         return ids
+
+
+@torch.no_grad()
+def _sample_beam_features(self, features, beam_size=5, states=None, end_id=None, steps=20, start_id=1, return_all=False):
+    """Beam search over `sample`'s loop (model2.py:91-111; the reference's `sample_beam` is a stub, model2.py:113-114, so parity
+    is pinned only at beam_size=1 == the greedy goldens).  Rows are (image b, hypothesis k) = b*K + k: the features and their
+    attention encoding are replicated per hypothesis once (data movement), every step runs the greedy step's kernels on B*K rows,
+    `sat_beam_step` keeps the best K of the K*V candidates per image, and h, c and the carried context follow their parent
+    (`sat_beam_gather_rows`).  Returns ids i64 [B,steps] of the best hypothesis (return_all: ids [B,K,steps] best-first, scores)."""
+    lib = L.load()
+    m, dev, st = self, features.device, L.stream()
+    B, P, C = features.shape
+    K = int(beam_size)
+    if K < 1 or K > 8:
+        raise ValueError("beam_size must be in 1..8")
+    E, H, V, Hin = m.embed_size, m.hidden_size, m.vocab_size, m.hidden_size
+    R = B * K
+    feats = features.contiguous().repeat_interleave(K, 0).contiguous()           # [R, P, C]
+    f2 = feats.view(R * P, C)
+    ctx_enc = torch.empty(R * P, C, device=dev)
+    _gemm(lib, 0, 1, f2, C, m.image_att_w, C, ctx_enc, C, R * P, C, C)
+    if states is None:
+        h, c = torch.zeros(R, H, device=dev), torch.zeros(R, H, device=dev)
+    else:
+        h = states[0].to(dev).float().repeat_interleave(K, 0).contiguous()
+        c = states[1].to(dev).float().repeat_interleave(K, 0).contiguous()
+    h2, c2 = torch.empty(R, H, device=dev), torch.empty(R, H, device=dev)
+    proj, X = torch.empty(R, C, device=dev), torch.empty(R, Hin, device=dev)
+    ctxb, ctx2 = torch.empty(R, C, device=dev), torch.empty(R, C, device=dev)
+    Zin, Z = torch.empty(R, C + H, device=dev), torch.empty(R, E, device=dev)
+    Wz = torch.empty(E, C + H, device=dev)
+    L.check(lib.sat_rows_copy(L.ptr(m.context2out.weight), C, None, 0, E, E, C, L.ptr(Wz), C + H, st), "sat_rows_copy")
+    L.check(lib.sat_rows_copy(L.ptr(m.hidden2tout.weight), H, None, 0, E, E, H, Wz.data_ptr() + C * 4, C + H, st), "sat_rows_copy")
+    ldl = (V + 3) // 4 * 4
+    logits = torch.zeros(R, ldl, device=dev)
+    scores = torch.full((B, K), float("-inf"), device=dev)
+    scores[:, 0] = 0.0
+    scores2 = torch.empty(B, K, device=dev)
+    bws = torch.empty(lib.sat_beam_step_ws_bytes(B, K), dtype=torch.uint8, device=dev)
+    parents = torch.empty(steps, R, dtype=torch.int32, device=dev)
+    tokens = torch.empty(steps, R, dtype=torch.int64, device=dev)
+    start = torch.full((R,), int(start_id), dtype=torch.int64, device=dev)
+    watt = m.weight_att.view(-1)
+    att_ws = torch.empty(R * P, device=dev)
+    eid = -1 if end_id is None else int(end_id)
+    for i in range(steps):
+        _gemm(lib, 0, 0, h, H, m.weight_hh.weight, H, proj, C, R, C, H, m.weight_hh.bias)
+        L.check(lib.sat_attention_fwd(L.ptr(ctx_enc), L.ptr(f2), L.ptr(proj), C, L.ptr(watt), R, P, C, None, L.ptr(ctxb), C,
+                                      att_ws.data_ptr(), att_ws.numel() * 4, st), "sat_attention_fwd")
+        if i == 0:                                                                   # model2.py:101-102
+            L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, start.data_ptr(), 1, V, R, E, L.ptr(X), Hin, st), "sat_rows_copy")
+            L.check(lib.sat_rows_copy(L.ptr(ctxb), C, None, 0, R, R, C, X.data_ptr() + E * 4, Hin, st), "sat_rows_copy")
+        L.check(lib.sat_lstmcell_fwd(L.ptr(X), L.ptr(h), L.ptr(c), L.ptr(m.lstmcell.weight_ih), L.ptr(m.lstmcell.weight_hh),
+                                     L.ptr(m.lstmcell.bias_ih), L.ptr(m.lstmcell.bias_hh), R, Hin, H, L.ptr(h2), None, None, st),
+                "sat_lstmcell_fwd")
+        h, h2 = h2, h
+        L.check(lib.sat_rows_copy(L.ptr(ctxb), C, None, 0, R, R, C, L.ptr(Zin), C + H, st), "sat_rows_copy")
+        L.check(lib.sat_rows_copy(L.ptr(h), H, None, 0, R, R, H, Zin.data_ptr() + C * 4, C + H, st), "sat_rows_copy")
+        _gemm(lib, 0, 0, Zin, C + H, Wz, C + H, Z, E, R, E, C + H, m.context2out.bias, m.hidden2tout.bias)
+        L.check(lib.sat_vocab_logits_fwd(L.ptr(Z), L.ptr(m.classifier.weight), L.ptr(m.classifier.bias), R, E, V, L.ptr(logits), ldl, st),
+                "sat_vocab_logits_fwd")
+        last = tokens[i - 1].data_ptr() if (i > 0 and eid >= 0) else None
+        L.check(lib.sat_beam_step(L.ptr(logits), ldl, L.ptr(scores), last, eid, B, K, V, parents[i].data_ptr(), tokens[i].data_ptr(),
+                                  L.ptr(scores2), L.ptr(bws), bws.numel(), st), "sat_beam_step")
+        scores, scores2 = scores2, scores
+        src_ctx = ctxb
+        if K > 1:                                    # the survivors' state: h, c and THIS step's context follow their parent
+            for (a, b_) in ((h, h2), (c, c2)):
+                L.check(lib.sat_beam_gather_rows(L.ptr(a), parents[i].data_ptr(), B, K, H, L.ptr(b_), st), "sat_beam_gather_rows")
+            h, h2, c, c2 = h2, h, c2, c
+            L.check(lib.sat_beam_gather_rows(L.ptr(ctxb), parents[i].data_ptr(), B, K, C, L.ptr(ctx2), st), "sat_beam_gather_rows")
+            src_ctx = ctx2
+        # model2.py:107-108: the NEXT LSTM input = [embedding(token), THIS step's context]
+        L.check(lib.sat_rows_copy(L.ptr(m.embedding.weight), E, tokens[i].data_ptr(), 1, V, R, E, L.ptr(X), Hin, st), "sat_rows_copy")
+        L.check(lib.sat_rows_copy(L.ptr(src_ctx), C, None, 0, R, R, C, X.data_ptr() + E * 4, Hin, st), "sat_rows_copy")
+    ids = torch.empty(B, K, steps, dtype=torch.int64, device=dev)
+    L.check(lib.sat_beam_backtrack(L.ptr(parents), L.ptr(tokens), steps, B, K, L.ptr(ids), st), "sat_beam_backtrack")
+    if return_all:
+        return ids, scores
+    return ids[:, 0].contiguous()
+
+
+@torch.no_grad()
+def _sample_beam(self, images, beam_size=5, states=None, end_id=None, return_all=False):
+    """`sample_beam(images, ...)`: the method the reference leaves as a stub (model2.py:113-114); BASELINE configs[4] asks beam 5."""
+    feats, _ = self._encode(images)
+    return self.sample_beam_features(feats, beam_size, states, end_id, return_all=return_all)
+
+
+ShowAttendTellModel.sample_beam_features = _sample_beam_features
+ShowAttendTellModel.sample_beam = _sample_beam

@@ -67,3 +67,19 @@ def test_vgg_feature_stack_shape_and_indices():
             macs += hw * c * v * 9
             c = v
     assert abs(macs / 1e9 - 14.884) < 0.25             # 14.884 GMAC/img
+
+
+@pytest.mark.parametrize("name", ["G6_attend_small.npz", "G7_attend_vgg_dims.npz"])
+def test_attend_beam_width_one_is_the_pinned_greedy_decode(golden_dir, name):
+    """the reference's `sample_beam` is a stub (model2.py:113-114): the oracle's beam search is pinned where it can be --
+    width 1 reproduces the golden greedy ids of `sample` under both state conventions"""
+    g = load(golden_dir, name)
+    params, _ = setup(g)
+    feats = torch.from_numpy(g["features"])
+    ids, scores = OA.attend_beam_search(params, feats, beam_size=1)
+    assert np.array_equal(ids[:, 0].numpy(), g["sample_ids_zero_state"]) and torch.isfinite(scores).all()
+    h0, c0 = OA.init_lstm(params, feats)
+    assert np.array_equal(OA.attend_beam_search(params, feats, 1, (h0, c0))[0][:, 0].numpy(), g["sample_ids_init_state"])
+    ids3, sc3 = OA.attend_beam_search(params, feats, beam_size=3)
+    assert (sc3[:, 0] >= scores[:, 0] - 1e-5).all()          # a wider beam never ends with a worse best hypothesis than greedy
+    assert (sc3[:, :-1] >= sc3[:, 1:]).all()                 # best first
