@@ -63,6 +63,16 @@ enum {
     SAT_OP_MAXPOOL3S2 = 10,/* out = maxpool 3x3 / stride 2 / no padding of in0 (NHWC, Cout channels; ldc = output row pitch) */
     SAT_OP_AVGPOOL3 = 11,  /* out = avgpool 3x3 / stride 1 / pad 1, count_include_pad (divide by 9) of in0 (NHWC, Cout channels) */
     SAT_OP_MAXPOOL2 = 9,   /* out = maxpool 2x2 / stride 2 of in0 (NHWC; Hin, Win even; Cout channels): VGG16, model2.py:15-16 */
+    SAT_OP_CONV3_FUSED = 12,/* bf16, training: the expansion conv of an identity-residual bottleneck + its train-mode BatchNorm + residual
+                            * add + ReLU in ONE launch (sat_conv3_fused.hip): out = relu(bn3(conv1x1(relu(bn2(in0)))) + in1).
+                            * in0 = RAW conv2 output [M][Cin], w [Cout][Cin], in1 = block input [M][Cout], out [M][Cout];
+                            * stat_acc1 / gamma1 / beta1 / running_*1 = conv2's integer sums and bn2 (input side);
+                            * stat_acc / gamma / beta / running_* = this conv's sums and bn3 (output side); count, momentum, eps;
+                            * scale_out = uint32[2] sync words (zero before first use), shift_out = uint32 sticky error word
+                            * (non-zero: a grid-barrier wait ran out, the outputs of that run are INVALID -- read it back).
+                            * Accumulators stay in registers across a grid-wide statistics barrier, so every workgroup must be
+                            * resident: sat_conv3_fused_ok(M, Cout, Cin) tells whether the device can (Cin = 256, Cout % 512 == 0,
+                            * ceil(M/128) * Cout/512 <= CUs); the launch runs under the process-wide residency token. */
     SAT_OP_BN_EVAL_BATCH = 8 /* eval mode: in0 = DEVICE array of `count` sat_bn_eval_item; every item's (scale, shift)
                               * from its running statistics in ONE launch (replaces one BN_FINALIZE per layer); eps */
 };
@@ -164,6 +174,7 @@ typedef struct sat_op {
 #define SAT_CONV_STATS_ONLY 4
 #define SAT_CONV_OUT_BN 8
 
+int sat_conv3_fused_ok(int64_t M, int Cout, int Cin);   /* 1: SAT_OP_CONV3_FUSED can run this geometry on the current device */
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
 /* same, with the step parity (0/1) that selects the half of every stat_acc buffer in use */
 /* Deferred running statistics.  A program built with its sat_op running_mean / running_var pointers aimed at PRIVATE, zeroed

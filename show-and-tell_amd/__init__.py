@@ -13,6 +13,7 @@ import os as _os
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _lib  # noqa: F401,E402
+from . import watch  # noqa: F401,E402
 from .models import (CaptionModel, Decoder, DecoderRNN, Encoder, EncoderCNN, ShowAndTell)  # noqa: F401
 from .attend import ShowAttendTellModel, VggFeatures  # noqa: F401
 from .input import DevicePrefetcher, collate_batch, collate_on_device  # noqa: F401

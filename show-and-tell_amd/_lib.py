@@ -16,6 +16,7 @@ OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_M
 OP_BN_EVAL_BATCH = 8
 OP_MAXPOOL2 = 9
 OP_MAXPOOL3S2, OP_AVGPOOL3 = 10, 11
+OP_CONV3_FUSED = 12
 CONV_PADW = 2
 CONV_STATS_ONLY, CONV_OUT_BN = 4, 8
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "sat_graph_destroy": (_i, [_vp]),
     "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
     "sat_conv_tiles_m": (_i, [_i64]),
+    "sat_conv3_fused_ok": (_i, [_i64, _i, _i]),
     "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp, _i64, _vp]),
     "sat_run_ops_timed": (_i, [C.POINTER(SatOp), _i, _i, _vp, C.POINTER(C.c_float)]),
     "sat_validate_ids": (_i, [_vp, _i64, _i, _i, _i64, _i64, _vp, _vp]),

@@ -24,6 +24,11 @@
 // timestamps into these events (hipExtLaunchKernelGGL: the dispatch packet's timestamps, what rocprofv3 reports)
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 void sat_conv_arm_timer(hipEvent_t start, hipEvent_t stop) { t_ev_start = start; t_ev_stop = stop; }
+// the armed timer, consumed (the fused conv3 launch of sat_conv3_fused.hip reports its own span the same way)
+void sat_conv_take_timer(hipEvent_t* start, hipEvent_t* stop) {
+    *start = t_ev_start; *stop = t_ev_stop;
+    t_ev_start = t_ev_stop = nullptr;
+}
 
 namespace {
 

@@ -43,6 +43,7 @@ extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_
             case SAT_OP_MAXPOOL2: rc = sat_maxpool2_launch(op, s); break;
             case SAT_OP_MAXPOOL3S2: rc = sat_pool3_launch(op, false, s); break;
             case SAT_OP_AVGPOOL3: rc = sat_pool3_launch(op, true, s); break;
+            case SAT_OP_CONV3_FUSED: rc = sat_conv3_fused_launch(op, parity, s); break;
             default: rc = SAT_ERR_UNSUPPORTED;
         }
         if (rc != SAT_OK) return rc;
@@ -123,7 +124,7 @@ extern "C" int sat_run_ops_timed(const sat_op* ops, int n_ops, int parity, sat_s
     for (int i = 0; i < n_ops && rc == SAT_OK; ++i) {
         const sat_op* op = ops + i;
         op_us[i] = 0.0f;
-        const bool timed = op->kind == SAT_OP_CONV && op->dtype == SAT_BF16 && (op->Cout % 8) == 0;
+        const bool timed = (op->kind == SAT_OP_CONV || op->kind == SAT_OP_CONV3_FUSED) && op->dtype == SAT_BF16 && (op->Cout % 8) == 0;
         if (timed) {
             if (hipEventCreate(&ev[n_ev]) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
             if (hipEventCreate(&ev[n_ev + 1]) != hipSuccess) { (void)hipEventDestroy(ev[n_ev]); rc = SAT_ERR_UNSUPPORTED; break; }

@@ -13,6 +13,12 @@ int sat_avgpool_launch(const sat_op* op, hipStream_t s);
 int sat_maxpool2_launch(const sat_op* op, hipStream_t s);
 int sat_pool3_launch(const sat_op* op, bool avg, hipStream_t s);
 
+int sat_conv3_fused_launch(const sat_op* op, int parity, hipStream_t s);
+// one device-wide token for kernels that need ALL their workgroups resident (sat_conv3_fused.hip): acquire ahead of the launch
+// (a one-wave kernel that spins, bounded; `err` receives 2 on a timeout), release behind it
+int sat_resident_token_acquire(unsigned* err, hipStream_t s);
+int sat_resident_token_release(hipStream_t s);
+
 int sat_skinny_store(const float* A, long lda, const float* W, long ldw, int wkm, int M, int N, int K, int nz,
                      float* out, long ldo, long slab_stride, const float* bias, hipStream_t s);
 int sat_skinny_lstm(const float* h_prev, const float* w_hh, const float* x, const float* w_ih, int In,

@@ -20,7 +20,8 @@ import torch.nn as nn
 
 from . import _lib as L
 from .pack import PackInfo
-from .resnet import RESNET152, ConvStackProgram, ResNetStack, weights_signature
+from .resnet import RESNET152, ConvStackProgram, ResNetStack, fused_conv3_enabled, weights_signature
+from .watch import ResidencyWatch
 
 _LSTM_SPLITK = os.environ.get("SAT_LSTM_SPLITK", "1") != "0"   # roomy LSTM-backward workspace => split-K dW_ih / dX GEMMs
 BN1D_MOMENTUM = 0.01   # models.py:17
@@ -152,7 +153,7 @@ class EncoderCNN(nn.Module):
         flight next to each other on side streams (TrainStep.prefetch_encoder)."""
         N, _, H, W = images.shape
         dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
-        key = (N, H, W, dt, self.training, str(images.device), weights_signature(self.resnet), instance)
+        key = (N, H, W, dt, self.training, str(images.device), weights_signature(self.resnet), instance, fused_conv3_enabled())
         prog = self._programs.pop(key, None)
         if prog is not None:
             self._programs[key] = prog                      # most recently used last
@@ -262,60 +263,27 @@ class EncoderCNN(nn.Module):
 # decoder
 class LstmWatch:
     """The persistent LSTM recurrence (`sat_lstm_persist.hip`) needs all its workgroups resident at once and bounds every
-    hand-off wait; when a wait runs out (co-tenants on the device kept part of the grid from being scheduled) the kernel sets
-    the STATUS WORD of its workspace and drains -- the tapes and `HS` of that call are garbage.  That must never pass
-    silently: the word is copied to pinned host memory behind every call and looked at when the next call is
-    submitted (or at once with `poll(block=True)`; `TrainStep.check_ids()` does); non-zero raises RuntimeError and switches
-    the process to one launch per step (`sat_lstm_persist_enable(0)`), which needs no co-residency."""
+    hand-off wait; when a wait runs out the kernel sets the STATUS WORD of its workspace and drains -- the tapes and `HS` of that
+    call are garbage.  `watch.ResidencyWatch` reads the word back behind every call and raises RuntimeError (at the latest one
+    call later; `TrainStep.check_ids()` polls at once) after switching the process to one launch per step
+    (`sat_lstm_persist_enable(0)`), which needs no co-residency."""
 
-    DEPTH = 8
-    _by_device = {}
+    @staticmethod
+    def get(device):
+        return _LstmWatchView(ResidencyWatch.get(device))
 
-    @classmethod
-    def get(cls, device):
-        key = str(device)
-        w = cls._by_device.get(key)
-        if w is None:
-            w = cls._by_device[key] = cls()
-        return w
 
-    def __init__(self):
-        self.host = torch.zeros(self.DEPTH, dtype=torch.int32).pin_memory()
-        self.pending = []           # (slot, event), oldest first
-        self.slot = 0
+class _LstmWatchView:
+    def __init__(self, watch):
+        self.watch = watch
 
     def submit(self, ws, offset):
         """ws: the uint8 workspace tensor sat_lstm_fwd just ran with; offset: sat_lstm_fwd_status_offset"""
-        self.poll(block=False)
-        while len(self.pending) >= self.DEPTH:
-            self._retire(block=True)
-        slot = self.slot
-        self.slot = (slot + 1) % self.DEPTH
-        self.host[slot:slot + 1].copy_(ws[offset:offset + 4].view(torch.int32), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.pending.append((slot, ev))
-
-    def _retire(self, block):
-        slot, ev = self.pending[0]
-        if block:
-            ev.synchronize()
-        elif not ev.query():
-            return False
-        self.pending.pop(0)
-        if int(self.host[slot]) != 0:
-            torch.cuda.current_stream().synchronize()
-            self.host.zero_()
-            self.pending.clear()
-            L.load().sat_lstm_persist_enable(0)
-            raise RuntimeError("show-and-tell_amd: the persistent LSTM recurrence timed out waiting for its group (its workgroups "
-                               "were not all resident: other work shares the device); the outputs of that call are invalid.  "
-                               "Later calls run one launch per step (SAT_LSTM_PERSIST=0 selects that from the start)")
-        return True
+        self.watch.submit(ws[offset:offset + 4].view(torch.int32), "the persistent LSTM recurrence",
+                          lambda: L.load().sat_lstm_persist_enable(0))
 
     def poll(self, block=False):
-        while self.pending and self._retire(block):
-            pass
+        self.watch.poll(block)
 
 
 class IdGuard:

@@ -122,12 +122,27 @@ def weights_signature(stack):
     return sig
 
 
+# SAT_OP_CONV3_FUSED (conv3 + bn3 + residual add + ReLU in one launch, accumulators kept across a grid-wide statistics barrier):
+# on by default where the device can hold the whole grid (layer 3 of ResNet-152 at batch 64: 196 workgroups on 256 CUs);
+# SAT_FUSED_CONV3=0 turns it off; a barrier timeout reported by a run turns it off for the rest of the process.
+_FUSED3 = {"enabled": os.environ.get("SAT_FUSED_CONV3", "1") != "0"}
+
+
+def fused_conv3_enabled():
+    return _FUSED3["enabled"]
+
+
+def disable_fused_conv3():
+    _FUSED3["enabled"] = False
+
+
 def _tdtype(dtype):
     return torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
 
 
 class ConvStackProgram:
     """Device buffers + sat_op array for one (batch, H, W, dtype, training) configuration."""
+    n_fused3 = 0            # SAT_OP_CONV3_FUSED launches in the program (their status word is read back after every run)
 
     def __init__(self, stack, N, H, W, dtype, training, device):
         self.N, self.H, self.W, self.dtype, self.training = N, H, W, dtype, training
@@ -292,6 +307,15 @@ class ConvStackProgram:
             self.bn_list.append(bn)
             return o, s, t
 
+        def fin_op_acc_only(bn, c, count):
+            """integer accumulators of a BatchNorm whose producer AND consumer are one fused launch (SAT_OP_CONV3_FUSED)"""
+            s, t = new_scale_shift(c)
+            acc = alloc((2, 1, 2, c), torch.int64, zero=True)
+            self.stat_accs.append(acc)
+            bnref[s.data_ptr()] = (acc.data_ptr(), bn, count, 1)
+            self.bn_list.append(bn)
+            return None, s, t
+
         def act_op(kind, x, s, t, out, n, h_, w__, c, x1=None, s1=None, t1=None):
             o = L.SatOp()
             o.kind, o.dtype = kind, dtype
@@ -372,6 +396,15 @@ class ConvStackProgram:
         # 17.7 us of the conv's 22 (the store is the smaller part of a K = 256 conv with its fused input BatchNorm), the second
         # pass 25.3, together 43 us against 22 + 16 for conv + normalise+add: 4.95 vs 4.85 ms/step (profiles/r03_twopass_ab.txt).
         two_pass = training and dtype == L.SAT_BF16 and not fuse_resid and os.environ.get("SAT_CONV3_TWOPASS", "0") == "1"
+        # SINGLE-PASS fused conv3 (SAT_OP_CONV3_FUSED, sat_conv3_fused.hip): conv3 + bn3 + residual add + ReLU in one launch, the
+        # f32 accumulators held in registers across a grid-wide statistics barrier -- the raw conv3 tensor and the normalise+add
+        # launch disappear without a second pass.  Needs the whole grid resident (sat_conv3_fused_ok) and integer-atomic sums.
+        fused3 = training and dtype == L.SAT_BF16 and not fuse_resid and not two_pass and fused_conv3_enabled()
+        self.fused_sync, self.fused_err, self.n_fused3 = None, None, 0
+        if fused3:
+            nblk = len(list(stack.blocks()))
+            self.fused_sync = alloc((nblk, 2), torch.int32, zero=True)
+            self.fused_err = alloc((4,), torch.int32, zero=True)
         pending = None          # (s3, t3, resid buffer) of the previous block when its bn_add is deferred to this conv1
         blocks_geo = list(zip(stack.blocks(), geo))
         for bi, (blk, (h, w_, h2, w2, inpl, planes, stride)) in enumerate(blocks_geo):
@@ -434,6 +467,32 @@ class ConvStackProgram:
                 ops.append(std_conv(blk.conv2, self.a1, self.c2, N, h, w_, h2, w2))
             f, s2, t2 = fin_op(blk.bn2, planes, N * h2 * w2, tm2)
             add(f)
+            ref2 = bnref.get(s2.data_ptr())
+            if (fused3 and blk.downsample is None and ref2 is not None and ref2[3] == 1 and tm2 <= ATOMIC_MAX_TILES and
+                    L.load().sat_conv3_fused_ok(N * h2 * w2, planes * 4, planes)):
+                acc2, bn2_, count2, shards2 = ref2
+                _, s3, t3 = fin_op_acc_only(blk.bn3, planes * 4, N * h2 * w2)
+                acc3, bn3_, count3, _ = bnref[s3.data_ptr()]
+                wt = prep_w(blk.conv3).reshape(blk.conv3.cout, -1)
+                self.keep.append(wt)
+                o = L.SatOp()
+                o.kind, o.dtype = L.OP_CONV3_FUSED, dtype
+                o.in0, o.w, o.in1, o.out = self.c2.data_ptr(), wt.data_ptr(), y.data_ptr(), ynext.data_ptr()
+                o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, h2, w2, planes, h2, w2, planes * 4
+                o.KH, o.KW, o.stride, o.pad = 1, 1, 1, 0
+                o.stat_acc1, o.stat_shards1 = acc2, shards2
+                o.gamma1, o.beta1 = bn2_.weight.data_ptr(), bn2_.bias.data_ptr()
+                o.running_mean1, o.running_var1 = bn2_.running_mean.data_ptr(), bn2_.running_var.data_ptr()
+                o.stat_acc, o.stat_shards = acc3, 1
+                o.gamma, o.beta = bn3_.weight.data_ptr(), bn3_.bias.data_ptr()
+                o.running_mean, o.running_var = bn3_.running_mean.data_ptr(), bn3_.running_var.data_ptr()
+                o.count, o.momentum, o.eps = count3, BN_MOMENTUM, BN_EPS
+                o.scale_out = self.fused_sync[bi].data_ptr()
+                o.shift_out = self.fused_err.data_ptr()
+                ops.append(o)
+                self.n_fused3 += 1
+                y, ynext = ynext, y
+                continue
             if fuse_in_bn and planes <= 512 and planes % 64 == 0:
                 # conv3 reads the RAW c2 and applies bn2 + ReLU to its A operand in LDS: a2 never exists in HBM
                 cv3 = std_conv(blk.conv3, self.c2, self.c3, N, h2, w2, h2, w2)
@@ -621,6 +680,11 @@ class ConvStackProgram:
         self._parity ^= 1
         if self.training and self._running_items is None:
             self.stack._nbt_flat += 1
+        if self.n_fused3:
+            # the fused conv3 launches' sticky status word (a grid-barrier wait that ran out): read back behind the run, raised
+            # at the latest on the next submit; the process then builds its programs without the fused launch
+            from .watch import ResidencyWatch
+            ResidencyWatch.get(self.pooled.device).submit(self.fused_err[0:1], "the fused conv3 + BatchNorm launch", disable_fused_conv3)
         return self.pooled
 
 
@@ -638,7 +702,7 @@ def _run_timed(self, images):
     self._parity ^= 1
     if self.training:
         self.stack._nbt_flat += 1
-    return self.pooled, [float(us[i]) for i in range(self.n_ops) if self.ops[i].kind == L.OP_CONV]
+    return self.pooled, [float(us[i]) for i in range(self.n_ops) if self.ops[i].kind in (L.OP_CONV, L.OP_CONV3_FUSED)]
 
 
 ConvStackProgram.run_timed = _run_timed

@@ -236,8 +236,8 @@ class TrainStep:
         """Block until the device-side verdicts of the last submitted batch are known: raises IndexError on a bad caption id,
         RuntimeError when the persistent LSTM recurrence gave up (`models.LstmWatch`)."""
         self.model.decoder.id_guard().poll(block=True)
-        from .models import LstmWatch
-        LstmWatch.get(self.model.decoder.linear.weight.device).poll(block=True)
+        from .watch import ResidencyWatch
+        ResidencyWatch.get(self.model.decoder.linear.weight.device).poll(block=True)
 
     def optimizer_step(self, lr=None):
         """clip_gradient + Adam (train.py:145-146) as one launch over the flat buffers."""

@@ -1018,3 +1018,79 @@ def test_vocab_ce_bf16_path_vs_exact_f32_path(lib, N, H, V):
           % (N, H, V, abs(loss16.item() - loss32.item()), rel(dW16, dW32), rel(db16, db32), rel(dH16, dH32)))
     assert rel(dW16, dW32) < 1e-2 and rel(db16, db32) < 1e-2 and rel(dH16, dH32) < 1e-2
     assert lib.sat_vocab_bf16_ws_bytes(N, 100, V) == 0 and lib.sat_vocab_bf16_ws_bytes(N, H, 20000) == 0      # unsupported shapes say so
+
+
+@pytest.mark.parametrize("Nimg,HW,Cout", [(3, 14, 512), (4, 14, 1024), (1, 12, 1024)])
+def test_conv3_fused_bn_add_relu_single_launch_vs_reference(lib, Nimg, HW, Cout):
+    """SAT_OP_CONV3_FUSED (sat_conv3_fused.hip): y = relu(bn3(conv1x1(relu(bn2(raw2)))) + x) in ONE launch, the accumulators held
+    across a grid-wide statistics barrier -- against the same arithmetic on the CPU (bf16 storage, f32 / f64 accumulate): outputs
+    to bf16 rounding, integer sums, running statistics, parity clearing, re-armed sync words; two consecutive runs (both
+    parities).  torchvision Bottleneck.forward under models.py:27."""
+    Cin, M = 256, Nimg * HW * HW
+    assert lib.sat_conv3_fused_ok(M, Cout, Cin) == 1 and lib.sat_conv3_fused_ok(M, Cout, 128) == 0
+    g = torch.Generator().manual_seed(M + Cout)
+    w = (torch.randn(Cout, Cin, generator=g) / 16).bfloat16()
+    g2, b2 = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.1
+    g3, b3 = torch.rand(Cout, generator=g) * 0.2 + 0.1, torch.randn(Cout, generator=g) * 0.1
+    rm2, rv2, rm3, rv3 = torch.zeros(Cin), torch.ones(Cin), torch.zeros(Cout), torch.ones(Cout)
+    dw, dg2, db2, dg3, db3 = cu(w), cu(g2), cu(b2), cu(g3), cu(b3)
+    drm2, drv2, drm3, drv3 = cu(rm2), cu(rv2), cu(rm3), cu(rv3)
+    acc2 = torch.zeros(2, 1, 2, Cin, dtype=torch.int64, device="cuda")
+    acc3 = torch.zeros(2, 1, 2, Cout, dtype=torch.int64, device="cuda")
+    sync_w, err = torch.zeros(2, dtype=torch.int32, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda")
+    out = torch.empty(M, Cout, dtype=torch.bfloat16, device="cuda")
+    for parity in (0, 1):
+        raw2 = (torch.randn(M, Cin, generator=g) * 1.5 + 0.3).bfloat16()
+        x = torch.randn(M, Cout, generator=g).bfloat16()
+        r2 = raw2.double()
+        acc2[parity, 0, 0] = torch.round(r2.sum(0) * 2 ** 22).long().cuda()          # what conv2's epilogue leaves
+        acc2[parity, 0, 1] = torch.round((r2 * r2).sum(0) * 2 ** 22).long().cuda()
+        acc2[1 - parity].fill_(7)                                                       # must be cleared by the launch
+        acc3[1 - parity].fill_(9)
+        draw, dx = cu(raw2), cu(x)
+        out.fill_(float("nan"))
+        o = L.SatOp()
+        o.kind, o.dtype = L.OP_CONV3_FUSED, L.SAT_BF16
+        o.in0, o.w, o.in1, o.out = draw.data_ptr(), dw.data_ptr(), dx.data_ptr(), out.data_ptr()
+        o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = Nimg, HW, HW, Cin, HW, HW, Cout
+        o.KH, o.KW, o.stride, o.pad = 1, 1, 1, 0
+        o.stat_acc1, o.stat_shards1, o.gamma1, o.beta1 = acc2.data_ptr(), 1, dg2.data_ptr(), db2.data_ptr()
+        o.running_mean1, o.running_var1 = drm2.data_ptr(), drv2.data_ptr()
+        o.stat_acc, o.stat_shards, o.gamma, o.beta = acc3.data_ptr(), 1, dg3.data_ptr(), db3.data_ptr()
+        o.running_mean, o.running_var = drm3.data_ptr(), drv3.data_ptr()
+        o.count, o.momentum, o.eps = M, 0.1, 1e-5
+        o.scale_out, o.shift_out = sync_w.data_ptr(), err.data_ptr()
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, parity, st()))
+        sync()
+        assert int(err[0]) == 0 and sync_w.tolist() == [0, 0]
+        # reference
+        m2 = r2.mean(0)
+        v2 = (r2 * r2).mean(0) - m2 * m2
+        sc2 = (g2.double() / torch.sqrt(v2 + 1e-5)).float()
+        sh2 = (b2.double() - m2 * sc2.double()).float()
+        a2 = torch.relu(raw2.float() * sc2 + sh2).bfloat16()
+        conv = a2.double() @ w.double().t()
+        m3 = conv.mean(0)
+        v3 = (conv * conv).mean(0) - m3 * m3
+        sc3 = (g3.double() / torch.sqrt(v3 + 1e-5)).float()
+        sh3 = (b3.double() - m3 * sc3.double()).float()
+        ref = torch.relu(conv.float().bfloat16().float() * sc3 + sh3 + x.float())
+        got = out.float().cpu()
+        assert torch.isfinite(got).all()
+        # bf16(conv) may round the other way when the f32 accumulation order differs: two output ulps
+        tol = 2 ** -7 * ref.abs().clamp(min=1.0) + 2 ** -7 * conv.abs().float() * sc3.abs()
+        assert ((got - ref).abs() <= tol).all(), ((got - ref).abs() / tol).max().item()
+        s1 = acc3[parity, 0, 0].cpu().double() / 2 ** 22
+        s2 = acc3[parity, 0, 1].cpu().double() / 2 ** 22
+        assert (s1 - conv.sum(0)).abs().max().item() < 2e-3 * M ** 0.5 + 2e-2
+        assert ((s2 - (conv * conv).sum(0)).abs() / (conv * conv).sum(0)).max().item() < 1e-3
+        assert int(acc2[1 - parity].abs().sum()) == 0 and int(acc3[1 - parity].abs().sum()) == 0
+        rm2 = 0.9 * rm2 + 0.1 * m2.float()
+        rv2 = 0.9 * rv2 + 0.1 * (v2 * M / (M - 1)).float()
+        rm3 = 0.9 * rm3 + 0.1 * m3.float()
+        rv3 = 0.9 * rv3 + 0.1 * (v3 * M / (M - 1)).float()
+        np.testing.assert_allclose(drm2.cpu().numpy(), rm2.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(drv2.cpu().numpy(), rv2.numpy(), rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(drm3.cpu().numpy(), rm3.numpy(), rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(drv3.cpu().numpy(), rv3.numpy(), rtol=2e-3, atol=1e-4)
+        acc3[parity].zero_()                       # (a consumer-less test: the next run of this parity starts from zero)
