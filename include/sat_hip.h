@@ -174,7 +174,9 @@ typedef struct sat_op {
 #define SAT_CONV_STATS_ONLY 4
 #define SAT_CONV_OUT_BN 8
 
-int sat_conv3_fused_ok(int64_t M, int Cout, int Cin);   /* 1: SAT_OP_CONV3_FUSED can run this geometry on the current device */
+int sat_conv3_fused_ok(int64_t M, int Cout, int Cin);
+/* diagnostics: device buffer [grid][8] uint64 that later fused launches fill with per-workgroup phase time stamps (NULL: off) */
+int sat_conv3_fused_debug(void* stamps);   /* 1: SAT_OP_CONV3_FUSED can run this geometry on the current device */
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
 /* same, with the step parity (0/1) that selects the half of every stat_acc buffer in use */
 /* Deferred running statistics.  A program built with its sat_op running_mean / running_var pointers aimed at PRIVATE, zeroed

@@ -70,6 +70,7 @@ SIGNATURES = {
     "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
     "sat_conv_tiles_m": (_i, [_i64]),
     "sat_conv3_fused_ok": (_i, [_i64, _i, _i]),
+    "sat_conv3_fused_debug": (_i, [_vp]),
     "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp, _i64, _vp]),
     "sat_run_ops_timed": (_i, [C.POINTER(SatOp), _i, _i, _vp, C.POINTER(C.c_float)]),
     "sat_validate_ids": (_i, [_vp, _i64, _i, _i, _i64, _i64, _vp, _vp]),

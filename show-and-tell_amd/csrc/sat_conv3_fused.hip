@@ -9,7 +9,7 @@
 // exactly that memory traffic (profiles/r03_twopass_ab.txt: the normalise+add launches are 0.95 ms of a 4.78 ms step).
 // Here every workgroup keeps its f32 accumulators IN REGISTERS across a grid-wide barrier:
 //   1. K phase: the workgroup owns 128 rows x 512 output columns (4 blocks of 128).  Its A panel (128 x K, K = 256) is loaded
-//      once into LDS and bn2 + ReLU is applied there once; the weights stream through a 3-stage LDS-DMA ring (one
+//      once into LDS and bn2 + ReLU is applied there once; the weights stream through a 5-stage LDS-DMA ring (one
 //      128-column x 64-k stage per barrier, counted vmcnt); 128 accumulator registers per thread.
 //   2. statistics: column sums / sums of squares of the f32 accumulators -> 2^22 fixed-point 64-bit integer atomics (bitwise
 //      reproducible whatever the arrival order), as the stand-alone conv does.
@@ -18,7 +18,7 @@
 //   4. epilogue: (scale, shift) from the integer sums (the arithmetic of bn_table_from_acc), then per 128-column block the
 //      normalise + add + ReLU kernel's arithmetic on the bf16-rounded accumulators with the residual read straight from
 //      memory: y is written ONCE; the raw conv tensor never exists.
-// Residency: the barrier needs every workgroup resident at once -- grid <= CUs, one workgroup per CU (114 KB of LDS) -- and no
+// Residency: the barrier needs every workgroup resident at once -- grid <= CUs, one workgroup per CU (146 KB of LDS) -- and no
 // OTHER spinning kernel may hold CUs it needs.  All such kernels of the process (this one in up to three look-ahead streams, the
 // persistent LSTM recurrence) therefore run under one device-wide TOKEN: a one-wave acquire kernel ahead of the launch spins
 // (holding no LDS, one wave slot) until the token is free; the last workgroup to leave releases it.  Ordinary kernels that
@@ -57,6 +57,7 @@ struct FusedArgs {
     unsigned* err;            // sticky error word (shared by the launches of one program)
     unsigned spin_limit;
     int hold_token;           // the launch runs under the residency token: the last workgroup to leave releases it
+    unsigned long long* dbg;  // diagnostics (sat_conv3_fused_debug): [workgroup][8] s_memtime stamps of lane 0, or NULL
 };
 constexpr double kStatScale = SAT_STAT_SCALE;
 
@@ -79,15 +80,19 @@ __global__ __launch_bounds__(64) void token_release_kernel() {
 __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
     constexpr int K = 64 * KS, NT = 512;
     constexpr int SLAB = 128 * 128;                    // one K-step of the A panel / one ring stage: 128 rows x 128 B
-    constexpr int A_BYTES = KS * SLAB, SB = 3, RING = SB * SLAB;
-    constexpr int CROW = 128 * 2 + 16;                 // bf16 C-tile row stride (epilogue staging, in the A region)
-    static_assert(128 * CROW <= A_BYTES, "C staging fits the A panel's region");
+    constexpr int A_BYTES = KS * SLAB, SB = 5, RING = SB * SLAB;   // 4 weight stages (64 KB) in flight per CU
+    constexpr int CROW = 128 * 2;                      // bf16 C-tile row stride (epilogue staging, first half of the A region)
+    constexpr int RBLK = 128 * 256;                    // one 128 x 128 bf16 block of the residual
+    static_assert(128 * CROW + RBLK <= A_BYTES && 2 * NB * 2 * 128 * 4 + 2 * 512 * 4 + RBLK <= RING, "epilogue buffers fit");
     __shared__ __attribute__((aligned(16))) char smem[A_BYTES + RING + 2 * K * 4];
     char* sA = smem;
     char* sB = smem + A_BYTES;
     float* in_tab = (float*)(smem + A_BYTES + RING);   // bn2 (scale, shift)
     float* red = (float*)sB;                           // after the K phase: [2 wm][NB][2][128] column sums ...
     float* otab = (float*)(sB + 2 * NB * 2 * 128 * 4); // ... and bn3 (scale, shift) of this workgroup's 512 columns
+    // epilogue: the residual blocks are prefetched into LDS by LDS-DMA (two buffers) while the grid barrier is waited for
+    char* rbuf0 = sA + 128 * CROW;
+    char* rbuf1 = sB + 2 * NB * 2 * 128 * 4 + 2 * 512 * 4;
     __shared__ int s_flag;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,6 +106,10 @@ __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
     const int tile_m = swz / p.tiles_g, g = swz - tile_m * p.tiles_g;
     const int m0 = tile_m * 128, n0 = g * (128 * NB);
     const bf16_t* zero = (const bf16_t*)&g_zero16_f;
+    auto stamp = [&](int k) {
+        if (p.dbg && tid == 0) p.dbg[(long)bid * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
 
     // ---- issue the A panel (4 slabs x 2 pieces per wave) and the first two weight stages (2 pieces per wave each) ----
 #pragma unroll
@@ -127,8 +136,8 @@ __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(live ? b_ptr[i] + off : zero), (lptr_t)(sB + buf * SLAB + (wave * 16 + i * 8) * 128), 16, 0, 0);
     };
-    issue_b(0, 0);
-    issue_b(1, 1);
+#pragma unroll
+    for (int t0 = 0; t0 < SB - 1; ++t0) issue_b(t0, t0);
 
     // ---- bn2 (scale, shift) for the K = 256 input channels, from conv2's integer sums (bn_table_from_acc's arithmetic) ----
     {
@@ -160,10 +169,11 @@ __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // my A pieces have landed (the two weight stages may still fly)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // my A pieces have landed (the four weight stages may still fly)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my table entries are written
     __builtin_amdgcn_s_barrier();                         // everybody's
     asm volatile("" ::: "memory");
+    stamp(1);
     // ---- relu(x * scale + shift) on the A panel, in place, once ----
 #pragma unroll
     for (int j = 0; j < KS * 128 * 8 / NT; ++j) {
@@ -212,10 +222,10 @@ __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
 #pragma unroll
         for (int kt = 0; kt < KS; ++kt) {
             const int t = nb * KS + kt;
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // my pieces of stage t have landed
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // my pieces of stage t have landed (three younger stages in flight)
             __builtin_amdgcn_s_barrier();                         // everybody's; everybody has finished reading stage t-1
             asm volatile("" ::: "memory");
-            issue_b(t + 2, (t + 2) % SB);                         // into the slot stage t-1 occupied
+            issue_b(t + SB - 1, (t + SB - 1) % SB);               // into the slot stage t-1 occupied
             const char* stA = sA + kt * SLAB;
             const char* stB = sB + (t % SB) * SLAB;
 #pragma unroll
@@ -229,6 +239,7 @@ __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(2);
 
     // ---- statistics of this workgroup's 128 x 512 f32 accumulators -> integer atomics ----
 #pragma unroll
@@ -258,9 +269,24 @@ __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
         atomicAdd((unsigned long long*)(p.out_acc + col), (unsigned long long)__double2ll_rn((double)s * kStatScale));
         atomicAdd((unsigned long long*)(p.out_acc + p.N + col), (unsigned long long)__double2ll_rn((double)q * kStatScale));
     }
-    // ---- grid barrier: my atomics are acknowledged, the workgroup's are (barrier), ONE lane arrives and polls ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // ---- residual blocks 0 and 1 -> LDS by LDS-DMA (4 pieces of 4 rows x 256 B per wave and block): they land while the grid
+    //      barrier is waited for.  A landed block is read back as [row][16 chunks of 16 B]: conflict free.
+    auto issue_r = [&](int nb, char* dst) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int piece = wave * 4 + it;
+            const int row = piece * 4 + (lane >> 4);
+            const bf16_t* src = (m0 + row < p.M) ? p.R + ((long)(m0 + row) * p.N + n0 + nb * 128 + (lane & 15) * 8) : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    issue_r(0, rbuf0);                                   // (neither buffer overlaps `red` / `otab`; the A panel is dead)
+    issue_r(1, rbuf1);
+    // ---- grid barrier: my atomics are acknowledged (all but the 8 younger LDS-DMA pieces), the workgroup's are (barrier),
+    //      ONE lane arrives and polls ----
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stamp(3);
     if (tid == 0) {
         int ok = 1;
         __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -276,8 +302,11 @@ __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
         }
         s_flag = ok;
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     const bool ok = s_flag != 0;
+    stamp(4);
 
     if (ok) {
         // ---- bn3 (scale, shift) of my 512 columns from the now complete sums; tile_m == 0 also updates the running statistics
@@ -306,10 +335,12 @@ __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
                 }
             }
         }
-        __syncthreads();
-        // ---- per 128-column block: bf16 C tile through LDS, then y = relu(c * scale + shift + x), 16 bytes per thread ----
+        // ---- per 128-column block: bf16 C tile through LDS, then y = relu(c * scale + shift + x) with x from the prefetched LDS
+        //      block, 16 bytes per thread; the block after next is fetched into the buffer just consumed.  Raw barriers: a
+        //      __syncthreads() would drain the LDS-DMA in flight. ----
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
+            char* rb = (nb & 1) ? rbuf1 : rbuf0;
             const int col = wn * 32 + r;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -318,30 +349,39 @@ __global__ __launch_bounds__(512) void conv3_fused_kernel(const FusedArgs p) {
                     const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     *(bf16_t*)(sA + row * CROW + col * 2) = (bf16_t)acc[nb][i][e];
                 }
-            __syncthreads();
+            // my pieces of residual block nb have landed.  A wave's memory counter is in order: behind block nb's 4 pieces come
+            // at most the previous block's stores and the 4 pieces of block nb+1 -- waiting for all but the 4 youngest
+            // operations therefore covers block nb whether or not this wave stored anything (rows past M store nothing)
+            if (nb < NB - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // C tile + table + everybody's residual pieces are in LDS
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int it = 0; it < 128 * 16 / NT; ++it) {
                 const int qid = tid + it * NT;
                 const int row = qid >> 4, cc = qid & 15;
                 const int grow = m0 + row, gcol = n0 + nb * 128 + cc * 8;
-                if (grow < p.M) {
-                    const bf16x8 c = *(const bf16x8*)(sA + row * CROW + cc * 16);
-                    const bf16x8 z = *(const bf16x8*)(p.R + (long)grow * p.N + gcol);
-                    const float* ts = otab + nb * 128 + cc * 8;
-                    const f32x4 s0 = *(const f32x4*)ts, s1 = *(const f32x4*)(ts + 4);
-                    const f32x4 t0 = *(const f32x4*)(ts + 512), t1 = *(const f32x4*)(ts + 512 + 4);
-                    bf16x8 o;
+                const bf16x8 c = *(const bf16x8*)(sA + row * CROW + cc * 16);
+                const bf16x8 z = *(const bf16x8*)(rb + row * 256 + cc * 16);
+                const float* ts = otab + nb * 128 + cc * 8;
+                const f32x4 s0 = *(const f32x4*)ts, s1 = *(const f32x4*)(ts + 4);
+                const f32x4 t0 = *(const f32x4*)(ts + 512), t1 = *(const f32x4*)(ts + 512 + 4);
+                bf16x8 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        o[k] = (bf16_t)fmaxf((float)c[k] * s0[k] + t0[k] + (float)z[k], 0.0f);
-                        o[k + 4] = (bf16_t)fmaxf((float)c[k + 4] * s1[k] + t1[k] + (float)z[k + 4], 0.0f);
-                    }
-                    store16_wt(p.Y + (long)grow * p.N + gcol, *(const u32x4*)&o);
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = (bf16_t)fmaxf((float)c[k] * s0[k] + t0[k] + (float)z[k], 0.0f);
+                    o[k + 4] = (bf16_t)fmaxf((float)c[k + 4] * s1[k] + t1[k] + (float)z[k + 4], 0.0f);
                 }
+                if (grow < p.M) store16_wt(p.Y + (long)grow * p.N + gcol, *(const u32x4*)&o);
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // everybody is done with the C tile and with rb
+            asm volatile("" ::: "memory");
+            if (nb + 2 < NB) issue_r(nb + 2, rb);
         }
     }
+    stamp(5);
     // ---- departure: the last workgroup to leave re-arms the counters and releases the residency token ----
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -382,9 +422,20 @@ int sat_resident_token_acquire(unsigned* err, hipStream_t s) {
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
+// the token only costs launches once a kernel that shares it with others has run in this process
+static int g_token_in_use = 0;
+int sat_resident_token_in_use() { return g_token_in_use; }
 int sat_resident_token_release(hipStream_t s) {
     hipLaunchKernelGGL(token_release_kernel, dim3(1), dim3(64), 0, s);
     SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+static unsigned long long* g_dbg_stamps = nullptr;
+// diagnostics: device buffer of [grid][8] u64 that lane 0 of every workgroup of the NEXT fused launches fills with s_memtime
+// stamps (0 start, 1 A panel landed + table, 2 K phase done, 3 statistics acknowledged, 4 grid barrier passed, 5 epilogue done)
+extern "C" int sat_conv3_fused_debug(void* stamps) {
+    g_dbg_stamps = (unsigned long long*)stamps;
     return SAT_OK;
 }
 
@@ -423,6 +474,8 @@ int sat_conv3_fused_launch(const sat_op* op, int parity, hipStream_t s) {
     a.sync = (unsigned*)op->scale_out; a.err = (unsigned*)op->shift_out;
     a.spin_limit = spin_limit_env();
     a.hold_token = 1;
+    a.dbg = g_dbg_stamps;
+    g_token_in_use = 1;
     SAT_TRY(sat_resident_token_acquire(a.err, s));
     const dim3 grid(sat_cdiv(M, 128) * a.tiles_g), block(512);
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -250,16 +250,19 @@ int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, flo
     if (e != hipSuccess) return (int)e;
     // all workgroups must be resident together: run under the process-wide residency token (sat_conv3_fused.hip) so that no other
     // spinning kernel of this process (the fused conv3 launches of the look-ahead streams) holds CUs this grid is waiting for
-    SAT_TRY(sat_resident_token_acquire(a.err, s));
+    const bool token = sat_resident_token_in_use() != 0;
+    if (token) SAT_TRY(sat_resident_token_acquire(a.err, s));
     const dim3 grid(groups * members), block(256);
     switch (H / 16) {
 #define SAT_PERSIST_CASE(n) case n: hipLaunchKernelGGL((lstm_persist_kernel<n>), grid, block, 0, s, a); break;
         SAT_PERSIST_CASE(2) SAT_PERSIST_CASE(4) SAT_PERSIST_CASE(6) SAT_PERSIST_CASE(8) SAT_PERSIST_CASE(16) SAT_PERSIST_CASE(32)
 #undef SAT_PERSIST_CASE
-        default: (void)sat_resident_token_release(s); return SAT_ERR_UNSUPPORTED;
+        default:
+            if (token) (void)sat_resident_token_release(s);
+            return SAT_ERR_UNSUPPORTED;
     }
     SAT_LAUNCH_CHECK();
-    return sat_resident_token_release(s);
+    return token ? sat_resident_token_release(s) : SAT_OK;
 }
 
 bool sat_lstm_persist_has(int H) {

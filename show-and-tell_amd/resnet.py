@@ -122,10 +122,14 @@ def weights_signature(stack):
     return sig
 
 
-# SAT_OP_CONV3_FUSED (conv3 + bn3 + residual add + ReLU in one launch, accumulators kept across a grid-wide statistics barrier):
-# on by default where the device can hold the whole grid (layer 3 of ResNet-152 at batch 64: 196 workgroups on 256 CUs);
-# SAT_FUSED_CONV3=0 turns it off; a barrier timeout reported by a run turns it off for the rest of the process.
-_FUSED3 = {"enabled": os.environ.get("SAT_FUSED_CONV3", "1") != "0"}
+# SAT_OP_CONV3_FUSED (conv3 + bn3 + residual add + ReLU in one launch, accumulators kept across a grid-wide statistics barrier),
+# OPT-IN (SAT_FUSED_CONV3=1) where the device can hold the whole grid (layer 3 of ResNet-152 at batch 64: 196 workgroups on 256
+# CUs).  Measured (profiles/r03_fused_conv3_ab.txt): the launch takes 28-31 us + a 4.8 us token-acquire launch against 24 + 16 us
+# for conv3 + normalise+add -- the strictly sequential step gains 0.12 ms (6.30 vs 6.42) -- but with three stacks in flight the
+# step LOSES 0.6 ms (5.41 vs 4.73 ms): the launch must own 196 CUs for its whole span (its workgroups idle at the barrier) and the
+# residency token serialises the three stacks' fused launches, where conv3 and the normalise+add pass of different stacks used to
+# overlap freely.  A barrier timeout reported by a run turns it off for the rest of the process.
+_FUSED3 = {"enabled": os.environ.get("SAT_FUSED_CONV3", "0") == "1"}
 
 
 def fused_conv3_enabled():
