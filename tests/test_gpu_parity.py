@@ -471,8 +471,18 @@ def test_cfg2_full_size_properties():
     assert torch.equal(g_a[:ts.flat.n], ts.flat.grads[:ts.flat.n])
     # (2) at random init the mean CE is ln(V) to within the logit scale
     assert abs(l0.item() - math.log(10000)) < 0.1
-    # (3) softmax-minus-onehot rows sum to zero => the vocab bias gradient sums to ~0
+    # (3) softmax-minus-onehot rows sum to zero => the vocab bias gradient sums to ~0.  In the bf16 throughput mode
+    # d(loss)/d(logits) is stored as bf16: the 1216 target entries -(1-p)/N are nearly EQUAL at initialisation, so their bf16
+    # rounding (2^-9 relative of 8e-4 each) is systematic, not random: the row sums miss zero by up to 2e-3 in total.  The
+    # exact-f32 decoder keeps the 1e-4.
+    assert ts.decoder_gemm_dtype == "bf16"
+    assert abs(ts.flat.grad("decoder.linear.bias").sum().item()) < 5e-3
+    ts.decoder_gemm_dtype = "f32"
+    l32 = ts.forward_backward((images, caps, lengths), 1.0 / (64 * 19)).clone()
     assert abs(ts.flat.grad("decoder.linear.bias").sum().item()) < 1e-4
+    assert abs(l32.item() - l0.item()) < 1e-4            # bf16 vs exact-f32 vocab projection: the CE moves by < 1e-4
+    ts.decoder_gemm_dtype = "bf16"
+    ts.forward_backward((images, caps, lengths), 1.0 / (64 * 19))
     # (4) linearity of the backward in the loss scale
     ts.forward_backward((images, caps, lengths), 2.0 / (64 * 19))
     torch.testing.assert_close(ts.flat.grad("decoder.lstm.weight_hh_l0"), 2 * g_a[slice(*_slice(ts, "decoder.lstm.weight_hh_l0"))].view(2048, 512),
