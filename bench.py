@@ -151,6 +151,16 @@ def f32_mode_rate(torch, sat, dev, images, caps, lengths, steps=6, lookahead=Tru
     torch.manual_seed(123)
     model = sat.ShowAndTell(CFG["embed"], CFG["hidden"], CFG["vocab"], CFG["layers"], compute_dtype="f32").to(dev).train()
     ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+    # the SAME weights (same seed) in the bf16 throughput mode: mean CE of the first forward in both modes -- what the reduced
+    # precision of the conv stack and of the decoder GEMMs costs on this batch
+    torch.manual_seed(123)
+    m16 = sat.ShowAndTell(CFG["embed"], CFG["hidden"], CFG["vocab"], CFG["layers"], compute_dtype="bf16").to(dev).train()
+    ts16 = sat.TrainStep(m16, lr=1e-3, grad_clip=0.1)
+    inv = 1.0 / sum(l - 1 for l in lengths)
+    ce32 = float(ts.forward_backward((images, caps, lengths), inv).item())
+    ce16 = float(ts16.forward_backward((images, caps, lengths), inv).item())
+    del ts16, m16
+    torch.cuda.empty_cache()
     depth = model.encoder.lookahead_depth if lookahead else 0
     batches = [images] + [images.clone() for _ in range(depth)]
 
@@ -169,6 +179,8 @@ def f32_mode_rate(torch, sat, dev, images, caps, lengths, steps=6, lookahead=Tru
     dt = time.perf_counter() - t0
     return {"value": round(CFG["batch"] * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
             "steps": steps, "final_loss": round(float(loss.item()), 4), "lookahead_depth": depth,
+            "ce_first_forward_f32": round(ce32, 6), "ce_first_forward_bf16_mode": round(ce16, 6),
+            "bf16_vs_f32_ce_delta_same_weights": float("%.3g" % abs(ce16 - ce32)),
             "note": "conv stack f32 (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak): the oracle-parity mode, not the headline"}
 
 
@@ -294,7 +306,7 @@ def main():
                         "images_per_sec_max": round(world * CFG["batch"] * args.steps / min(dts), 1)},
             "config": {"workload": "BASELINE configs[1]: batch=64/GPU 224x224x3 + len-20 captions, ResNet-152 encoder (frozen, train-mode BN), embed=256 hidden=512 vocab=10000 L=1; fwd+CE+bwd+clamp+Adam",
                        "global_batch": world * CFG["batch"], "parallelism": "dp%d" % world,
-                       "precision": "conv stack bf16 MFMA / f32 accumulate; head, LSTM, vocab, CE, Adam f32 (exact-f32 MFMA)",
+                       "precision": "conv stack bf16 MFMA / f32 accumulate; vocab projection + its gradients and the LSTM's batched GEMMs on the bf16 MFMA pipe from bf16 operand copies (f32 accumulate, f32 logits / outputs / master weights); LSTM recurrence, head, CE, Adam f32",
                        "schedule": ("encoder look-ahead depth %d: the frozen conv stacks of batches i+1..i+%d run on side streams next to each other and under batch i's head/decoder/backward/Adam; "
                                     "K conv passes + K decoder passes inside the timed region, fill and drain included" % (depth, depth)) if args.lookahead
                                    else "strictly sequential steps",

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 11
+#define SAT_ABI_VERSION 12
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -277,6 +277,19 @@ int sat_lstm_bwd(const float* dHS /*[N,H]*/, const float* X, const float* w_ih, 
                  const int32_t* batch_sizes /*[T] host*/, int T, int In, int H,
                  float* DG /*[N,4H] out*/, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
                  float* dX /*[N,In] or NULL*/, float* workspace, int64_t ws_bytes, sat_stream_t stream);
+
+/* bf16 THROUGHPUT mode of an LSTM layer's batched GEMMs (BASELINE configs[1] names bf16): sat_lstm_fwd / sat_lstm_bwd with the
+ * x-gates product and dW_ih / dW_hh / dX on v_mfma_f32_32x32x16_bf16 (f32 accumulate and outputs) from bf16 copies of the f32
+ * operands made in `mixed_ws` (sat_lstm_mixed_ws_bytes, 256-byte aligned); the recurrence, the gate arithmetic, the bias
+ * gradients and the master weights stay f32.  A too small mixed_ws silently keeps the exact-f32 GEMMs. */
+int64_t sat_lstm_mixed_ws_bytes(int N /*packed rows*/, int In, int H);
+int sat_lstm_fwd_bf16(const float* X, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                      const int32_t* batch_sizes /*[T] host*/, int T, int In, int H, float* GA, float* CS, float* HS, float* HP,
+                      float* c_state, void* workspace, int64_t ws_bytes, void* mixed_ws, int64_t mixed_bytes, sat_stream_t stream);
+int sat_lstm_bwd_bf16(const float* dHS, const float* X, const float* w_ih, const float* w_hh, const float* GA, const float* CS,
+                      const float* HP, const int32_t* batch_sizes /*[T] host*/, int T, int In, int H, float* DG, float* dw_ih,
+                      float* dw_hh, float* db_ih, float* db_hh, float* dX, float* workspace, int64_t ws_bytes, void* mixed_ws,
+                      int64_t mixed_bytes, sat_stream_t stream);
 
 /* vocab projection (models.py:53) */
 /* logits rows have stride ldl >= V floats.  For the backward (sat_vocab_ce_bwd) ldl must be a multiple of 4 and the

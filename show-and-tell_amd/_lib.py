@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -81,6 +81,10 @@ SIGNATURES = {
     "sat_embed_concat_bwd": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sat_pack_targets": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
     "sat_lstm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sat_lstm_mixed_ws_bytes": (_i64, [_i, _i, _i]),
+    "sat_lstm_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "sat_lstm_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "sat_lstm_fwd_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_fwd_status_offset": (_i64, [_i, _i]),
     "sat_lstm_persist_enable": (_i, [_i]),

@@ -26,6 +26,7 @@ struct GemmArgs {
     const bf16_t* B;      // [N][ldb], K contiguous
     float* C;             // [M][ldc] (+ z * slab for split-K slice z)
     const float* bias;    // [N] or NULL (ignored when ksplit > 1)
+    const float* bias2;   // second bias added like the first (nn.LSTM's b_ih + b_hh), or NULL
     int M, N, K;          // K: multiple of 64
     long lda, ldb, ldc, slab;
     int tiles_n, ksteps;  // K-steps of 64 per split slice
@@ -181,7 +182,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel(const GemmArgs p) {
             const int grow = m0 + hf * 64 + row, gcol = n0 + c4 * 4;
             if (grow < p.M && gcol < p.N) {             // N % 4 == 0: a chunk is all in or all out
                 f32x4 v = *(const f32x4*)(ct + row * CROWF + c4 * 4);
-                if (add_bias) v += *(const f32x4*)(p.bias + gcol);
+                if (add_bias) {
+                    v += *(const f32x4*)(p.bias + gcol);
+                    if (p.bias2) v += *(const f32x4*)(p.bias2 + gcol);
+                }
                 *(f32x4*)(C + (long)grow * p.ldc + gcol) = v;
             }
         }
@@ -360,11 +364,11 @@ __global__ __launch_bounds__(256) void sum_scale_b_kernel(const float* __restric
 int pad64(int x) { return (x + 63) / 64 * 64; }
 
 int launch_gemm(const bf16_t* A, long lda, const bf16_t* B, long ldb, float* C, long ldc, const float* bias, int M, int N, int K,
-                int ksplit, long slab, hipStream_t s) {
+                int ksplit, long slab, hipStream_t s, const float* bias2 = nullptr) {
     if (!A || !B || !C || M < 1 || N < 1 || K < 64 || (K % 64) || (N % 4) || (lda % 8) || (ldb % 8) || (ldc % 4) || ksplit < 1)
         return SAT_ERR_ARG;
     GemmArgs a = {};
-    a.A = A; a.B = B; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.slab = slab;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.bias2 = bias2; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.slab = slab;
     const int nk = K / 64;
     a.ksteps = sat_cdiv(nk, ksplit);
     const int tm = sat_cdiv(M, 128), tn = sat_cdiv(N, 128);
@@ -430,6 +434,38 @@ extern "C" int sat_transpose_f32_bf16(const float* in, int64_t ldi, int R, int C
                        (long)ldi, R, C, (bf16_t*)out, (long)ldo, (float*)nullptr);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
+}
+
+// C[M,N] f32 = op(A) op(B)^T (+ bias + bias2) on the bf16 matrix pipe from F32 operands: each operand is cast (row-major
+// [rows][K]) or transposed ([K][rows], "k-major") into a bf16 [rows][Kpad] copy in `scratch` (Kpad = K rounded up to 64, zero
+// padded), then the NT kernel runs.  scratch: (M + N) * Kpad * 2 bytes, 256-byte aligned.  N % 4 == 0, lda / ldb % 4 == 0.
+int64_t sat_gemm_mixed_scratch_bytes(int M, int N, int K) {
+    const int64_t kp = pad64(K);
+    return (((int64_t)M * kp * 2 + 255) / 256 * 256) + (((int64_t)N * kp * 2 + 255) / 256 * 256);
+}
+int sat_gemm_mixed_nt(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor, float* C, long ldc,
+                      const float* bias, const float* bias2, int M, int N, int K, void* scratch, int64_t scratch_bytes, hipStream_t s) {
+    if (!A || !B || !C || !scratch || M < 1 || N < 1 || K < 1) return SAT_ERR_ARG;
+    if ((N % 4) || (ldc % 4)) return SAT_ERR_UNSUPPORTED;
+    if (scratch_bytes < sat_gemm_mixed_scratch_bytes(M, N, K) || (((uintptr_t)scratch) & 255)) return SAT_ERR_WORKSPACE;
+    const int kp = pad64(K);
+    bf16_t* ab = (bf16_t*)scratch;
+    bf16_t* bb = (bf16_t*)((char*)scratch + (((int64_t)M * kp * 2 + 255) / 256 * 256));
+    auto prep = [&](const float* src, long ld, int kmajor, int rows, bf16_t* dst) {
+        if (kmajor) {       // src [K][rows] -> dst [rows][kp]
+            hipLaunchKernelGGL((transpose_bf16_kernel<float>), dim3(sat_cdiv(rows, 64), sat_cdiv(kp, 64)), dim3(256), 0, s, src, ld, K, rows,
+                               dst, (long)kp, (float*)nullptr);
+        } else {            // src [rows][K] -> dst [rows][kp]
+            long g = ((long)rows * kp / 8 + 255) / 256;
+            hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3((unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g))), dim3(256), 0, s, src, ld, rows, K,
+                               dst, (long)kp);
+        }
+    };
+    prep(A, lda, a_kmajor, M, ab);
+    SAT_LAUNCH_CHECK();
+    prep(B, ldb, b_kmajor, N, bb);
+    SAT_LAUNCH_CHECK();
+    return launch_gemm(ab, kp, bb, kp, C, ldc, bias, M, N, kp, 1, 0, s, bias2);
 }
 
 extern "C" int64_t sat_vocab_bf16_ws_bytes(int N, int H, int V) { return vocab_bf16_ok(N, H, V) ? vocab_ws(N, H, V).total : 0; }

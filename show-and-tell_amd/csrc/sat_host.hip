@@ -206,10 +206,10 @@ static int device_cu_count() {
     return n;
 }
 
-extern "C" int sat_lstm_fwd(const float* X, const float* w_ih, const float* w_hh, const float* b_ih,
-                            const float* b_hh, const int32_t* batch_sizes, int T, int In, int H, float* GA,
-                            float* CS, float* HS, float* HP, float* c_state, void* workspace, int64_t ws_bytes,
-                            sat_stream_t stream) {
+static int lstm_fwd_impl(const float* X, const float* w_ih, const float* w_hh, const float* b_ih,
+                         const float* b_hh, const int32_t* batch_sizes, int T, int In, int H, float* GA,
+                         float* CS, float* HS, float* HP, float* c_state, void* workspace, int64_t ws_bytes,
+                         void* mixed, int64_t mixed_bytes, sat_stream_t stream) {
     if (!X || !w_ih || !w_hh || !b_ih || !b_hh || !batch_sizes || !GA || !CS || !HS || !HP || !c_state || T < 1)
         return SAT_ERR_ARG;
     if ((In & 3) || (H & 3)) return SAT_ERR_UNSUPPORTED;
@@ -221,7 +221,11 @@ extern "C" int sat_lstm_fwd(const float* X, const float* w_ih, const float* w_hh
         N += batch_sizes[t];
     }
     // x-gates for every packed row in one batched MFMA GEMM: GA = X * W_ih^T + b_ih + b_hh
-    SAT_TRY(sat_gemm_f32(0, 0, X, In, w_ih, In, GA, 4L * H, b_ih, b_hh, (int)N, 4 * H, In, stream));
+    // (bf16 throughput mode: the same product on the bf16 matrix pipe from bf16 copies of X and W_ih, f32 accumulate and output)
+    if (mixed && mixed_bytes >= sat_gemm_mixed_scratch_bytes((int)N, 4 * H, In))
+        SAT_TRY(sat_gemm_mixed_nt(X, In, 0, w_ih, In, 0, GA, 4L * H, b_ih, b_hh, (int)N, 4 * H, In, mixed, mixed_bytes, s));
+    else
+        SAT_TRY(sat_gemm_f32(0, 0, X, In, w_ih, In, GA, 4L * H, b_ih, b_hh, (int)N, 4 * H, In, stream));
     hipError_t e = hipMemsetAsync(HP, 0, (size_t)B * H * sizeof(float), s);   // h_{-1} = 0 for the rows of step 0
     if (e != hipSuccess) return (int)e;
     // the recurrence: ONE persistent launch (W_hh in registers, per-group hidden-state exchange) when every workgroup
@@ -248,6 +252,32 @@ extern "C" int sat_lstm_fwd(const float* X, const float* w_ih, const float* w_hh
         off += n;
     }
     return SAT_OK;
+}
+
+extern "C" int sat_lstm_fwd(const float* X, const float* w_ih, const float* w_hh, const float* b_ih,
+                            const float* b_hh, const int32_t* batch_sizes, int T, int In, int H, float* GA,
+                            float* CS, float* HS, float* HP, float* c_state, void* workspace, int64_t ws_bytes,
+                            sat_stream_t stream) {
+    return lstm_fwd_impl(X, w_ih, w_hh, b_ih, b_hh, batch_sizes, T, In, H, GA, CS, HS, HP, c_state, workspace, ws_bytes, nullptr, 0, stream);
+}
+
+// scratch for the bf16-pipe forms of an LSTM layer's batched GEMMs (x-gates, dW_ih, dW_hh, dX): N = packed rows
+extern "C" int64_t sat_lstm_mixed_ws_bytes(int N, int In, int H) {
+    int64_t m = sat_gemm_mixed_scratch_bytes(N, 4 * H, In);
+    const int64_t c[3] = {sat_gemm_mixed_scratch_bytes(4 * H, In, N), sat_gemm_mixed_scratch_bytes(4 * H, H, N),
+                          sat_gemm_mixed_scratch_bytes(N, In, 4 * H)};
+    for (int i = 0; i < 3; ++i) m = c[i] > m ? c[i] : m;
+    return m;
+}
+
+// sat_lstm_fwd with the x-gates GEMM (models.py:52, the input half of nn.LSTM) on the bf16 matrix pipe; the recurrence stays f32
+extern "C" int sat_lstm_fwd_bf16(const float* X, const float* w_ih, const float* w_hh, const float* b_ih,
+                                 const float* b_hh, const int32_t* batch_sizes, int T, int In, int H, float* GA,
+                                 float* CS, float* HS, float* HP, float* c_state, void* workspace, int64_t ws_bytes,
+                                 void* mixed_ws, int64_t mixed_bytes, sat_stream_t stream) {
+    if (!mixed_ws) return SAT_ERR_ARG;
+    return lstm_fwd_impl(X, w_ih, w_hh, b_ih, b_hh, batch_sizes, T, In, H, GA, CS, HS, HP, c_state, workspace, ws_bytes, mixed_ws,
+                         mixed_bytes, stream);
 }
 
 static int lstm_bwd_split(int H) {
@@ -280,10 +310,10 @@ extern "C" int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H) {
     return base > extra ? base : extra;
 }
 
-extern "C" int sat_lstm_bwd(const float* dHS, const float* X, const float* w_ih, const float* w_hh, const float* GA,
-                            const float* CS, const float* HP, const int32_t* batch_sizes, int T, int In, int H,
-                            float* DG, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dX,
-                            float* workspace, int64_t ws_bytes, sat_stream_t stream) {
+static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, const float* w_hh, const float* GA,
+                         const float* CS, const float* HP, const int32_t* batch_sizes, int T, int In, int H,
+                         float* DG, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dX,
+                         float* workspace, int64_t ws_bytes, void* mixed, int64_t mixed_bytes, sat_stream_t stream) {
     if (!dHS || !X || !w_ih || !w_hh || !GA || !CS || !HP || !batch_sizes || !DG || !dw_ih || !dw_hh || !db_ih ||
         !db_hh || !workspace || T < 1)
         return SAT_ERR_ARG;
@@ -319,6 +349,17 @@ extern "C" int sat_lstm_bwd(const float* dHS, const float* X, const float* w_ih,
     }
     // batched weight gradients over all packed rows (the recurrence above is done with the workspace: it is free for
     // split-K slabs when the caller sized it with sat_lstm_bwd_ws_bytes_full)
+    if (mixed && mixed_bytes >= sat_lstm_mixed_ws_bytes((int)N, In, H)) {
+        // bf16 throughput mode: the three batched GEMMs on the bf16 matrix pipe (f32 accumulate / output); DG, X, HP are read
+        // "k-major" (the packed-row axis is the contraction), W_ih k-major for dX
+        SAT_TRY(sat_gemm_mixed_nt(DG, 4L * H, 1, X, In, 1, dw_ih, In, nullptr, nullptr, 4 * H, In, (int)N, mixed, mixed_bytes, s));
+        SAT_TRY(sat_gemm_mixed_nt(DG, 4L * H, 1, HP, H, 1, dw_hh, H, nullptr, nullptr, 4 * H, H, (int)N, mixed, mixed_bytes, s));
+        SAT_TRY(sat_colsum_f32(DG, 4L * H, (int)N, 4 * H, db_ih, stream));
+        e = hipMemcpyAsync(db_hh, db_ih, (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+        if (dX) SAT_TRY(sat_gemm_mixed_nt(DG, 4L * H, 0, w_ih, In, 1, dX, In, nullptr, nullptr, (int)N, In, 4 * H, mixed, mixed_bytes, s));
+        return SAT_OK;
+    }
     const bool roomy = ws_bytes >= sat_lstm_bwd_ws_bytes_full((int)N, B, In, H);
     const int ks_dw = roomy ? fill_split(4L * H, In, N) : 1;
     if (ks_dw > 1) {
@@ -343,6 +384,24 @@ extern "C" int sat_lstm_bwd(const float* dHS, const float* X, const float* w_ih,
         }
     }
     return SAT_OK;
+}
+
+extern "C" int sat_lstm_bwd(const float* dHS, const float* X, const float* w_ih, const float* w_hh, const float* GA,
+                            const float* CS, const float* HP, const int32_t* batch_sizes, int T, int In, int H,
+                            float* DG, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dX,
+                            float* workspace, int64_t ws_bytes, sat_stream_t stream) {
+    return lstm_bwd_impl(dHS, X, w_ih, w_hh, GA, CS, HP, batch_sizes, T, In, H, DG, dw_ih, dw_hh, db_ih, db_hh, dX, workspace, ws_bytes,
+                         nullptr, 0, stream);
+}
+
+// sat_lstm_bwd with dW_ih, dW_hh and dX on the bf16 matrix pipe (the recurrence and the bias gradients stay f32)
+extern "C" int sat_lstm_bwd_bf16(const float* dHS, const float* X, const float* w_ih, const float* w_hh, const float* GA,
+                                 const float* CS, const float* HP, const int32_t* batch_sizes, int T, int In, int H,
+                                 float* DG, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dX,
+                                 float* workspace, int64_t ws_bytes, void* mixed_ws, int64_t mixed_bytes, sat_stream_t stream) {
+    if (!mixed_ws) return SAT_ERR_ARG;
+    return lstm_bwd_impl(dHS, X, w_ih, w_hh, GA, CS, HP, batch_sizes, T, In, H, DG, dw_ih, dw_hh, db_ih, db_hh, dX, workspace, ws_bytes,
+                         mixed_ws, mixed_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

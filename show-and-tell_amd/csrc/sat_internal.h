@@ -13,6 +13,11 @@ int sat_avgpool_launch(const sat_op* op, hipStream_t s);
 int sat_maxpool2_launch(const sat_op* op, hipStream_t s);
 int sat_pool3_launch(const sat_op* op, bool avg, hipStream_t s);
 
+// f32 operands on the bf16 matrix pipe (sat_gemm_bf16.hip): C[M,N] = op(A) op(B)^T + bias + bias2, operands row-major [rows][K]
+// (kmajor 0) or [K][rows] (kmajor 1), cast / transposed into bf16 copies in `scratch`
+int64_t sat_gemm_mixed_scratch_bytes(int M, int N, int K);
+int sat_gemm_mixed_nt(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor, float* C, long ldc,
+                      const float* bias, const float* bias2, int M, int N, int K, void* scratch, int64_t scratch_bytes, hipStream_t s);
 int sat_conv3_fused_launch(const sat_op* op, int parity, hipStream_t s);
 // one device-wide token for kernels that need ALL their workgroups resident (sat_conv3_fused.hip): acquire ahead of the launch
 // (a one-wave kernel that spins, bounded; `err` receives 2 on a timeout), release behind it

@@ -362,7 +362,7 @@ class _Weight(nn.Module):
             self.bias = nn.Parameter(torch.zeros(bias))
 
 
-def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, captions, pi, logits=None, ce=None):
+def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, captions, pi, logits=None, ce=None, mixed_ws=None):
     """embed+cat+pack -> L x LSTM -> vocab logits (models.py:49-53).  Returns (logits, tapes).
     `ce` = dict(targets, inv_denom, lse, row_loss, loss_out, ws): the projection and the cross entropy (train.py:143) run as
     ONE fused op (`sat_vocab_ce_fwd`: the loss never re-reads the logits)."""
@@ -393,8 +393,13 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
         cst = torch.empty(B, H, device=dev)
         wsb = lib.sat_lstm_fwd_ws_bytes(B, H)            # hidden-state exchange of the persistent recurrence
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-        L.check(lib.sat_lstm_fwd(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), pi.bs_c, T, In, H,
-                                 L.ptr(GA), L.ptr(CS), L.ptr(HS), L.ptr(HP), L.ptr(cst), L.ptr(ws), wsb, st), "sat_lstm_fwd")
+        if mixed_ws is not None:          # bf16 throughput mode: the x-gates GEMM on the bf16 matrix pipe
+            L.check(lib.sat_lstm_fwd_bf16(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), pi.bs_c, T, In, H,
+                                          L.ptr(GA), L.ptr(CS), L.ptr(HS), L.ptr(HP), L.ptr(cst), L.ptr(ws), wsb, L.ptr(mixed_ws),
+                                          mixed_ws.numel(), st), "sat_lstm_fwd_bf16")
+        else:
+            L.check(lib.sat_lstm_fwd(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), pi.bs_c, T, In, H,
+                                     L.ptr(GA), L.ptr(CS), L.ptr(HS), L.ptr(HP), L.ptr(cst), L.ptr(ws), wsb, st), "sat_lstm_fwd")
         soff = lib.sat_lstm_fwd_status_offset(B, H)
         if soff >= 0 and wsb > 0:
             LstmWatch.get(dev).submit(ws, soff)          # the recurrence's status word: raises (at the latest one call later)
@@ -420,7 +425,7 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
     return logits, tapes
 
 
-def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi, grads_out, on_stage=None, ce=None):
+def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi, grads_out, on_stage=None, ce=None, mixed_ws=None):
     """Backward of decoder_forward_tapes.  `dlogits`: f32 [N, ld] with ld = V rounded up to 4 and zero pad columns.  grads_out: dict name -> preallocated f32 tensor to fill:
     'embed', ('w_ih',l), ('w_hh',l), ('b_ih',l), ('b_hh',l), 'lin_w', 'lin_b', 'features'.
     on_stage(i) is called when gradient group i is final (0 vocab projection, 1 LSTM) -- the data-parallel
@@ -456,10 +461,17 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
         dX = torch.empty(N, In, device=dev)
         wsb = lib.sat_lstm_bwd_ws_bytes_full(N, B, In, H) if _LSTM_SPLITK else lib.sat_lstm_bwd_ws_bytes(B, H)
         ws = torch.empty(wsb // 4, device=dev)
-        L.check(lib.sat_lstm_bwd(L.ptr(dH), L.ptr(tapes["X"][l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(GA), L.ptr(CS),
-                                 L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
-                                 L.ptr(grads_out[("w_hh", l)]), L.ptr(grads_out[("b_ih", l)]),
-                                 L.ptr(grads_out[("b_hh", l)]), L.ptr(dX), L.ptr(ws), wsb, st), "sat_lstm_bwd")
+        if mixed_ws is not None:
+            L.check(lib.sat_lstm_bwd_bf16(L.ptr(dH), L.ptr(tapes["X"][l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(GA), L.ptr(CS),
+                                          L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
+                                          L.ptr(grads_out[("w_hh", l)]), L.ptr(grads_out[("b_ih", l)]),
+                                          L.ptr(grads_out[("b_hh", l)]), L.ptr(dX), L.ptr(ws), wsb, L.ptr(mixed_ws), mixed_ws.numel(),
+                                          st), "sat_lstm_bwd_bf16")
+        else:
+            L.check(lib.sat_lstm_bwd(L.ptr(dH), L.ptr(tapes["X"][l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(GA), L.ptr(CS),
+                                     L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
+                                     L.ptr(grads_out[("w_hh", l)]), L.ptr(grads_out[("b_ih", l)]),
+                                     L.ptr(grads_out[("b_hh", l)]), L.ptr(dX), L.ptr(ws), wsb, st), "sat_lstm_bwd")
         dH = dX
     if on_stage is not None:
         on_stage(1)

@@ -203,8 +203,14 @@ class TrainStep:
         if ce is None and _FUSED_CE:          # projection + CE as one op; the backward forms d(loss)/d(logits) inside its GEMMs
             ce = dict(kind="fused", targets=bufs["targets"], inv_denom=inv_denom, lse=bufs["lse"], row_loss=bufs["row_loss"], loss_out=loss_slot,
                       ws=bufs["ce_ws"])
+        mixed_ws = None
+        if self.decoder_gemm_dtype == "bf16":          # the LSTM layers' batched GEMMs on the bf16 matrix pipe too
+            if "lstm_mixed_ws" not in bufs:
+                need = max(lib.sat_lstm_mixed_ws_bytes(N, E if l == 0 else dec.hidden_size, dec.hidden_size) for l in range(dec.num_layers))
+                bufs["lstm_mixed_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+            mixed_ws = bufs["lstm_mixed_ws"]
         logits, tapes = decoder_forward_tapes(lib, feats_in, dec.embed.weight, layers, dec.linear.weight,
-                                              dec.linear.bias, captions[:, :-1], pi, logits=bufs["logits"], ce=ce)
+                                              dec.linear.bias, captions[:, :-1], pi, logits=bufs["logits"], ce=ce, mixed_ws=mixed_ws)
         if ce is None:
             # ---- loss + d(loss)/d(logits) in place (train.py:143) ----
             L.check(lib.sat_ce_rows(L.ptr(logits), logits.stride(0), L.ptr(bufs["targets"]), N, V, float(inv_denom), 1,
@@ -216,7 +222,7 @@ class TrainStep:
             for short, n in (("w_ih", "weight_ih"), ("w_hh", "weight_hh"), ("b_ih", "bias_ih"), ("b_hh", "bias_hh")):
                 g[(short, l)] = flat.grad("decoder.lstm.%s_l%d" % (n, l))
         decoder_backward_tapes(lib, logits, tapes, dec.embed.weight, layers, dec.linear.weight, pi, g,
-                               on_stage=on_bucket_ready, ce=ce)
+                               on_stage=on_bucket_ready, ce=ce, mixed_ws=mixed_ws)
         if not cached_features:
             fc, bn = enc.resnet.fc, enc.bn
             L.check(lib.sat_fc_bn1d_bwd(L.ptr(bufs["d_feat"]), L.ptr(pooled), L.ptr(bufs["xhat"]), L.ptr(bufs["rstd"]),

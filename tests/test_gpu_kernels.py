@@ -1094,3 +1094,56 @@ def test_conv3_fused_bn_add_relu_single_launch_vs_reference(lib, Nimg, HW, Cout)
         np.testing.assert_allclose(drm3.cpu().numpy(), rm3.numpy(), rtol=1e-3, atol=1e-4)
         np.testing.assert_allclose(drv3.cpu().numpy(), rv3.numpy(), rtol=2e-3, atol=1e-4)
         acc3[parity].zero_()                       # (a consumer-less test: the next run of this parity starts from zero)
+
+
+@pytest.mark.parametrize("B,T,In,H", [(8, 6, 32, 64), (64, 19, 256, 512), (5, 4, 36, 48)])
+def test_lstm_layer_bf16_pipe_gemms_vs_exact_f32(lib, B, T, In, H):
+    """`sat_lstm_fwd_bf16` / `sat_lstm_bwd_bf16` (the layer's batched GEMMs -- x-gates, dW_ih, dW_hh, dX -- on the bf16 matrix pipe
+    from bf16 copies of the f32 operands; recurrence and gate arithmetic f32) against `sat_lstm_fwd` / `sat_lstm_bwd`: tapes and
+    gradients within bf16 operand rounding (1 % relative L2); ragged batch, K tails (models.py:52, train.py:144)."""
+    g = torch.Generator().manual_seed(B + T + H)
+    lengths = sorted([int(x) for x in torch.randint(1, T + 1, (B,), generator=g)], reverse=True)
+    lengths[0] = T
+    pi = sat.PackInfo.get(lengths, "cuda")
+    N = pi.N
+    k = 1.0 / H ** 0.5
+    X = torch.randn(N, In, generator=g)
+    ws_ = [torch.empty(4 * H, In).uniform_(-k, k, generator=g), torch.empty(4 * H, H).uniform_(-k, k, generator=g),
+           torch.empty(4 * H).uniform_(-k, k, generator=g), torch.empty(4 * H).uniform_(-k, k, generator=g)]
+    dH = torch.randn(N, H, generator=g) * 0.1
+    d = [cu(t) for t in [X] + ws_ + [dH]]
+    mb = lib.sat_lstm_mixed_ws_bytes(N, In, H)
+    assert mb > 0
+    mixed = torch.empty(mb, dtype=torch.uint8, device="cuda")
+
+    def run(bf):
+        GA, CS = torch.full((N, 4 * H), float("nan"), device="cuda"), torch.full((N, H), float("nan"), device="cuda")
+        HS, HP = torch.full((N, H), float("nan"), device="cuda"), torch.full((N, H), float("nan"), device="cuda")
+        cst = torch.empty(B, H, device="cuda")
+        wsb = lib.sat_lstm_fwd_ws_bytes(B, H)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+        args = (d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), pi.bs_c, pi.T, In, H,
+                GA.data_ptr(), CS.data_ptr(), HS.data_ptr(), HP.data_ptr(), cst.data_ptr(), ws.data_ptr(), wsb)
+        if bf:
+            L.check(lib.sat_lstm_fwd_bf16(*args, mixed.data_ptr(), mb, st()))
+        else:
+            L.check(lib.sat_lstm_fwd(*args, st()))
+        DG = torch.full((N, 4 * H), float("nan"), device="cuda")
+        dwi, dwh = torch.full((4 * H, In), float("nan"), device="cuda"), torch.full((4 * H, H), float("nan"), device="cuda")
+        dbi, dbh, dX = torch.empty(4 * H, device="cuda"), torch.empty(4 * H, device="cuda"), torch.full((N, In), float("nan"), device="cuda")
+        bwsb = lib.sat_lstm_bwd_ws_bytes_full(N, B, In, H)
+        bws = torch.empty(bwsb // 4, device="cuda")
+        bargs = (d[5].data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), GA.data_ptr(), CS.data_ptr(), HP.data_ptr(), pi.bs_c, pi.T,
+                 In, H, DG.data_ptr(), dwi.data_ptr(), dwh.data_ptr(), dbi.data_ptr(), dbh.data_ptr(), dX.data_ptr(), bws.data_ptr(), bwsb)
+        if bf:
+            L.check(lib.sat_lstm_bwd_bf16(*bargs, mixed.data_ptr(), mb, st()))
+        else:
+            L.check(lib.sat_lstm_bwd(*bargs, st()))
+        sync()
+        return dict(HS=HS.cpu(), CS=CS.cpu(), dwi=dwi.cpu(), dwh=dwh.cpu(), dbi=dbi.cpu(), dX=dX.cpu())
+    ref, got = run(False), run(True)
+    for key in ref:
+        assert torch.isfinite(got[key]).all(), key
+        rel = ((got[key] - ref[key]).norm() / (ref[key].norm() + 1e-20)).item()
+        assert rel < 1e-2, (key, rel)
+    assert lib.sat_lstm_fwd_bf16(*([None] * 5), pi.bs_c, pi.T, In, H, *([None] * 6), 0, None, 0, st()) == 1001
