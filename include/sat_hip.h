@@ -272,6 +272,11 @@ int sat_lstm_persist_enable(int on);
 int64_t sat_lstm_bwd_ws_bytes(int B, int H);          /* minimum */
 /* size that also lets the batched dW_ih / dX GEMMs run split-K when they would leave most CUs idle (N = packed rows) */
 int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H);
+/* With the FULL workspace (and the forward's envelope: H in {32,...,512}, T <= 64, ceil(B/8) * H/16 <= CUs) the backward
+ * recurrence runs as ONE persistent launch too (SAT_LSTM_PERSIST_BWD=0: one launch per step).  Its STATUS WORD (uint32) sits at
+ * this byte offset of the workspace: zeroed by every such call, non-zero when a bounded wait of the persistent launch ran out --
+ * DG and every gradient of that call are then INVALID; read it back behind the call as for sat_lstm_fwd_status_offset. */
+int64_t sat_lstm_bwd_status_offset(int N, int B, int In, int H);
 int sat_lstm_bwd(const float* dHS /*[N,H]*/, const float* X, const float* w_ih, const float* w_hh,
                  const float* GA, const float* CS, const float* HP,
                  const int32_t* batch_sizes /*[T] host*/, int T, int In, int H,

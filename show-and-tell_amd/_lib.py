@@ -90,6 +90,7 @@ SIGNATURES = {
     "sat_lstm_persist_enable": (_i, [_i]),
     "sat_lstm_bwd_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_bwd_ws_bytes_full": (_i64, [_i, _i, _i, _i]),
+    "sat_lstm_bwd_status_offset": (_i64, [_i, _i, _i, _i]),
     "sat_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_vocab_logits_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),

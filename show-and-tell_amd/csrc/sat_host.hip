@@ -195,6 +195,9 @@ extern "C" int sat_fc_bn1d_bwd(const float* dy, const float* pooled, const float
 bool sat_lstm_persist_ok(int B, int H, int T, int n_cu);          // sat_lstm_persist.hip
 int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, float* HP, const int32_t* batch_sizes, int T,
                             int H, void* workspace, int64_t ws_bytes, hipStream_t s);
+int64_t sat_lstm_persist_bwd_ws_bytes(int B, int H);
+int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* CS, const float* W, float* DG,
+                                const int32_t* batch_sizes, int T, int H, void* xch, unsigned* err, hipStream_t s);
 
 static int device_cu_count() {
     static int n = -1;
@@ -306,9 +309,17 @@ extern "C" int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H) {
     const int64_t base = sat_lstm_bwd_ws_bytes(B, H);
     const int64_t dx = (int64_t)fill_split(N, In, 4L * H) * N * In * sizeof(float);
     const int64_t dw = (int64_t)fill_split(4L * H, In, N) * 4 * H * In * sizeof(float);
-    const int64_t extra = dx > dw ? dx : dw;
-    return base > extra ? base : extra;
+    int64_t m = dx > dw ? dx : dw;
+    if (base > m) m = base;
+    const int64_t pb = sat_lstm_persist_bwd_ws_bytes(B, H);          // granule exchange of the persistent backward recurrence
+    if (pb > m) m = pb;
+    return (m + 255) / 256 * 256 + 64;                               // + the recurrence's status word (last 64 bytes)
 }
+
+// Byte offset of the backward recurrence's STATUS WORD (uint32) in a workspace of sat_lstm_bwd_ws_bytes_full bytes: zeroed by every
+// sat_lstm_bwd call that got the full workspace, set non-zero when the persistent backward recurrence gave up waiting for its
+// group (DG and every gradient of that call are then INVALID) -- read it back like sat_lstm_fwd_status_offset's word.
+extern "C" int64_t sat_lstm_bwd_status_offset(int N, int B, int In, int H) { return sat_lstm_bwd_ws_bytes_full(N, B, In, H) - 64; }
 
 static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, const float* w_hh, const float* GA,
                          const float* CS, const float* HP, const int32_t* batch_sizes, int T, int In, int H,
@@ -330,8 +341,24 @@ static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, co
     hipError_t e = hipMemsetAsync(dc_state, 0, (size_t)slab * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
     static const int fused_step = getenv("SAT_LSTM_BWD_FUSED") ? atoi(getenv("SAT_LSTM_BWD_FUSED")) : 1;
+    // the recurrence: ONE persistent launch (W_hh in registers, per-group exchange of the d(pre-activation) rows) when every
+    // workgroup can be resident and the caller brought the full workspace (its last 64 bytes = the status word); otherwise one
+    // launch per step
+    static const int persist_bwd = getenv("SAT_LSTM_PERSIST_BWD") ? atoi(getenv("SAT_LSTM_PERSIST_BWD")) : 1;
+    const int64_t full = sat_lstm_bwd_ws_bytes_full((int)N, B, In, H);
+    bool recurrence_done = false;
+    if (ws_bytes >= full) {
+        unsigned* status = (unsigned*)((char*)workspace + (full - 64));
+        if (persist_bwd && sat_lstm_persist_bwd_ws_bytes(B, H) > 0 && sat_lstm_persist_ok(B, H, T, device_cu_count())) {
+            SAT_TRY(sat_lstm_persist_bwd_launch(dHS, GA, CS, w_hh, DG, batch_sizes, T, H, workspace, status, s));
+            recurrence_done = true;
+        } else {
+            e = hipMemsetAsync(status, 0, 64, s);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
     long off = N;
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t = T - 1; t >= 0 && !recurrence_done; --t) {
         const int n = batch_sizes[t];
         off -= n;
         const int n_next = (t + 1 < T) ? batch_sizes[t + 1] : 0;

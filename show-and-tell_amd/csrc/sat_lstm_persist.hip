@@ -193,6 +193,183 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
     }
 }
 
+
+// ---- persistent BACKWARD recurrence (train.py:144 through models.py:52) -------------------------------------------------------
+// dh_t = dHS_t + DG_{t+1} W_hh, gate backward, dc carried -- all time steps in ONE launch, same decomposition as the forward:
+// groups of 8 batch rows, member workgroups of 16 hidden units.  A member needs the FULL d(pre-activation) rows DG_{t+1} of its
+// group (8 x 4H: every member's 16 units x 4 gates), so the exchange carries 8 x 64 granules per member and step (4x the
+// forward's) and the contraction runs over K = 4H: each of the 4 waves keeps a [H x 16] slice of W_hh in registers (128 VGPRs at
+// H = 512) and reduces its K quarter; the four partial 8 x 16 tiles meet in LDS.  dc stays in a register for the whole sequence.
+// Going backwards in time a group JOINS when its rows start (batch_sizes shrink with t), it never leaves.
+struct PersistBwdArgs {
+    const float* dHS;     // [N][H]
+    const float* GA;      // [N][4H] activated gates i,f,g,o
+    const float* CS;      // [N][H]
+    const float* W;       // [4H][H]
+    float* DG;            // [N][4H] out
+    unsigned long long* xch;   // [2 parities][groups][members][8 rows][64] granules, zeroed per call
+    unsigned* err;
+    unsigned spin_limit;
+    int dbg_stall;
+    int H, T, B, members;
+    int prefix[kMaxT + 1];
+};
+
+template <int NKB>      // H = 16 * NKB
+__global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(const PersistBwdArgs p) {
+    constexpr int H = 16 * NKB, K4 = 4 * H;
+    constexpr int GROW = K4 + 4;                       // LDS row stride (floats)
+    __shared__ __attribute__((aligned(16))) float g_lds[kRows * GROW];
+    __shared__ __attribute__((aligned(16))) float c_lds[4][kRows][16];
+    __shared__ int s_abort;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = blockIdx.x / p.members, member = blockIdx.x - group * p.members;
+    const int row0 = group * kRows;
+    const int n16 = lane & 15, kg = lane >> 4;
+    const int u0 = member * kUnits;
+
+    // ---- W_hh slice -> registers: wave w reduces k in [w*H, (w+1)*H); lane (n16, kg) holds W[w*H + 16 kb + 4 kg + e][u0 + n16] ----
+    f32x4 wreg[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wreg[kb][e] = p.W[(long)(wave * H + kb * 16 + kg * 4 + e) * H + u0 + n16];
+
+    for (int i = tid; i < kRows * GROW; i += 256) g_lds[i] = 0.0f;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+
+    // epilogue ownership: threads 0..127 own (row = tid >> 4, unit = u0 + (tid & 15)); dc lives in a register
+    const int erow = tid >> 4, eu = u0 + (tid & 15);
+    float dc_reg = 0.0f;
+    gu64* xch = (gu64*)p.xch;
+    const long slab = (long)p.members * kRows * 64;                        // granules per (parity, group)
+    const int groups = gridDim.x / p.members;
+
+    // the steps in which this group has rows: t in [0, Tg)
+    int Tg = 0;
+    for (int t = 0; t < p.T; ++t)
+        if (p.prefix[t + 1] - p.prefix[t] - row0 > 0) Tg = t + 1;
+
+    for (int t = Tg - 1; t >= 0; --t) {
+        const int active = p.prefix[t + 1] - p.prefix[t] - row0;          // > 0 for every t < Tg (batch sizes never grow with t)
+        const int next_active = (t + 1 < Tg) ? p.prefix[t + 2] - p.prefix[t + 1] - row0 : 0;     // rows of the group running at t+1
+
+        // ---- DG_{t+1} of my group: every member's granules of step t+1 (tag = t + 2) ----
+        if (t + 1 < Tg) {
+            const gu64* src = xch + ((long)((t + 1) & 1) * groups + group) * slab;
+            const int n = (int)slab;
+            const unsigned want = (unsigned)(t + 2);
+            unsigned spins = 0;
+            bool fail = false;
+            for (;;) {
+                bool ok = true;
+                for (int base = 0; base < n; base += 256 * 16) {
+                    unsigned long long x[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int i = base + tid + k * 256;
+                        x[k] = i < n ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : ((unsigned long long)want << 32);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int i = base + tid + k * 256;
+                        if ((unsigned)(x[k] >> 32) == want) {
+                            if (i < n) {
+                                const int mem = i >> 9, r = (i >> 6) & 7, gte = (i >> 4) & 3, u = i & 15;
+                                g_lds[r * GROW + gte * H + mem * kUnits + u] = __uint_as_float((unsigned)x[k]);
+                            }
+                        } else {
+                            ok = false;
+                        }
+                    }
+                }
+                if (__syncthreads_and(ok ? 1 : 0)) break;
+                if ((++spins & 63u) == 0) {
+                    if (tid == 0 && (spins > p.spin_limit ||
+                                     __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
+                        s_abort = 1;
+                    __syncthreads();
+                    if (s_abort) { fail = true; break; }
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (fail) {
+                if (tid == 0) __hip_atomic_store((gu32*)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+
+        // ---- the epilogue's own operands, fetched under the MFMAs ----
+        const bool own = tid < 128 && erow < active;
+        const long prow = (long)p.prefix[t] + row0 + erow;
+        float dhs = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cs = 0.f, cprev = 0.f;
+        if (own) {
+            dhs = p.dHS[prow * H + eu];
+            const float* ga = p.GA + prow * K4;
+            gi = ga[eu]; gf = ga[H + eu]; gg = ga[2 * H + eu]; go = ga[3 * H + eu];
+            cs = p.CS[prow * H + eu];
+            if (t > 0) cprev = p.CS[((long)p.prefix[t - 1] + row0 + erow) * H + eu];
+        }
+
+        // ---- dh partial of this wave: 16 rows (8 real) x 16 units over its K quarter ----
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const bool arow = n16 < kRows;
+        const float* gsrc = g_lds + n16 * GROW + wave * H + kg * 4;
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb += 2) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            if (arow) {
+                a0 = *(const f32x4*)(gsrc + kb * 16);
+                a1 = *(const f32x4*)(gsrc + kb * 16 + 16);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], wreg[kb][e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], wreg[kb + 1][e], acc1, 0, 0, 0);
+            }
+        }
+        if (kg < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c_lds[wave][kg * 4 + e][n16] = acc0[e] + acc1[e];
+        }
+        __syncthreads();
+
+        if (tid < 128) {
+            float dh = dhs;
+            if (erow < next_active)            // this row ran at t+1: the recurrent term exists (fixed order over the 4 K quarters)
+                dh += (c_lds[0][erow][tid & 15] + c_lds[1][erow][tid & 15]) + (c_lds[2][erow][tid & 15] + c_lds[3][erow][tid & 15]);
+            const float dcn = erow < next_active ? dc_reg : 0.0f;
+            const float tc = tanhf(cs);
+            const float d_o = dh * tc;
+            const float dc = dh * go * (1.0f - tc * tc) + dcn;
+            float d4[4];
+            d4[0] = dc * gg * gi * (1.0f - gi);
+            d4[1] = dc * cprev * gf * (1.0f - gf);
+            d4[2] = dc * gi * (1.0f - gg * gg);
+            d4[3] = d_o * go * (1.0f - go);
+            dc_reg = dc * gf;
+            if (!own) { d4[0] = d4[1] = d4[2] = d4[3] = 0.0f; dc_reg = 0.0f; }
+            if (own) {
+                float* dg = p.DG + prow * K4;
+                dg[eu] = d4[0]; dg[H + eu] = d4[1]; dg[2 * H + eu] = d4[2]; dg[3 * H + eu] = d4[3];
+            }
+            // publish DG_t of (row, unit) x 4 gates for the group: tag = t + 1 (never 0), parity t & 1
+            if (t > 0 && !(p.dbg_stall && blockIdx.x == 0)) {
+                gu64* dst = xch + ((long)(t & 1) * groups + group) * slab + ((long)member * kRows + erow) * 64 + (tid & 15);
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte)
+                    __hip_atomic_store(dst + gte * 16, ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(d4[gte]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();         // c_lds / g_lds are rewritten by the next step
+    }
+}
+
 }  // namespace
 
 bool sat_lstm_persist_has(int H);
@@ -255,6 +432,46 @@ int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, flo
     const dim3 grid(groups * members), block(256);
     switch (H / 16) {
 #define SAT_PERSIST_CASE(n) case n: hipLaunchKernelGGL((lstm_persist_kernel<n>), grid, block, 0, s, a); break;
+        SAT_PERSIST_CASE(2) SAT_PERSIST_CASE(4) SAT_PERSIST_CASE(6) SAT_PERSIST_CASE(8) SAT_PERSIST_CASE(16) SAT_PERSIST_CASE(32)
+#undef SAT_PERSIST_CASE
+        default:
+            if (token) (void)sat_resident_token_release(s);
+            return SAT_ERR_UNSUPPORTED;
+    }
+    SAT_LAUNCH_CHECK();
+    return token ? sat_resident_token_release(s) : SAT_OK;
+}
+
+// granule exchange of the persistent BACKWARD recurrence (+ 64 bytes for its status word)
+int64_t sat_lstm_persist_bwd_ws_bytes(int B, int H) {
+    if (H < 16 || (H % 16)) return 0;
+    const int64_t groups = (B + kRows - 1) / kRows, members = H / kUnits;
+    return 2 * groups * members * kRows * 64 * 8 + 64;
+}
+
+int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* CS, const float* W, float* DG,
+                                const int32_t* batch_sizes, int T, int H, void* xch, unsigned* err, hipStream_t s) {
+    const int B = batch_sizes[0];
+    const int groups = (B + kRows - 1) / kRows, members = H / kUnits;
+    PersistBwdArgs a = {};
+    a.dHS = dHS; a.GA = GA; a.CS = CS; a.W = W; a.DG = DG;
+    a.xch = (unsigned long long*)xch; a.err = err;
+    a.H = H; a.T = T; a.B = B; a.members = members;
+    const char* sl = getenv("SAT_LSTM_SPIN_LIMIT");
+    a.spin_limit = (sl && atol(sl) > 0) ? (unsigned)atol(sl) : kSpinLimit;
+    const char* ds = getenv("SAT_LSTM_DEBUG_STALL");
+    a.dbg_stall = (ds && ds[0] == '2') ? 1 : 0;
+    a.prefix[0] = 0;
+    for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
+    hipError_t e = hipMemsetAsync(xch, 0, (size_t)(sat_lstm_persist_bwd_ws_bytes(B, H) - 64), s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(err, 0, 64, s);
+    if (e != hipSuccess) return (int)e;
+    const bool token = sat_resident_token_in_use() != 0;
+    if (token) SAT_TRY(sat_resident_token_acquire(a.err, s));
+    const dim3 grid(groups * members), block(256);
+    switch (H / 16) {
+#define SAT_PERSIST_CASE(n) case n: hipLaunchKernelGGL((lstm_persist_bwd_kernel<n>), grid, block, 0, s, a); break;
         SAT_PERSIST_CASE(2) SAT_PERSIST_CASE(4) SAT_PERSIST_CASE(6) SAT_PERSIST_CASE(8) SAT_PERSIST_CASE(16) SAT_PERSIST_CASE(32)
 #undef SAT_PERSIST_CASE
         default:

@@ -472,6 +472,9 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
                                      L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
                                      L.ptr(grads_out[("w_hh", l)]), L.ptr(grads_out[("b_ih", l)]),
                                      L.ptr(grads_out[("b_hh", l)]), L.ptr(dX), L.ptr(ws), wsb, st), "sat_lstm_bwd")
+        if _LSTM_SPLITK:                       # full workspace: the backward recurrence may have run persistently -- its status word
+            soff = lib.sat_lstm_bwd_status_offset(N, B, In, H)
+            LstmWatch.get(dev).submit(ws.view(torch.uint8), soff)
         dH = dX
     if on_stage is not None:
         on_stage(1)

@@ -1147,3 +1147,55 @@ def test_lstm_layer_bf16_pipe_gemms_vs_exact_f32(lib, B, T, In, H):
         rel = ((got[key] - ref[key]).norm() / (ref[key].norm() + 1e-20)).item()
         assert rel < 1e-2, (key, rel)
     assert lib.sat_lstm_fwd_bf16(*([None] * 5), pi.bs_c, pi.T, In, H, *([None] * 6), 0, None, 0, st()) == 1001
+
+
+@pytest.mark.parametrize("B,T,In,H,ragged", [(64, 19, 256, 512, False), (64, 19, 256, 512, True), (16, 7, 32, 64, True), (5, 4, 36, 48, True),
+                                             (24, 12, 64, 128, True)])
+def test_lstm_bwd_persistent_recurrence_equals_per_step_launches(lib, B, T, In, H, ragged, monkeypatch):
+    """sat_lstm_bwd with the FULL workspace (the backward recurrence as ONE persistent launch: W_hh quarter per wave in registers,
+    per-group exchange of the d(pre-activation) rows, dc in a register) against the same entry point with the minimal workspace
+    (one fused launch per step): DG and every gradient to 2e-6 relative of the largest entry (another K summation order); status
+    word clean; and a withheld hand-off (SAT_LSTM_DEBUG_STALL=2) is REPORTED through the status word.  train.py:144 / models.py:52"""
+    g = torch.Generator().manual_seed(B * 5 + T + H)
+    lengths = sorted([int(x) for x in torch.randint(1, T + 1, (B,), generator=g)], reverse=True) if ragged else [T] * B
+    lengths[0] = T
+    pi = sat.PackInfo.get(lengths, "cuda")
+    N = pi.N
+    k = 1.0 / H ** 0.5
+    X = torch.randn(N, In, generator=g)
+    ws_ = [torch.empty(4 * H, In).uniform_(-k, k, generator=g), torch.empty(4 * H, H).uniform_(-k, k, generator=g),
+           torch.empty(4 * H).uniform_(-k, k, generator=g), torch.empty(4 * H).uniform_(-k, k, generator=g)]
+    dH = torch.randn(N, H, generator=g) * 0.1
+    d = [cu(t) for t in [X] + ws_ + [dH]]
+    GA, CS = torch.empty(N, 4 * H, device="cuda"), torch.empty(N, H, device="cuda")
+    HS, HP = torch.empty(N, H, device="cuda"), torch.empty(N, H, device="cuda")
+    cst = torch.empty(B, H, device="cuda")
+    L.check(lib.sat_lstm_fwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), pi.bs_c, pi.T, In, H,
+                             GA.data_ptr(), CS.data_ptr(), HS.data_ptr(), HP.data_ptr(), cst.data_ptr(), None, 0, st()))
+    full = lib.sat_lstm_bwd_ws_bytes_full(N, B, In, H)
+    soff = lib.sat_lstm_bwd_status_offset(N, B, In, H)
+    assert soff == full - 64
+
+    def run(nbytes):
+        DG = torch.full((N, 4 * H), float("nan"), device="cuda")
+        dwi, dwh = torch.full((4 * H, In), float("nan"), device="cuda"), torch.full((4 * H, H), float("nan"), device="cuda")
+        dbi, dbh, dX = torch.empty(4 * H, device="cuda"), torch.empty(4 * H, device="cuda"), torch.full((N, In), float("nan"), device="cuda")
+        bws = torch.full((nbytes // 4,), float("nan"), device="cuda")
+        L.check(lib.sat_lstm_bwd(d[5].data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), GA.data_ptr(), CS.data_ptr(), HP.data_ptr(),
+                                 pi.bs_c, pi.T, In, H, DG.data_ptr(), dwi.data_ptr(), dwh.data_ptr(), dbi.data_ptr(), dbh.data_ptr(),
+                                 dX.data_ptr(), bws.data_ptr(), nbytes, st()))
+        sync()
+        status = int(bws.view(torch.int32)[soff // 4].item()) if nbytes >= full else 0
+        return dict(DG=DG.cpu(), dwi=dwi.cpu(), dwh=dwh.cpu(), dbi=dbi.cpu(), dX=dX.cpu()), status
+    step, _ = run(lib.sat_lstm_bwd_ws_bytes(B, H))
+    pers, status = run(full)
+    assert status == 0, "persistent backward recurrence timed out"
+    for key in step:
+        assert torch.isfinite(pers[key]).all(), key
+        scale = step[key].abs().max().item() + 1e-30
+        assert (pers[key] - step[key]).abs().max().item() < 2e-6 * scale + 1e-9, (key, (pers[key] - step[key]).abs().max().item(), scale)
+    if lib.sat_lstm_fwd_ws_bytes(B, H) > 0 and B >= 16:
+        monkeypatch.setenv("SAT_LSTM_DEBUG_STALL", "2")
+        monkeypatch.setenv("SAT_LSTM_SPIN_LIMIT", "128")
+        _, status = run(full)
+        assert status != 0                       # reported, not swallowed (models.LstmWatch raises on it)
