@@ -196,31 +196,35 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
 
 // ---- persistent BACKWARD recurrence (train.py:144 through models.py:52) -------------------------------------------------------
 // dh_t = dHS_t + DG_{t+1} W_hh, gate backward, dc carried -- all time steps in ONE launch, same decomposition as the forward:
-// groups of 8 batch rows, member workgroups of 16 hidden units.  A member needs the FULL d(pre-activation) rows DG_{t+1} of its
-// group (8 x 4H: every member's 16 units x 4 gates), so the exchange carries 8 x 64 granules per member and step (4x the
-// forward's) and the contraction runs over K = 4H: each of the 4 waves keeps a [H x 16] slice of W_hh in registers (128 VGPRs at
-// H = 512) and reduces its K quarter; the four partial 8 x 16 tiles meet in LDS.  dc stays in a register for the whole sequence.
-// Going backwards in time a group JOINS when its rows start (batch_sizes shrink with t), it never leaves.
+// groups of 8 batch rows, member workgroups of 16 hidden units.  The contraction runs over K = 4H gate columns, and a member
+// PRODUCES exactly 64 of them (its 16 units x 4 gates).  So the product is split over K by member: each member multiplies ITS
+// OWN fresh d(pre-activation) tile [8 x 64] with its W_hh slice [64 x H] (register resident: 128 VGPRs at H = 512) into a partial
+// dh for ALL H units and hands every other member the 8 x 16 block that member owns -- the exchange carries 8 x 16 granules per
+// (source, destination) pair and a member sweeps members x 128 granules per step, the forward's volume, summing the partials in
+// member order as they arrive in its registers (no LDS staging; even / odd sources in two thread halves, combined in a fixed
+// order).  dc stays in a register for the whole sequence.  Going backwards in time a group JOINS when its rows start
+// (batch_sizes shrink with t); it never leaves.
 struct PersistBwdArgs {
     const float* dHS;     // [N][H]
     const float* GA;      // [N][4H] activated gates i,f,g,o
     const float* CS;      // [N][H]
     const float* W;       // [4H][H]
     float* DG;            // [N][4H] out
-    unsigned long long* xch;   // [2 parities][groups][members][8 rows][64] granules, zeroed per call
+    unsigned long long* xch;   // [2 parities][groups][dest member][src member][8 rows][16 units] granules (NOT zeroed: epoch tags)
     unsigned* err;
     unsigned spin_limit;
+    unsigned epoch;       // call counter: tags are epoch * 128 + step + 1, so granules of an earlier call never match (no 17 MB memset)
     int dbg_stall;
     int H, T, B, members;
     int prefix[kMaxT + 1];
 };
 
-template <int NKB>      // H = 16 * NKB
+template <int NKB>      // H = 16 * NKB (NKB = members)
 __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(const PersistBwdArgs p) {
     constexpr int H = 16 * NKB, K4 = 4 * H;
-    constexpr int GROW = K4 + 4;                       // LDS row stride (floats)
-    __shared__ __attribute__((aligned(16))) float g_lds[kRows * GROW];
-    __shared__ __attribute__((aligned(16))) float c_lds[4][kRows][16];
+    constexpr int TPW = (NKB + 3) / 4;                 // destination members (16-column tiles) per wave
+    __shared__ __attribute__((aligned(16))) float d_lds[kRows][64 + 4];      // my DG_t tile: [row][gate * 16 + unit]
+    __shared__ float half_lds[128];
     __shared__ int s_abort;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -230,64 +234,79 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(const PersistBwdA
     const int n16 = lane & 15, kg = lane >> 4;
     const int u0 = member * kUnits;
 
-    // ---- W_hh slice -> registers: wave w reduces k in [w*H, (w+1)*H); lane (n16, kg) holds W[w*H + 16 kb + 4 kg + e][u0 + n16] ----
-    f32x4 wreg[NKB];
+    // ---- W_hh slice -> registers: rows = my 64 gate columns (local k = gate * 16 + unit), columns = all H hidden units; wave w
+    //      owns destination members w * TPW ..; lane (n16, kg) holds W[gate*H + u0 + unit][dest * 16 + n16] for local
+    //      k = 16 kb + 4 kg + e ----
+    f32x4 wreg[4][TPW];
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wreg[kb][e] = p.W[(long)(wave * H + kb * 16 + kg * 4 + e) * H + u0 + n16];
-
-    for (int i = tid; i < kRows * GROW; i += 256) g_lds[i] = 0.0f;
+        for (int tl = 0; tl < TPW; ++tl) {
+            const int dest = wave * TPW + tl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kl = kb * 16 + kg * 4 + e;                     // gate = kl >> 4, unit = kl & 15
+                wreg[kb][tl][e] = dest < NKB ? p.W[(long)((kl >> 4) * H + u0 + (kl & 15)) * H + dest * 16 + n16] : 0.0f;
+            }
+        }
     if (tid == 0) s_abort = 0;
     __syncthreads();
 
     // epilogue ownership: threads 0..127 own (row = tid >> 4, unit = u0 + (tid & 15)); dc lives in a register
-    const int erow = tid >> 4, eu = u0 + (tid & 15);
+    const int erow = (tid & 127) >> 4, eu = u0 + (tid & 15);
     float dc_reg = 0.0f;
     gu64* xch = (gu64*)p.xch;
-    const long slab = (long)p.members * kRows * 64;                        // granules per (parity, group)
+    const long pair = (long)kRows * 16;                                     // granules per (dest, src) pair
+    const long slab = (long)p.members * p.members * pair;                   // granules per (parity, group)
     const int groups = gridDim.x / p.members;
 
-    // the steps in which this group has rows: t in [0, Tg)
-    int Tg = 0;
+    int Tg = 0;                                                             // the steps in which this group has rows: t in [0, Tg)
     for (int t = 0; t < p.T; ++t)
         if (p.prefix[t + 1] - p.prefix[t] - row0 > 0) Tg = t + 1;
 
     for (int t = Tg - 1; t >= 0; --t) {
-        const int active = p.prefix[t + 1] - p.prefix[t] - row0;          // > 0 for every t < Tg (batch sizes never grow with t)
-        const int next_active = (t + 1 < Tg) ? p.prefix[t + 2] - p.prefix[t + 1] - row0 : 0;     // rows of the group running at t+1
+        const int active = p.prefix[t + 1] - p.prefix[t] - row0;           // > 0 for every t < Tg
+        const int next_active = (t + 1 < Tg) ? p.prefix[t + 2] - p.prefix[t + 1] - row0 : 0;
 
-        // ---- DG_{t+1} of my group: every member's granules of step t+1 (tag = t + 2) ----
+        // ---- the epilogue's own operands (issued before the sweep: they do not depend on it) ----
+        const bool own = tid < 128 && erow < active;
+        const long prow = (long)p.prefix[t] + row0 + erow;
+        float dhs = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cs = 0.f, cprev = 0.f;
+        if (own) {
+            dhs = p.dHS[prow * H + eu];
+            const float* ga = p.GA + prow * K4;
+            gi = ga[eu]; gf = ga[H + eu]; gg = ga[2 * H + eu]; go = ga[3 * H + eu];
+            cs = p.CS[prow * H + eu];
+            if (t > 0) cprev = p.CS[((long)p.prefix[t - 1] + row0 + erow) * H + eu];
+        }
+
+        // ---- the recurrent term: partial dh blocks of step t+1 from every member of my group (tag = t + 2), summed per
+        //      (row, unit) over the source members in a fixed order: thread half q sums sources q, q+2, q+4, ... ----
+        float rec = 0.0f;
         if (t + 1 < Tg) {
-            const gu64* src = xch + ((long)((t + 1) & 1) * groups + group) * slab;
-            const int n = (int)slab;
-            const unsigned want = (unsigned)(t + 2);
+            const gu64* src = xch + (((long)((t + 1) & 1) * groups + group) * p.members + member) * p.members * pair;
+            const unsigned want = p.epoch * 128u + (unsigned)(t + 2);
+            const int q = tid >> 7, cell = tid & 127;
             unsigned spins = 0;
             bool fail = false;
             for (;;) {
                 bool ok = true;
-                for (int base = 0; base < n; base += 256 * 16) {
+                float sum = 0.0f;
+                for (int m0 = 0; m0 < NKB; m0 += 32) {
                     unsigned long long x[16];
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
-                        const int i = base + tid + k * 256;
-                        x[k] = i < n ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                     : ((unsigned long long)want << 32);
+                        const int m = m0 + q + 2 * k;
+                        x[k] = m < NKB ? __hip_atomic_load(src + (long)m * pair + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : ((unsigned long long)want << 32);
                     }
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
-                        const int i = base + tid + k * 256;
-                        if ((unsigned)(x[k] >> 32) == want) {
-                            if (i < n) {
-                                const int mem = i >> 9, r = (i >> 6) & 7, gte = (i >> 4) & 3, u = i & 15;
-                                g_lds[r * GROW + gte * H + mem * kUnits + u] = __uint_as_float((unsigned)x[k]);
-                            }
-                        } else {
-                            ok = false;
-                        }
+                        if ((unsigned)(x[k] >> 32) != want) ok = false;
+                        sum += __uint_as_float((unsigned)x[k]);
                     }
                 }
-                if (__syncthreads_and(ok ? 1 : 0)) break;
+                if (__syncthreads_and(ok ? 1 : 0)) { rec = sum; break; }
                 if ((++spins & 63u) == 0) {
                     if (tid == 0 && (spins > p.spin_limit ||
                                      __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
@@ -301,47 +320,13 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(const PersistBwdA
                 if (tid == 0) __hip_atomic_store((gu32*)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-        }
-
-        // ---- the epilogue's own operands, fetched under the MFMAs ----
-        const bool own = tid < 128 && erow < active;
-        const long prow = (long)p.prefix[t] + row0 + erow;
-        float dhs = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cs = 0.f, cprev = 0.f;
-        if (own) {
-            dhs = p.dHS[prow * H + eu];
-            const float* ga = p.GA + prow * K4;
-            gi = ga[eu]; gf = ga[H + eu]; gg = ga[2 * H + eu]; go = ga[3 * H + eu];
-            cs = p.CS[prow * H + eu];
-            if (t > 0) cprev = p.CS[((long)p.prefix[t - 1] + row0 + erow) * H + eu];
-        }
-
-        // ---- dh partial of this wave: 16 rows (8 real) x 16 units over its K quarter ----
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const bool arow = n16 < kRows;
-        const float* gsrc = g_lds + n16 * GROW + wave * H + kg * 4;
-#pragma unroll
-        for (int kb = 0; kb < NKB; kb += 2) {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-            if (arow) {
-                a0 = *(const f32x4*)(gsrc + kb * 16);
-                a1 = *(const f32x4*)(gsrc + kb * 16 + 16);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], wreg[kb][e], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], wreg[kb + 1][e], acc1, 0, 0, 0);
-            }
-        }
-        if (kg < 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c_lds[wave][kg * 4 + e][n16] = acc0[e] + acc1[e];
+            if (tid >= 128) half_lds[tid & 127] = rec;
         }
         __syncthreads();
 
         if (tid < 128) {
             float dh = dhs;
-            if (erow < next_active)            // this row ran at t+1: the recurrent term exists (fixed order over the 4 K quarters)
-                dh += (c_lds[0][erow][tid & 15] + c_lds[1][erow][tid & 15]) + (c_lds[2][erow][tid & 15] + c_lds[3][erow][tid & 15]);
+            if (erow < next_active) dh += rec + half_lds[tid];        // even sources + odd sources: fixed order
             const float dcn = erow < next_active ? dc_reg : 0.0f;
             const float tc = tanhf(cs);
             const float d_o = dh * tc;
@@ -357,16 +342,43 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(const PersistBwdA
                 float* dg = p.DG + prow * K4;
                 dg[eu] = d4[0]; dg[H + eu] = d4[1]; dg[2 * H + eu] = d4[2]; dg[3 * H + eu] = d4[3];
             }
-            // publish DG_t of (row, unit) x 4 gates for the group: tag = t + 1 (never 0), parity t & 1
-            if (t > 0 && !(p.dbg_stall && blockIdx.x == 0)) {
-                gu64* dst = xch + ((long)(t & 1) * groups + group) * slab + ((long)member * kRows + erow) * 64 + (tid & 15);
 #pragma unroll
-                for (int gte = 0; gte < 4; ++gte)
-                    __hip_atomic_store(dst + gte * 16, ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(d4[gte]),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int gte = 0; gte < 4; ++gte) d_lds[erow][gte * 16 + (tid & 15)] = d4[gte];
+        }
+        if (t == 0) break;                          // nothing consumes a hand-off of step 0
+        __syncthreads();
+
+        // ---- my share of dh_{t-1}: P[8 x H] = DG_t[8 x 64 (mine)] W_hh[64 x H]; tile tl of wave w belongs to member w*TPW + tl ----
+        f32x4 acc[TPW];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) acc[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (n16 < kRows) a = *(const f32x4*)(&d_lds[n16][kb * 16 + kg * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl)
+                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wreg[kb][tl][e], acc[tl], 0, 0, 0);
+        }
+        // C/D map: col = lane & 15 (unit of the destination member), row = (lane >> 4) * 4 + reg: rows 0..7 sit in lanes kg < 2
+        if (kg < 2 && !(p.dbg_stall && blockIdx.x == 0)) {
+            gu64* dst0 = xch + ((long)(t & 1) * groups + group) * slab;
+            const unsigned long long tag = (unsigned long long)(p.epoch * 128u + (unsigned)(t + 1)) << 32;
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) {
+                const int dest = wave * TPW + tl;
+                if (dest < NKB) {
+                    gu64* dst = dst0 + ((long)dest * p.members + member) * pair + n16;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        __hip_atomic_store(dst + (kg * 4 + e) * 16, tag | (unsigned long long)__float_as_uint(acc[tl][e]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
-        __syncthreads();         // c_lds / g_lds are rewritten by the next step
+        __syncthreads();         // d_lds / half_lds are rewritten by the next step
     }
 }
 
@@ -446,7 +458,7 @@ int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, flo
 int64_t sat_lstm_persist_bwd_ws_bytes(int B, int H) {
     if (H < 16 || (H % 16)) return 0;
     const int64_t groups = (B + kRows - 1) / kRows, members = H / kUnits;
-    return 2 * groups * members * kRows * 64 * 8 + 64;
+    return 2 * groups * members * members * kRows * 16 * 8 + 64;
 }
 
 int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* CS, const float* W, float* DG,
@@ -463,9 +475,10 @@ int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* 
     a.dbg_stall = (ds && ds[0] == '2') ? 1 : 0;
     a.prefix[0] = 0;
     for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
-    hipError_t e = hipMemsetAsync(xch, 0, (size_t)(sat_lstm_persist_bwd_ws_bytes(B, H) - 64), s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(err, 0, 64, s);
+    static unsigned epoch = 0;
+    a.epoch = (++epoch) & 0x00ffffffu;
+    if (a.epoch == 0) a.epoch = epoch = 1;
+    hipError_t e = hipMemsetAsync(err, 0, 64, s);
     if (e != hipSuccess) return (int)e;
     const bool token = sat_resident_token_in_use() != 0;
     if (token) SAT_TRY(sat_resident_token_acquire(a.err, s));
