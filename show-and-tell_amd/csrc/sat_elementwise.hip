@@ -12,7 +12,11 @@ namespace {
 constexpr int EW_BLOCK = 256;
 inline int ew_grid(long n_items) {
     static long cap = 0;
-    if (cap == 0) { const char* e = getenv("SAT_EW_GRID_CAP"); cap = e ? atol(e) : 2048; if (cap < 1) cap = 2048; }
+    // 768 workgroups (3 per CU), measured under the encoder look-ahead (tools/run_gpu_bn_ab.sh, round 3): with three stacks in
+    // flight the HBM-bound BatchNorm passes of one stack run beside the convs of the others, and a grid that takes fewer wave
+    // slots per CU leaves those convs their CUs: 2048 / 1024 / 768 / 512 / 384 = 13.55 / 13.8 / 14.0 / 13.95 k img/s (with the
+    // non-temporal operand loads 13.75 / 14.2 / 14.27 / 14.3 / 14.3 k); the sequential step does not move until 384 (6.36 -> 6.49 ms)
+    if (cap == 0) { const char* e = getenv("SAT_EW_GRID_CAP"); cap = e ? atol(e) : 768; if (cap < 1) cap = 768; }
     long b = (n_items + EW_BLOCK - 1) / EW_BLOCK;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));   // cap and grid-stride the rest
 }
@@ -33,6 +37,11 @@ template <> __device__ __forceinline__ void load_chunk<bf16_t>(const bf16_t* p, 
 }
 // raw 16-byte load now, conversion later: lets a kernel put loads in flight before work they do not depend on
 template <typename T> __device__ __forceinline__ u32x4 load_raw(const T* p) { return *(const u32x4*)p; }
+// NT: non-temporal (streaming) load -- for an operand no later kernel reads again
+template <typename T, bool NT> __device__ __forceinline__ u32x4 load_in(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const u32x4*)p);
+    else return *(const u32x4*)p;
+}
 template <typename T> __device__ __forceinline__ void unpack_chunk(const u32x4& r, float (&v)[Vec<T>::N]);
 template <> __device__ __forceinline__ void unpack_chunk<float>(const u32x4& r, float (&v)[4]) {
 #pragma unroll
@@ -246,8 +255,9 @@ __device__ __forceinline__ void bn_table_from_acc(const BnSrc& b, int C, double 
 // out = relu(in0*s0 + t0)  /  out = relu(in0*s0 + t0 + (in1*s1 + t1 | in1)); NHWC, C % chunk == 0.
 // The launcher makes the total thread count a multiple of the chunks per pixel, so a thread's channel chunk never
 // changes along its grid-stride walk: scale/shift live in registers and the loop is pure 16-byte streaming.
-template <typename T, bool ADD>
-__global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ in1, T* __restrict__ out,
+// `out` may alias `in0` (in-place normalise: every chunk is read before it is written, by the thread that writes it).
+template <typename T, bool ADD, bool NT = false>
+__global__ void bn_act_kernel(const T* in0, const T* __restrict__ in1, T* out,
                               const BnSrc b0, const BnSrc b1, int has_b1, double count, float momentum, float eps,
                               long nchunks, int C) {
     constexpr int V = Vec<T>::N;
@@ -268,8 +278,8 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
         for (int u = 0; u < U; ++u) {
             const long iu = i0 + u * stride;
             if (iu < nchunks) {
-                rx[u] = load_raw<T>(in0 + iu * V);
-                if constexpr (ADD) rz[u] = load_raw<T>(in1 + iu * V);
+                rx[u] = load_in<T, NT>(in0 + iu * V);
+                if constexpr (ADD) rz[u] = load_in<T, NT>(in1 + iu * V);
             }
         }
     }
@@ -301,8 +311,8 @@ __global__ void bn_act_kernel(const T* __restrict__ in0, const T* __restrict__ i
             for (int u = 0; u < U; ++u) {          // next stage in flight while this one is computed and stored
                 const long iu = inext + u * stride;
                 if (iu < nchunks) {
-                    nx[u] = load_raw<T>(in0 + iu * V);
-                    if constexpr (ADD) nz[u] = load_raw<T>(in1 + iu * V);
+                    nx[u] = load_in<T, NT>(in0 + iu * V);
+                    if constexpr (ADD) nz[u] = load_in<T, NT>(in1 + iu * V);
                 }
             }
 #pragma unroll
@@ -995,7 +1005,21 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
         if (grid < g0) grid = g0;
     }
     const double count = (double)op->count;
-    if (add)
+    // The normalise+add kernel reads its two operands with NON-TEMPORAL loads: both are dead after it (the raw conv3 tensor, and
+    // the block input that y replaces), so they need not displace the other stacks' live tensors from the Infinity Cache.
+    // Measured under look-ahead (round 3): +1.2-2.9 % at every grid size (13.55 -> 13.75 k at 2048 workgroups, 14.0 -> 14.27 k at
+    // 768); SAT_BN_NT=0 restores plain loads, =2 also reads the normalise+ReLU kernel's operand that way.
+    static const int bn_nt = getenv("SAT_BN_NT") ? atoi(getenv("SAT_BN_NT")) : 1;
+    if (!add && bn_nt >= 2) {
+        hipLaunchKernelGGL((bn_act_kernel<T, false, true>), dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (const T*)nullptr,
+                           (T*)op->out, b0, b1, 0, count, op->momentum, op->eps, nch, C);
+        SAT_LAUNCH_CHECK();
+        return SAT_OK;
+    }
+    if (add && bn_nt)
+        hipLaunchKernelGGL((bn_act_kernel<T, true, true>), dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (const T*)op->in1,
+                           (T*)op->out, b0, b1, has_b1, count, op->momentum, op->eps, nch, C);
+    else if (add)
         hipLaunchKernelGGL((bn_act_kernel<T, true>), dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (const T*)op->in1,
                            (T*)op->out, b0, b1, has_b1, count, op->momentum, op->eps, nch, C);
     else

@@ -409,6 +409,12 @@ class ConvStackProgram:
             nblk = len(list(stack.blocks()))
             self.fused_sync = alloc((nblk, 2), torch.int32, zero=True)
             self.fused_err = alloc((4,), torch.int32, zero=True)
+        # IN-PLACE BatchNorm-apply passes (bf16 training): relu(bn1(c1)) overwrites c1, and conv3 writes its raw output straight into
+        # the next block-output buffer, which the normalise+add pass then transforms in place -- a bottleneck touches two large
+        # buffers instead of three (c3 disappears), so a stack's live set in layer 3 drops from ~90 to ~65 MB and three stacks in
+        # flight fit the 256 MB Infinity Cache (the look-ahead step is bound by memory traffic).  SAT_BN_INPLACE=0: off.
+        inplace = (training and dtype == L.SAT_BF16 and not fuse_resid and not two_pass and
+                   os.environ.get("SAT_BN_INPLACE", "1") != "0")
         pending = None          # (s3, t3, resid buffer) of the previous block when its bn_add is deferred to this conv1
         blocks_geo = list(zip(stack.blocks(), geo))
         for bi, (blk, (h, w_, h2, w2, inpl, planes, stride)) in enumerate(blocks_geo):
@@ -467,8 +473,9 @@ class ConvStackProgram:
                     cv2.count, cv2.momentum, cv2.eps = count1_, BN_MOMENTUM, BN_EPS
                 ops.append(cv2)
             else:
-                ops.append(act_op(L.OP_BN_RELU, self.c1, s1, t1, self.a1, N, h, w_, planes))
-                ops.append(std_conv(blk.conv2, self.a1, self.c2, N, h, w_, h2, w2))
+                a1buf = self.c1 if inplace else self.a1
+                ops.append(act_op(L.OP_BN_RELU, self.c1, s1, t1, a1buf, N, h, w_, planes))
+                ops.append(std_conv(blk.conv2, a1buf, self.c2, N, h, w_, h2, w2))
             f, s2, t2 = fin_op(blk.bn2, planes, N * h2 * w2, tm2)
             add(f)
             ref2 = bnref.get(s2.data_ptr())
@@ -499,7 +506,8 @@ class ConvStackProgram:
                 continue
             if fuse_in_bn and planes <= 512 and planes % 64 == 0:
                 # conv3 reads the RAW c2 and applies bn2 + ReLU to its A operand in LDS: a2 never exists in HBM
-                cv3 = std_conv(blk.conv3, self.c2, self.c3, N, h2, w2, h2, w2)
+                c3buf = ynext if inplace else self.c3
+                cv3 = std_conv(blk.conv3, self.c2, c3buf, N, h2, w2, h2, w2)
                 ref = bnref.get(s2.data_ptr())
                 if ref is None:
                     cv3.scale0, cv3.shift0 = s2.data_ptr(), t2.data_ptr()
@@ -511,8 +519,10 @@ class ConvStackProgram:
                     cv3.count, cv3.momentum, cv3.eps = count2, BN_MOMENTUM, BN_EPS
                 ops.append(cv3)
             else:
-                ops.append(act_op(L.OP_BN_RELU, self.c2, s2, t2, self.a2, N, h2, w2, planes))
-                ops.append(std_conv(blk.conv3, self.a2, self.c3, N, h2, w2, h2, w2))
+                c3buf = ynext if inplace else self.c3
+                a2buf = self.c2 if inplace else self.a2
+                ops.append(act_op(L.OP_BN_RELU, self.c2, s2, t2, a2buf, N, h2, w2, planes))
+                ops.append(std_conv(blk.conv3, a2buf, c3buf, N, h2, w2, h2, w2))
             cv3_first = ops[-1]
             f, s3, t3 = fin_op(blk.bn3, planes * 4, N * h2 * w2, tm2)
             add(f)
@@ -542,11 +552,11 @@ class ConvStackProgram:
                 ops.append(std_conv(blk.downsample[0], y, self.cd, N, h, w_, h2, w2))
                 f, sd, td_ = fin_op(blk.downsample[1], planes * 4, N * h2 * w2, tm2)
                 add(f)
-                ops.append(act_op(L.OP_BN_ADD_RELU, self.c3, s3, t3, ynext, N, h2, w2, planes * 4, self.cd, sd, td_))
+                ops.append(act_op(L.OP_BN_ADD_RELU, c3buf, s3, t3, ynext, N, h2, w2, planes * 4, self.cd, sd, td_))
             elif (fuse_resid and bi + 1 < len(blocks_geo) and (planes * 4) % 64 == 0 and planes * 4 <= 2048):
                 pending = (s3, t3, y)            # the next block's conv1 forms relu(c3*s3+t3 + y) itself and writes it to ynext
             else:
-                ops.append(act_op(L.OP_BN_ADD_RELU, self.c3, s3, t3, ynext, N, h2, w2, planes * 4, y))
+                ops.append(act_op(L.OP_BN_ADD_RELU, c3buf, s3, t3, ynext, N, h2, w2, planes * 4, y))
             y, ynext = ynext, y
         ap = L.SatOp()
         ap.kind, ap.dtype = L.OP_AVGPOOL, dtype
