@@ -139,10 +139,14 @@ def cpu_baseline(torch, seed):
         OT.full_step(ep, eb, dp, images, caps, lengths, state)
     dt = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
-    return {"value": B * n / dt, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "CPU oracle (oracle/train_step.py full_step, torch-CPU fp32), batch %d of the same shapes, %d timed "
-                      "steps at the best of {8,16,32,%d} torch threads (probed at batch %d, where one step ran at %.1f images/sec)"
-                      % (B, n, default_threads, pb, best[0])}
+    rate64 = B * n / dt
+    # the oracle is slower per image at batch 64 than at the probe's batch 16 on these hosts (the conv stack's working set
+    # leaves the last-level cache); the BEST rate found is the baseline, both are reported
+    return {"value": max(rate64, best[0]), "unit": "images/sec", "cores": threads, "kind": "port",
+            "images_per_sec_batch64": round(rate64, 2), "images_per_sec_batch%d" % pb: round(best[0], 2),
+            "sample": "CPU oracle (oracle/train_step.py full_step, torch-CPU fp32) on the same shapes: %d timed steps at batch %d and one "
+                      "at batch %d, at the best of {8,16,32,%d} torch threads (%d); value = the better of the two rates"
+                      % (n, B, pb, default_threads, threads)}
 
 
 def f32_mode_rate(torch, sat, dev, images, caps, lengths, steps=6, lookahead=True):
@@ -266,6 +270,9 @@ def main():
             out = dp.step((batches[i % nb], caps, lengths), global_tokens, next_images=nxt or None)
         return out
 
+    prio_env = os.environ.get("SAT_MAIN_STREAM_PRIO")          # experiment: run the step's own stream at another priority
+    if prio_env is not None:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(prio_env)))
     if args.warmup:
         loss = run_steps(args.warmup)
     # The timed region: EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks.  K = 20 steps are 0.1 s of

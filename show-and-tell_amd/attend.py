@@ -494,6 +494,9 @@ class ShowAttendTellModel(nn.Module):
         stream = lookahead_stream(images.device, inst)
         main = torch.cuda.current_stream(images.device)
         stream.wait_stream(main)
+        ready = getattr(images, "_sat_ready_event", None)      # a DevicePrefetcher copy still in flight on its own stream
+        if ready is not None:
+            stream.wait_event(ready)
         with torch.cuda.stream(stream), torch.no_grad():
             feats, fmean = self._program_for(images, instance=inst).run(images)
             feats, fmean = feats.clone(), fmean.clone()

@@ -1134,6 +1134,32 @@ int sat_bn1d_fwd_launch(const float* part, int nz, long slab_stride, const float
     return SAT_OK;
 }
 
+// dW[e][f] = sum_b dz[b][e] * pooled[b][f] for a batch of at most a few hundred rows (the encoder head's fc gradient,
+// models.py:16): one thread per (e, 4 consecutive f), an fmaf chain over b in row order (what the exact-f32 MFMA GEMM computes,
+// which spends 35 us on this K = 64 product)
+__global__ __launch_bounds__(256) void outer_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x, int B, int E, int F,
+                                                          float* __restrict__ dw) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int f4 = F >> 2;
+    if (i >= (long)E * f4) return;
+    const int e = (int)(i / f4), f = (int)(i - (long)e * f4) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+        const float d = dz[(long)b * E + e];
+        const f32x4 v = *(const f32x4*)(x + (long)b * F + f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fmaf(d, v[k], acc[k]);
+    }
+    *(f32x4*)(dw + (long)e * F + f) = acc;
+}
+
+int sat_outer_wgrad_launch(const float* dz, const float* x, int B, int E, int F, float* dw, hipStream_t s) {
+    const long n = (long)E * (F >> 2);
+    hipLaunchKernelGGL(outer_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dz, x, B, E, F, dw);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
 int sat_bn1d_bwd_launch(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int E,
                         float* dz, float* dgamma, float* dbeta, float* db_fc, hipStream_t s) {
     hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(sat_cdiv(E, 32)), dim3(256), 0, s, dy, xhat, rstd, gamma, B, E, dz, dgamma,

@@ -39,6 +39,7 @@ int sat_lstm_bwd_point_launch(const float* dHS, const float* dh_part, int nz, lo
 int sat_bn1d_fwd_launch(const float* part, int nz, long slab_stride, const float* b_fc, const float* gamma,
                         const float* beta, float* rm, float* rv, float momentum, float eps, int training, int B, int E,
                         float* zbuf, float* feats, float* xhat, float* rstd, hipStream_t s);
+int sat_outer_wgrad_launch(const float* dz, const float* x, int B, int E, int F, float* dw, hipStream_t s);
 int sat_bn1d_bwd_launch(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int E,
                         float* dz, float* dgamma, float* dbeta, float* db_fc, hipStream_t s);
 

@@ -88,12 +88,13 @@ class DevicePrefetcher:
         return (d_images, d_captions) + tuple(batch[2:]), ev
 
     def upcoming_images(self):
-        """device image tensors of the staged batches that follow the one just yielded; the current stream is made to wait
-        for their copies, so work ordered behind it (a look-ahead stream's `wait_stream`) may read them"""
-        cur = torch.cuda.current_stream(self.device)
+        """device image tensors of the staged batches that follow the one just yielded.  Their H2D copies may still be in
+        flight: each tensor carries its copy-done event (`_sat_ready_event`), which `EncoderCNN.prefetch` makes ITS side stream
+        wait for -- the caller's compute stream is not held up by copies of batches it will only consume later; it
+        waits for a batch's copy when `__iter__` yields that batch."""
         out = []
         for staged, ev in self._queue:
-            cur.wait_event(ev)
+            staged[0]._sat_ready_event = ev
             out.append(staged[0])
         return out
 

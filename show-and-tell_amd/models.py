@@ -198,6 +198,9 @@ class EncoderCNN(nn.Module):
         inst = next(i for i in range(self.lookahead_depth) if i not in busy)
         stream = lookahead_stream(images.device, inst)
         stream.wait_stream(torch.cuda.current_stream(images.device))   # the images, and this instance's previous consumer
+        ready = getattr(images, "_sat_ready_event", None)              # a DevicePrefetcher copy still in flight on its own stream
+        if ready is not None:
+            stream.wait_event(ready)
         with torch.cuda.stream(stream), torch.no_grad():
             prog = self._program(images, instance=inst)
             prog.run(images)
