@@ -249,7 +249,7 @@ def main():
     model = sat.ShowAndTell(CFG["embed"], CFG["hidden"], CFG["vocab"], CFG["layers"], compute_dtype="bf16").to(dev).train()
     ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
     dp = sat.DataParallelStep(ts)
-    if args.force_dist:
+    if args.force_dist and os.environ.get("SAT_FORCE_DIST_INIT_ONLY", "0") != "1":
         dp.world = 2          # take the multi-rank code path (async bucket all-reduces) on the single rank
     images, caps, lengths = synth_batch(torch, CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 123 + rank)
     global_tokens = world * sum(l - 1 for l in lengths)

@@ -361,13 +361,43 @@ class DataParallelStep:
         self.engine = engine
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # How the bucket all-reduces overlap the rest of the backward.  "c10d" (default): async_op=True + work.wait() before clamp +
+        # Adam.  "stream" (SAT_DP_OVERLAP=stream): a communication stream of our own that waits for the bucket's gradients, issues
+        # the collective synchronously and is waited for once.  Measured on ONE rank, where RCCL launches no kernel
+        # (tools/dp_overhead.py, bench.py --force-dist): any DEFERRED wait costs 0.4-0.5 ms of a 4.5 ms step (4.87 / 4.96 ms for
+        # c10d / stream against 4.49 without collective calls), whatever the bucket count (1 or 3) or the hardware-queue count;
+        # waiting at once (async_op=False on the compute stream) costs nothing (4.41) but would expose the whole exchange with
+        # N > 1.  Not resolvable without N > 1 hardware: the default stays the overlapping form.
+        self.mode = _os.environ.get("SAT_DP_OVERLAP", "c10d")
+        self._comm_stream = None
 
     def step(self, batch, global_tokens, lr=None, next_images=None):
         eng, dist = self.engine, self.dist
         works = []
 
+        single = _os.environ.get("SAT_DP_SINGLE_BUCKET", "0") == "1"      # experiment: ONE all-reduce of the whole flat gradient at the end
+
+        use_stream = self.mode == "stream" and self.world > 1 and eng.flat_grad.is_cuda
+        if use_stream and self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=eng.flat_grad.device)
+        comm = self._comm_stream
+
         def ready(i):
+            if use_stream:
+                if single and i != len(eng.buckets) - 1:
+                    return
+                s, e = (0, eng.flat_grad.numel()) if single else eng.buckets[i]
+                ev = torch.cuda.Event()
+                ev.record()                               # the bucket's gradients are final on the compute stream here
+                comm.wait_event(ev)
+                with torch.cuda.stream(comm):
+                    dist.all_reduce(eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group)
+                return
             if self.world > 1:
+                if single:
+                    if i == len(eng.buckets) - 1:
+                        works.append(dist.all_reduce(eng.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    return
                 s, e = eng.buckets[i]
                 works.append(dist.all_reduce(eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -377,6 +407,10 @@ class DataParallelStep:
             loss = eng.forward_backward(batch, 1.0 / float(global_tokens), ready)
         for w in works:
             w.wait()
+        if use_stream:
+            done = torch.cuda.Event()
+            done.record(comm)
+            torch.cuda.current_stream().wait_event(done)  # every bucket is reduced before clamp + Adam read the gradients
         loss = loss.clone()          # the slot in the flat gradient buffer is overwritten by the next step
         eng.optimizer_step(lr)
         return loss
