@@ -434,6 +434,7 @@ int sat_resident_token_release(hipStream_t s) {
 static unsigned long long* g_dbg_stamps = nullptr;
 // diagnostics: device buffer of [grid][8] u64 that lane 0 of every workgroup of the NEXT fused launches fills with s_memtime
 // stamps (0 start, 1 A panel landed + table, 2 K phase done, 3 statistics acknowledged, 4 grid barrier passed, 5 epilogue done)
+unsigned long long* sat_dbg_stamps() { return g_dbg_stamps; }      // conv_xp_kernel's stamps go to the same buffer
 extern "C" int sat_conv3_fused_debug(void* stamps) {
     g_dbg_stamps = (unsigned long long*)stamps;
     return SAT_OK;

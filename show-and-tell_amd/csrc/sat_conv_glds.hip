@@ -93,6 +93,8 @@ struct ConvArgs {
     const bf16_t* R;
     bf16_t* Y;
     long ldy;
+    int ct;                  // conv_xp_kernel: column tiles per workgroup
+    unsigned long long* stamps;   // conv_xp_kernel diagnostics: [workgroup][8] s_memtime stamps of lane 0, or NULL
     int dbg;                 // diagnostics only (SAT_CONV_DBG): 1 = no loads, 2 = no MFMA, 4 = no epilogue, 8 = expansion (1x1, N = 4 Cin) convs store nothing
 };
 // fixed-point scale of the atomic statistics is SAT_STAT_SCALE (sat_internal.h)
@@ -861,7 +863,7 @@ int tune_env(const char* name, int dflt) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows, dual-source A).
 // LDS = S * (BM/8 + BN/8 [+ BM/8]) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, dual, xa; };
+struct Variant { int bn, s, nw, spec, pf, bm, dual, xa, xp; };      // xp: conv_xp_kernel with xp column tiles per workgroup
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128, 0}, {128, 3, 8, 0, 0, 128, 0}, {128, 2, 8, 0, 0, 128, 0}, {64, 4, 8, 0, 0, 128, 0}, {64, 3, 8, 0, 0, 128, 0},
     {64, 2, 8, 0, 0, 128, 0}, {128, 4, 4, 0, 0, 128, 0}, {128, 2, 4, 0, 0, 128, 0}, {64, 3, 4, 0, 0, 128, 0}, {64, 2, 4, 0, 0, 128, 0},
@@ -874,8 +876,11 @@ constexpr Variant kVariants[] = {
     {128, 3, 8, 0, 0, 64, 0}, {128, 2, 8, 0, 0, 64, 0},                                                                             // 64-row tiles: 2 workgroups per CU on the N = 256 layers
     {128, 3, 8, 0, 0, 128, 0, 1}, {128, 4, 8, 0, 0, 128, 0, 1}, {64, 3, 8, 0, 0, 128, 0, 1}, {64, 4, 8, 0, 0, 128, 0, 1},
     {128, 3, 8, 0, 0, 64, 0, 1}, {128, 4, 8, 0, 0, 64, 0, 1}, {256, 3, 8, 0, 0, 128, 0, 1},                                          // pipelined input affine (any uniform geometry)
+    {128, 5, 4, 0, 0, 128, 0, 0, 1}, {128, 5, 4, 0, 0, 128, 0, 0, 2}, {128, 5, 4, 0, 0, 128, 0, 0, 4},                               // register-resident A panel (expansion 1x1 convs, sat_conv_xp.inc)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+#include "sat_conv_xp.inc"
 
 int launch_variant(int v, ConvArgs& a, hipStream_t s) {
     switch (v) {
@@ -918,6 +923,9 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 36: return launch_glds<128, 3, 8, false, false, 64, false, true>(a, s);
         case 37: return launch_glds<128, 4, 8, false, false, 64, false, true>(a, s);
         case 38: return launch_glds<256, 3, 8, false, false, 128, false, true>(a, s);
+        case 39: return launch_xp(a, 1, s);
+        case 40: return launch_xp(a, 2, s);
+        case 41: return launch_xp(a, 4, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -973,6 +981,10 @@ ConvArgs make_args(const sat_op* op) {
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
+    if (k.xp) {
+        static const int no_xp = tune_env("SAT_CONV_NO_XP", 0);      // A/B switch: the tuner never offers conv_xp_kernel
+        return !no_xp && xp_ok(a, k.xp);
+    }
     if (k.bn >= 128 && a.N <= 64) return false;
     if (k.bn == 256 && a.N <= 128) return false;
     if ((k.spec || k.pf) && a.in_affine) return false;

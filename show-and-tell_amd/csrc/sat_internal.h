@@ -23,6 +23,7 @@ int sat_conv3_fused_launch(const sat_op* op, int parity, hipStream_t s);
 // (a one-wave kernel that spins, bounded; `err` receives 2 on a timeout), release behind it
 int sat_resident_token_acquire(unsigned* err, hipStream_t s);
 int sat_resident_token_release(hipStream_t s);
+unsigned long long* sat_dbg_stamps();   // diagnostics: [workgroup][8] u64 device buffer armed by sat_conv3_fused_debug, or NULL
 int sat_resident_token_in_use();      // 0 until a fused conv3 launch has run in this process: nothing to exclude before that
 
 int sat_skinny_store(const float* A, long lda, const float* W, long ldw, int wkm, int M, int N, int K, int nz,

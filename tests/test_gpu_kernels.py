@@ -107,7 +107,7 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 39
+NUM_CONV_VARIANTS = 42
 PLAIN_CONV_VARIANTS = list(range(1, 22)) + [28, 29, 30, 31, 32]      # 33..39: pipelined input affine (their own test)      # 22..27 are dual-source only (their own test)
 
 
@@ -130,6 +130,68 @@ def test_conv_bf16_every_kernel_variant(lib, variant, N, H, W, Cin, Cout, k, str
     part = keep[3].cpu().double()
     np.testing.assert_allclose(part[:, 0].sum(0).numpy(), ref.sum(0).numpy(), rtol=0, atol=1e-3 * ref.shape[0] ** 0.5 + 1e-4)
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("stat_mode", ["slab", "atomic"])
+@pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.parametrize("variant,N,H,W,Cin,Cout", [
+    (40, 5, 12, 12, 256, 1024), (41, 5, 12, 12, 256, 1024), (42, 3, 14, 14, 256, 1024), (40, 2, 16, 16, 128, 512),
+    (41, 7, 9, 9, 128, 512), (42, 2, 28, 28, 128, 512), (40, 3, 20, 20, 64, 256), (41, 1, 30, 30, 64, 256), (41, 64, 14, 14, 256, 1024)])
+def test_conv_expansion_1x1_register_resident_panel_is_bit_identical(lib, variant, N, H, W, Cin, Cout, affine, stat_mode):
+    """conv_xp_kernel (variants 40-42: 1 / 2 / 4 column tiles per workgroup, the A panel of an expansion 1x1 conv held in MFMA
+    fragment registers, the operand's BatchNorm + ReLU applied there once) against the 128x128-tile ring kernel (variant 3) on
+    the same op: output tensor, per-tile statistics slabs and the integer-atomic sums BITWISE equal; ragged M (rows past the last
+    full 128-row tile), the derive-from-sums table with its running-statistics update; models.py:27."""
+    g = torch.Generator().manual_seed(variant * 7 + Cin + N)
+    x = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
+    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).bfloat16()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    xf = x.float().reshape(-1, Cin).double()
+    M = xf.shape[0]
+
+    def run(v):
+        o, keep, _ = _conv_op(L.SAT_BF16, x.float(), w.float().reshape(Cout, 1, 1, Cin), 1, 0, stats=(stat_mode == "slab"))
+        o.variant = v
+        extra = {}
+        if stat_mode == "atomic":
+            acc = torch.zeros(2, 4, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc, o.stat_shards = acc.data_ptr(), 4
+            extra["acc"] = acc
+        if affine:
+            iacc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
+            iacc[0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
+            iacc[0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
+            iacc[1] = 777
+            gd, bd, rm, rv = cu(gamma), cu(beta), cu(torch.zeros(Cin)), cu(torch.ones(Cin))
+            o.stat_acc1, o.gamma1, o.beta1 = iacc.data_ptr(), gd.data_ptr(), bd.data_ptr()
+            o.running_mean1, o.running_var1 = rm.data_ptr(), rv.data_ptr()
+            o.count, o.momentum, o.eps = M, 0.1, 1e-5
+            extra.update(iacc=iacc, gd=gd, bd=bd, rm=rm, rv=rv)
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+        sync()
+        return keep, extra
+
+    want, wx = run(3)
+    got, gx = run(variant)
+    assert torch.isfinite(got[2].float()).all()
+    assert torch.equal(got[2], want[2])
+    if stat_mode == "slab":
+        assert torch.equal(got[3], want[3])
+    else:
+        assert torch.equal(gx["acc"].sum(1), wx["acc"].sum(1))       # shard = workgroup id % 4: only the totals are comparable
+        assert int(gx["acc"][0].abs().sum()) > 0
+    if affine:
+        assert int(gx["iacc"][1].abs().sum()) == 0
+        assert torch.equal(gx["rm"], wx["rm"]) and torch.equal(gx["rv"], wx["rv"])
+    # and against the f64 definition
+    a = x.float().reshape(-1, Cin)
+    if affine:
+        mean, var = xf.mean(0), xf.var(0, unbiased=False)
+        scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
+        shift = (beta.double() - mean * scale.double()).float()
+        a = torch.clamp(a * scale + shift, min=0).bfloat16().float()
+    ref = a.double() @ w.float().double().t()
+    assert (got[2].float().cpu().double() - ref).abs().max().item() < 3e-2 + 4e-3 * ref.abs().max().item()
 
 
 def test_conv_autotune_sets_a_variant_and_keeps_results(lib):

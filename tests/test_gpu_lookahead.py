@@ -199,6 +199,9 @@ def test_two_pass_conv3_is_bit_identical_to_conv_plus_normalise_add(monkeypatch)
 
     def build(flag):
         monkeypatch.setenv("SAT_CONV3_TWOPASS", flag)
+        # the tile shape fixes the summation order of the BatchNorm statistics: bitwise equality needs the SAME conv variants in
+        # both programs, so the timing-dependent tuner is off here (the heuristic picks by geometry alone)
+        monkeypatch.setenv("SAT_AUTOTUNE", "0")
         enc = sat.EncoderCNN(E, arch=arch, compute_dtype="bf16")
         enc.load_state_dict({**params, **buffers})
         return enc.cuda().train()
