@@ -64,6 +64,7 @@ struct ConvArgs {
     float* in_running_mean;
     float* in_running_var;
     double in_count;
+    double in_inv;           // 1 / (2^22 * in_count) (conv_xp_kernel: the division happens on the host)
     float in_momentum, in_eps;
     int in_affine;
     // Output-side fusion (inference: BatchNorm is a fixed per-channel affine): out = [relu](acc*out_scale[n] +

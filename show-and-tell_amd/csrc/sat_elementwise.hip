@@ -1004,6 +1004,18 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
         grid = grid / g0 * g0;
         if (grid < g0) grid = g0;
     }
+    // Workgroup size of the table-deriving launches (SAT_BN_BLOCK): every workgroup turns the integer sums of ALL C channels into
+    // (scale, shift) first -- f64 arithmetic, ~90 vector instructions per channel -- so at 256 threads a 1024-channel
+    // normalise+add spends ~360 instructions per thread there, on every one of its 768 workgroups, before it streams.  The same
+    // threads in 4x fewer, 4x larger workgroups derive each channel 4x less often.
+    // Measured (round 3, bench.py): strictly sequential steps 6.14 -> 6.02 ms at 512 (6.05 at 1024); with three stacks in flight the
+    // prologue hides under the neighbours' work either way (4.39 vs 4.40 ms) and 1024 loses 2 %: default 512.
+    static const int bn_block = getenv("SAT_BN_BLOCK") ? atoi(getenv("SAT_BN_BLOCK")) : 512;
+    int block = EW_BLOCK;
+    if (lds && (bn_block == 512 || bn_block == 1024) && (bn_block % cch) == 0 && grid >= bn_block / EW_BLOCK) {
+        block = bn_block;
+        grid = grid / (bn_block / EW_BLOCK);
+    }
     const double count = (double)op->count;
     // The normalise+add kernel reads its two operands with NON-TEMPORAL loads: both are dead after it (the raw conv3 tensor, and
     // the block input that y replaces), so they need not displace the other stacks' live tensors from the Infinity Cache.
@@ -1011,19 +1023,19 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
     // 768); SAT_BN_NT=0 restores plain loads, =2 also reads the normalise+ReLU kernel's operand that way.
     static const int bn_nt = getenv("SAT_BN_NT") ? atoi(getenv("SAT_BN_NT")) : 1;
     if (!add && bn_nt >= 2) {
-        hipLaunchKernelGGL((bn_act_kernel<T, false, true>), dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (const T*)nullptr,
+        hipLaunchKernelGGL((bn_act_kernel<T, false, true>), dim3(grid), dim3(block), lds, s, (const T*)op->in0, (const T*)nullptr,
                            (T*)op->out, b0, b1, 0, count, op->momentum, op->eps, nch, C);
         SAT_LAUNCH_CHECK();
         return SAT_OK;
     }
     if (add && bn_nt)
-        hipLaunchKernelGGL((bn_act_kernel<T, true, true>), dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (const T*)op->in1,
+        hipLaunchKernelGGL((bn_act_kernel<T, true, true>), dim3(grid), dim3(block), lds, s, (const T*)op->in0, (const T*)op->in1,
                            (T*)op->out, b0, b1, has_b1, count, op->momentum, op->eps, nch, C);
     else if (add)
-        hipLaunchKernelGGL((bn_act_kernel<T, true>), dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (const T*)op->in1,
+        hipLaunchKernelGGL((bn_act_kernel<T, true>), dim3(grid), dim3(block), lds, s, (const T*)op->in0, (const T*)op->in1,
                            (T*)op->out, b0, b1, has_b1, count, op->momentum, op->eps, nch, C);
     else
-        hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (const T*)nullptr,
+        hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(grid), dim3(block), lds, s, (const T*)op->in0, (const T*)nullptr,
                            (T*)op->out, b0, b1, 0, count, op->momentum, op->eps, nch, C);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
