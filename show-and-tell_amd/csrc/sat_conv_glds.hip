@@ -106,7 +106,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 9 || N == 10 || N == 12 ||
-                      N == 15 || N == 16 || N == 18 || N == 20 || N == 24,
+                      N == 15 || N == 16 || N == 18 || N == 20 || N == 21 || N == 22 || N == 24,
                   "add the vmcnt literal");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -114,6 +114,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
     if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    if constexpr (N == 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+    if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -864,7 +866,7 @@ int tune_env(const char* name, int dflt) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows, dual-source A).
 // LDS = S * (BM/8 + BN/8 [+ BM/8]) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, dual, xa, xp; };      // xp: conv_xp_kernel with xp column tiles per workgroup
+struct Variant { int bn, s, nw, spec, pf, bm, dual, xa, xp, pr; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128, 0}, {128, 3, 8, 0, 0, 128, 0}, {128, 2, 8, 0, 0, 128, 0}, {64, 4, 8, 0, 0, 128, 0}, {64, 3, 8, 0, 0, 128, 0},
     {64, 2, 8, 0, 0, 128, 0}, {128, 4, 4, 0, 0, 128, 0}, {128, 2, 4, 0, 0, 128, 0}, {64, 3, 4, 0, 0, 128, 0}, {64, 2, 4, 0, 0, 128, 0},
@@ -878,10 +880,12 @@ constexpr Variant kVariants[] = {
     {128, 3, 8, 0, 0, 128, 0, 1}, {128, 4, 8, 0, 0, 128, 0, 1}, {64, 3, 8, 0, 0, 128, 0, 1}, {64, 4, 8, 0, 0, 128, 0, 1},
     {128, 3, 8, 0, 0, 64, 0, 1}, {128, 4, 8, 0, 0, 64, 0, 1}, {256, 3, 8, 0, 0, 128, 0, 1},                                          // pipelined input affine (any uniform geometry)
     {128, 5, 4, 0, 0, 128, 0, 0, 1}, {128, 5, 4, 0, 0, 128, 0, 0, 2}, {128, 5, 4, 0, 0, 128, 0, 0, 4},                               // register-resident A panel (expansion 1x1 convs, sat_conv_xp.inc)
+    {128, 6, 8, 1, 0, 128, 0, 0, 0, 1},                                                                                             // LDS-resident input patch (3x3 / stride 1, sat_conv_pr.inc)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 #include "sat_conv_xp.inc"
+#include "sat_conv_pr.inc"
 
 int launch_variant(int v, ConvArgs& a, hipStream_t s) {
     switch (v) {
@@ -927,6 +931,7 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 39: return launch_xp(a, 1, s);
         case 40: return launch_xp(a, 2, s);
         case 41: return launch_xp(a, 4, s);
+        case 42: return launch_pr(a, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -982,6 +987,10 @@ ConvArgs make_args(const sat_op* op) {
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
+    if (k.pr) {
+        static const int no_pr = tune_env("SAT_CONV_NO_PR", 0);      // A/B switch: the tuner never offers conv_pr_kernel
+        return !no_pr && pr_ok(a);
+    }
     if (k.xp) {
         static const int no_xp = tune_env("SAT_CONV_NO_XP", 0);      // A/B switch: the tuner never offers conv_xp_kernel
         return !no_xp && xp_ok(a, k.xp);

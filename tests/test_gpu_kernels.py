@@ -107,7 +107,7 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 42
+NUM_CONV_VARIANTS = 43
 PLAIN_CONV_VARIANTS = list(range(1, 22)) + [28, 29, 30, 31, 32]      # 33..39: pipelined input affine (their own test)      # 22..27 are dual-source only (their own test)
 
 
@@ -193,6 +193,45 @@ def test_conv_expansion_1x1_register_resident_panel_is_bit_identical(lib, varian
         a = torch.clamp(a * scale + shift, min=0).bfloat16().float()
     ref = a.double() @ w.float().double().t()
     assert (got[2].float().cpu().double() - ref).abs().max().item() < 3e-2 + 4e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("stat_mode", ["slab", "atomic"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 15, 13, 64, 192), (64, 14, 14, 256, 256), (5, 28, 28, 128, 128), (7, 7, 7, 512, 136),
+                                            (2, 5, 31, 64, 128), (1, 3, 3, 128, 256)])
+def test_conv3x3_lds_resident_patch_matches_the_ring_kernel(lib, N, H, W, Cin, Cout, stat_mode):
+    """conv_pr_kernel (variant 43: 3x3 / stride 1 / pad 1 with the input patch of a 128-row tile resident in LDS, only the weights
+    streaming) against the f64 definition and against the ring kernel (variant 1): the K axis is walked channel-block major,
+    so outputs agree to f32 summation order (then one bf16 rounding), not bitwise; image borders, rows of two images in one tile,
+    ragged M and N, the widest supported image (W = 31); models.py:27."""
+    g = torch.Generator().manual_seed(N * 17 + W + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cout)
+
+    def run(v):
+        o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1, stats=(stat_mode == "slab"))
+        o.variant = v
+        acc = None
+        if stat_mode == "atomic":
+            acc = torch.zeros(2, 4, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc, o.stat_shards = acc.data_ptr(), 4
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+        sync()
+        return keep, acc
+
+    want, wacc = run(1)
+    got, gacc = run(43)
+    out = got[2].float().cpu().double()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < 2e-2
+    # one bf16 ulp at most between the two kernels, and only on a small fraction of the elements
+    d = (got[2].float() - want[2].float()).abs()
+    assert d.max().item() <= 2.0 ** -6 * max(1.0, want[2].float().abs().max().item())
+    assert (d > 0).float().mean().item() < 0.05
+    if stat_mode == "slab":
+        torch.testing.assert_close(got[3], want[3], rtol=1e-4, atol=2e-3)
+    else:
+        torch.testing.assert_close(gacc.sum(1).double() / 2 ** 22, wacc.sum(1).double() / 2 ** 22, rtol=1e-4, atol=5e-3)
 
 
 def test_conv_autotune_sets_a_variant_and_keeps_results(lib):
