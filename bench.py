@@ -318,7 +318,7 @@ def main():
                                     "K conv passes + K decoder passes inside the timed region, fill and drain included" % (depth, depth)) if args.lookahead
                                    else "strictly sequential steps",
                        "final_loss": round(final_loss, 4)},
-            "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel (bf16 implicit-GEMM conv, %d launches/step, variants autotuned per geometry)" % n_conv,
+            "roofline": {"bound": "mfma", "kernel": "bf16 implicit-GEMM conv launches (%d per step: conv_glds_kernel ring variants, conv_xp_kernel for the expansion 1x1 convs, conv_pr_kernel for the 3x3 convs; autotuned per geometry)" % n_conv,
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "algorithmic_gflop_per_launch": round(conv_flops / n_conv / 1e9, 3),

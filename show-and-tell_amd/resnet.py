@@ -253,7 +253,14 @@ class ConvStackProgram:
         # bn1+ReLU inside conv2 (3x3), OPT-IN: measured 7.33 vs 6.85 ms/step -- a 3x3 conv stages every input element 9 taps x
         # (N/128) tile columns = 18 times, so the in-LDS transform does 18x the work of the separate 5.6 us stream kernel and
         # doubles the LDS traffic of an LDS-bound K loop
-        fuse_bn1 = training and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_BN1", "0") == "1"
+        # SAT_FUSE_BN1=2 (round 3): only where conv_pr_kernel can run the conv (3x3 / stride 1, 128 <= planes <= 512, rows of <= 31
+        # pixels): there the transform touches each 64-channel slice of the input patch ONCE per workgroup (LDS-resident patch,
+        # sat_conv_pr.inc) instead of once per tap
+        # Measured (bench.py, A/B on one box): 15.37 -> 15.95 k img/s with three stacks in flight, 11.1 -> 11.5 k strictly sequential:
+        # 42 of the 50 normalise+ReLU launches of ResNet-152 disappear.  Default 2; 0 restores the separate launches, 1 fuses
+        # everywhere (the in-ring transform of the older kernels where conv_pr_kernel cannot run: the measured loss above).
+        fuse_bn1_mode = int(os.environ.get("SAT_FUSE_BN1", "2")) if (training and dtype == L.SAT_BF16) else 0
+        fuse_bn1 = fuse_bn1_mode == 1
         slab_to_acc = os.environ.get("SAT_SLAB_TO_ACC", "1") != "0"
         fuse_out_bn = (not training) and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_EVAL_BN", "1") != "0"
         # many-tile layers (ATOMIC_MAX_TILES < tiles <= SHARD_MAX_TILES): the same integer atomics into 8 SHARDS of the
@@ -458,7 +465,8 @@ class ConvStackProgram:
                 ops.append(std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_))
             f, s1, t1 = fin_op(blk.bn1, planes, N * h * w_, tm1)
             add(f)
-            if fuse_bn1 and planes <= 512 and planes % 64 == 0:
+            pr_geom = (h2 == h and w2 == w_ and planes % 64 == 0 and 128 <= planes <= 512 and w_ <= 31)
+            if (fuse_bn1 or (fuse_bn1_mode == 2 and pr_geom)) and planes <= 512 and planes % 64 == 0:
                 # conv2 (3x3) reads the RAW c1 and applies bn1 + ReLU to every landed A stage in LDS (pipelined one K-step
                 # ahead of the MFMAs; a per-row tap mask keeps the zero padding zero): a1 never exists in HBM
                 cv2 = std_conv(blk.conv2, self.c1, self.c2, N, h, w_, h2, w2)

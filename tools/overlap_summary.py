@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def cls(n):
-    if 'conv_glds_kernel' in n:
+    if 'conv_glds_kernel' in n or 'conv_xp_kernel' in n or 'conv_pr_kernel' in n:
         return 'conv'
     if 'bn_act_kernel' in n or 'bn_relu' in n or 'bn_strided' in n:
         return 'bn apply'
@@ -46,9 +46,10 @@ def main():
           % (nsteps, wall, tot / nsteps, tot / nsteps / wall))
     for k in sorted(busy, key=lambda k: -busy[k]):
         print("  %-28s %5d launches/step  %7.3f ms/step of spans" % (k, cnt[k] // nsteps, busy[k] / nsteps))
-    conv_win = [r for r in win if 'conv_glds_kernel' in r['Kernel_Name']]
+    is_conv = lambda r: any(k in r['Kernel_Name'] for k in ('conv_glds_kernel', 'conv_xp_kernel', 'conv_pr_kernel'))
+    conv_win = [r for r in win if is_conv(r)]
     # bench.py's roofline leg: the conv launches after the last optimizer step run in sequence, alone
-    tail = [r for r in rows if r['s'] > adam[-1]['e'] and 'conv_glds_kernel' in r['Kernel_Name']]
+    tail = [r for r in rows if r['s'] > adam[-1]['e'] and is_conv(r)]
     ip = [r for r in rows if r['s'] > adam[-1]['e'] and 'image_prep' in r['Kernel_Name']]
     if ip:
         tail = [r for r in tail if r['s'] > ip[-1]['s']]

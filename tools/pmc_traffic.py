@@ -53,7 +53,7 @@ def main():
     out["whole_step_hbm_bytes_corrected"] = round(tot)
     c = out["kernels"].get("conv_glds_kernel")
     if c:
-        out["kernel"] = "conv_glds_kernel (all variants), one training step"
+        out["kernel"] = "conv_glds_kernel + conv_xp_kernel + conv_pr_kernel (all conv launches), one training step"
         out["launches"] = c["launches"]
         out["hbm_bytes_per_step_corrected"] = c["hbm_bytes_corrected"]
         out["hbm_bytes_per_launch_corrected"] = c["hbm_bytes_per_launch_corrected"]
