@@ -984,13 +984,15 @@ ConvArgs make_args(const sat_op* op) {
 }
 
 // a variant the kernel can run for these arguments (the in-LDS input transform lives in the plain unified-wave loop)
+bool pr_enabled() {
+    static const int no_pr = tune_env("SAT_CONV_NO_PR", 0);      // A/B switch: conv_pr_kernel is never offered
+    return !no_pr;
+}
+
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
-    if (k.pr) {
-        static const int no_pr = tune_env("SAT_CONV_NO_PR", 0);      // A/B switch: the tuner never offers conv_pr_kernel
-        return !no_pr && pr_ok(a);
-    }
+    if (k.pr) return pr_enabled() && pr_ok(a);
     if (k.xp) {
         static const int no_xp = tune_env("SAT_CONV_NO_XP", 0);      // A/B switch: the tuner never offers conv_xp_kernel
         return !no_xp && xp_ok(a, k.xp);
@@ -1009,7 +1011,8 @@ int heuristic_variant(const ConvArgs& a) {
     // 128x128 with a deep ring when it still leaves >= 2 tiles per CU and K is long enough to use the ring;
     // otherwise 128x64 with a shallower ring (more workgroups per CU to overlap prologue/epilogue phases)
     if (a.R) return a.N > 128 ? 21 : 25;          // dual-source: 64-row tiles covering all of N where N <= 256
-    if (a.in_affine && !a.linear) return a.N > 64 ? 32 : 34;      // 3x3 with a fused input BatchNorm: pipelined transform only
+    // 3x3 with a fused input BatchNorm: the LDS-resident patch where it can run (what the builder fuses bn1 for), else the pipelined in-ring transform
+    if (a.in_affine && !a.linear) return (pr_enabled() && pr_ok(a)) ? 42 : (a.N > 64 ? 32 : 34);
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const int nk = sat_cdiv(a.K, 64);
     if (a.N > 64 && t128 >= 512) return nk <= 4 ? 2 : 0;
