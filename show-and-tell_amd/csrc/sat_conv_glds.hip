@@ -1100,6 +1100,12 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
     hipEvent_t ex[3] = {nullptr, nullptr, nullptr};
     for (int c = 1; c < copies; ++c)
         if (hipEventCreate(&ex[c - 1]) != hipSuccess) return SAT_ERR_UNSUPPORTED;
+    // SAT_TUNE_COLD=1: every timed launch reads an input tensor that was just REWRITTEN (a fill of the op's own input buffer ahead of
+    // it, outside the timed span: the launch's dispatch timestamps) -- the state the conv meets in the program, where its producer
+    // ran a moment ago and nothing it reads is warm in its XCD's L2 from a previous launch of itself.  Back-to-back replays of one
+    // launch favour shallow rings (everything hits L2); in the program the 1x1 reductions of layer 3 take 18 us, not the 13 us the
+    // warm replay promises.
+    static const int cold = tune_env("SAT_TUNE_COLD", 0);
     int rc = SAT_OK;
     for (int i = 0; i < n_ops && rc == SAT_OK; ++i) {
         sat_op* op = ops + i;
@@ -1129,6 +1135,22 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
         for (int v = 0; v < kNumVariants; ++v) {
             if (!variant_ok(v, a)) continue;
             float tmin = 1e30f;
+            if (cold && copies == 1) {
+                const size_t in_bytes = (size_t)(op->sN > 0 ? op->sN : (long)op->Hin * op->Win * op->Cin) * op->N * sizeof(bf16_t);
+                for (int round = 0; round < 4 && rc == SAT_OK; ++round) {   // round 0 = warm-up, then best of 3 (each the mean of reps launches)
+                    float sum = 0.f;
+                    for (int r = 0; r < reps && rc == SAT_OK; ++r) {
+                        if (hipMemsetAsync((void*)op->in0, 0, in_bytes, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+                        sat_conv_arm_timer(e0, e1);
+                        rc = launch_variant(v, a, s);
+                        if (rc != SAT_OK) break;
+                        float ms = 0.f;
+                        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+                        sum += ms;
+                    }
+                    if (round >= 1 && sum / reps < tmin) tmin = sum / reps;
+                }
+            } else
             for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
                 if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
                 for (int c = 1; c < copies; ++c)
