@@ -106,13 +106,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 9 || N == 10 || N == 12 ||
-                      N == 15 || N == 16 || N == 18 || N == 20 || N == 21 || N == 22 || N == 24,
+                      N == 15 || N == 16 || N == 18 || N == 19 || N == 20 || N == 21 || N == 22 || N == 24,
                   "add the vmcnt literal");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    if constexpr (N == 19) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
     if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
     if constexpr (N == 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
     if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
@@ -866,7 +867,7 @@ int tune_env(const char* name, int dflt) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows, dual-source A).
 // LDS = S * (BM/8 + BN/8 [+ BM/8]) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, dual, xa, xp, pr; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel
+struct Variant { int bn, s, nw, spec, pf, bm, dual, xa, xp, pr, du; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; du: conv_du_kernel
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128, 0}, {128, 3, 8, 0, 0, 128, 0}, {128, 2, 8, 0, 0, 128, 0}, {64, 4, 8, 0, 0, 128, 0}, {64, 3, 8, 0, 0, 128, 0},
     {64, 2, 8, 0, 0, 128, 0}, {128, 4, 4, 0, 0, 128, 0}, {128, 2, 4, 0, 0, 128, 0}, {64, 3, 4, 0, 0, 128, 0}, {64, 2, 4, 0, 0, 128, 0},
@@ -881,11 +882,13 @@ constexpr Variant kVariants[] = {
     {128, 3, 8, 0, 0, 64, 0, 1}, {128, 4, 8, 0, 0, 64, 0, 1}, {256, 3, 8, 0, 0, 128, 0, 1},                                          // pipelined input affine (any uniform geometry)
     {128, 5, 4, 0, 0, 128, 0, 0, 1}, {128, 5, 4, 0, 0, 128, 0, 0, 2}, {128, 5, 4, 0, 0, 128, 0, 0, 4},                               // register-resident A panel (expansion 1x1 convs, sat_conv_xp.inc)
     {128, 6, 8, 1, 0, 128, 0, 0, 0, 1},                                                                                             // LDS-resident input patch (3x3 / stride 1, sat_conv_pr.inc)
+    {256, 6, 8, 1, 0, 64, 1, 0, 0, 0, 1},                                                                                           // dual-source 1x1 reduction, loader-side transform (sat_conv_du.inc)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 #include "sat_conv_xp.inc"
 #include "sat_conv_pr.inc"
+#include "sat_conv_du.inc"
 
 int launch_variant(int v, ConvArgs& a, hipStream_t s) {
     switch (v) {
@@ -932,6 +935,7 @@ int launch_variant(int v, ConvArgs& a, hipStream_t s) {
         case 40: return launch_xp(a, 2, s);
         case 41: return launch_xp(a, 4, s);
         case 42: return launch_pr(a, s);
+        case 43: return launch_du(a, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -984,6 +988,11 @@ ConvArgs make_args(const sat_op* op) {
 }
 
 // a variant the kernel can run for these arguments (the in-LDS input transform lives in the plain unified-wave loop)
+bool du_enabled() {
+    static const int no_du = tune_env("SAT_CONV_NO_DU", 0);      // A/B switch: conv_du_kernel is never offered
+    return !no_du;
+}
+
 bool pr_enabled() {
     static const int no_pr = tune_env("SAT_CONV_NO_PR", 0);      // A/B switch: conv_pr_kernel is never offered
     return !no_pr;
@@ -993,6 +1002,8 @@ bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
     if (k.pr) return pr_enabled() && pr_ok(a);
+    if (k.du) return du_enabled() && du_ok(a);
+    if (a.R && (const void*)a.Y == (const void*)a.A) return false;      // y written over the raw operand: conv_du_kernel only
     if (k.xp) {
         static const int no_xp = tune_env("SAT_CONV_NO_XP", 0);      // A/B switch: the tuner never offers conv_xp_kernel
         return !no_xp && xp_ok(a, k.xp);
@@ -1010,6 +1021,7 @@ bool variant_ok(int v, const ConvArgs& a) {
 int heuristic_variant(const ConvArgs& a) {
     // 128x128 with a deep ring when it still leaves >= 2 tiles per CU and K is long enough to use the ring;
     // otherwise 128x64 with a shallower ring (more workgroups per CU to overlap prologue/epilogue phases)
+    if (a.R && du_enabled() && du_ok(a)) return 43;
     if (a.R) return a.N > 128 ? 21 : 25;          // dual-source: 64-row tiles covering all of N where N <= 256
     // 3x3 with a fused input BatchNorm: the LDS-resident patch where it can run (what the builder fuses bn1 for), else the pipelined in-ring transform
     if (a.in_affine && !a.linear) return (pr_enabled() && pr_ok(a)) ? 42 : (a.N > 64 ? 32 : 34);
@@ -1042,7 +1054,9 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
     if (a.R) {
         // dual-source A: needs the input affine (the previous bn3), a dense 1x1 geometry and room for the table
         if (!a.in_affine || !a.linear || a.Cin > 2048 || (a.Cin % 64) || !a.Y || a.out_scale) return SAT_ERR_UNSUPPORTED;
-        if ((const void*)a.Y == (const void*)a.A || (const void*)a.Y == (const void*)a.R || (const void*)a.Y == (const void*)a.C) return SAT_ERR_ARG;
+        if ((const void*)a.Y == (const void*)a.R || (const void*)a.Y == (const void*)a.C) return SAT_ERR_ARG;
+        // y over the raw operand (in place): only the kernel whose one workgroup per row tile reads each operand stage before it stores y there
+        if ((const void*)a.Y == (const void*)a.A && !(du_enabled() && du_ok(a))) return SAT_ERR_ARG;
     }
     if (a.in_affine) {
         if (a.Cin > (a.R ? 2048 : 512) || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;

@@ -397,7 +397,12 @@ class ConvStackProgram:
         # OPT-IN (SAT_FUSE_RESIDUAL=1): measured at cfg 2 it is a wash (6.83 vs 6.81 ms/step): the 77 MB the
         # separate kernel streams at 5.5 TB/s from 2048 workgroups then has to come through 196 workgroups' LDS rings
         # (2.6 TB/s: bytes in flight per CU), which costs the conv what the removed launch saved.
-        fuse_resid = training and dtype == L.SAT_BF16 and os.environ.get("SAT_FUSE_RESIDUAL", "0") == "1"
+        # SAT_FUSE_RESIDUAL=2 (round 3): only where conv_du_kernel can run the next conv1 (K = 4 * planes <= 1024 input channels, 256
+        # output columns: the transitions inside layer 3 and into it) -- 64 rows x all columns per workgroup, 32-channel stages in a
+        # six-slot ring, the transform and the y store on the loader waves (sat_conv_du.inc); y is written over the raw conv3
+        # tensor IN PLACE, so the in-place passes of the other layers stay as they are.
+        fuse_resid_mode = int(os.environ.get("SAT_FUSE_RESIDUAL", "0")) if (training and dtype == L.SAT_BF16) else 0
+        fuse_resid = fuse_resid_mode == 1
         # TWO-PASS conv3 (bf16 training, identity-residual bottlenecks), OPT-IN (SAT_CONV3_TWOPASS=1): conv3 runs once for its
         # BatchNorm statistics only (no output), then again with bn3 + residual add + ReLU in its epilogue (scale / shift derived
         # from the sums of pass 1).  The raw conv3 tensor is never written or re-read and the normalise+add launch disappears
@@ -448,7 +453,12 @@ class ConvStackProgram:
                 continue
             if pending is not None:
                 ps3, pt3, presid = pending
-                cv1 = std_conv(blk.conv1, self.c3, self.c1, N, h, w_, h, w_)      # A = previous RAW conv3 output ...
+                if fuse_resid_mode == 2:
+                    # the raw conv3 tensor sits in y itself (in-place mode): conv_du_kernel forms relu(bn3(y) + presid) stage by stage,
+                    # multiplies it and writes it back over y
+                    cv1 = std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_)
+                else:
+                    cv1 = std_conv(blk.conv1, self.c3, self.c1, N, h, w_, h, w_)  # A = previous RAW conv3 output ...
                 cv1.in1, cv1.out1 = presid.data_ptr(), y.data_ptr()              # ... + previous block input -> y (stored too)
                 ref = bnref.get(ps3.data_ptr())
                 if ref is None:
@@ -563,6 +573,9 @@ class ConvStackProgram:
                 ops.append(act_op(L.OP_BN_ADD_RELU, c3buf, s3, t3, ynext, N, h2, w2, planes * 4, self.cd, sd, td_))
             elif (fuse_resid and bi + 1 < len(blocks_geo) and (planes * 4) % 64 == 0 and planes * 4 <= 2048):
                 pending = (s3, t3, y)            # the next block's conv1 forms relu(c3*s3+t3 + y) itself and writes it to ynext
+            elif (fuse_resid_mode == 2 and inplace and bi + 1 < len(blocks_geo) and (planes * 4) % 64 == 0 and 320 <= planes * 4 <= 1024 and
+                  blocks_geo[bi + 1][1][5] == 256 and ref3 is not None and tm2 <= ATOMIC_MAX_TILES):
+                pending = (s3, t3, y)            # (conv3 wrote its raw output into ynext: the next conv1 transforms it in place)
             else:
                 ops.append(act_op(L.OP_BN_ADD_RELU, c3buf, s3, t3, ynext, N, h2, w2, planes * 4, y))
             y, ynext = ynext, y

@@ -275,3 +275,39 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "xpstamps":
     for v in (41, 42):
         for f in (0, 1):
             xp_stamps(v, f)
+
+
+def bench_du(reps=20):
+    """dual-source conv1 of layer 3 (M = 12544, K = 1024, N = 256): conv_du_kernel (44) against the dual ring kernels (22, 24) and against
+    the un-fused pair (normalise+add launch, then the plain conv)"""
+    lib = L.load()
+    N, H, W, Cin, Cout = 64, 14, 14, 1024, 256
+    M = N * H * W
+    c3 = torch.randn(M, Cin, device="cuda").bfloat16()
+    resid = torch.randn(M, Cin, device="cuda").clamp(min=0).bfloat16()
+    w = (torch.randn(Cout, Cin, device="cuda") / 32).bfloat16()
+    out = torch.empty(M, Cout, device="cuda", dtype=torch.bfloat16)
+    yd = torch.empty(M, Cin, device="cuda", dtype=torch.bfloat16)
+    own = torch.zeros(2, 8, 2, Cout, dtype=torch.int64, device="cuda")
+    sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
+
+    def conv(v, dual, in_place=False):
+        o = L.SatOp()
+        o.kind, o.dtype = L.OP_CONV, L.SAT_BF16
+        o.in0, o.w, o.out = c3.data_ptr(), w.data_ptr(), out.data_ptr()
+        o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, H, W, Cout
+        o.KH, o.KW, o.stride, o.pad = 1, 1, 1, 0
+        o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
+        o.stat_acc, o.stat_shards, o.variant = own.data_ptr(), 8, v
+        if dual:
+            o.in1, o.out1 = resid.data_ptr(), (c3 if in_place else yd).data_ptr()
+            o.scale0, o.shift0 = sc.data_ptr(), sh.data_ptr()
+        return o
+    for name, o in (("plain conv v12 (no fusion; + a normalise+add launch of ~19 us in the program)", conv(12, False)),
+                    ("plain conv v16", conv(16, False)), ("dual ring v22", conv(22, True)), ("dual ring v24", conv(24, True)),
+                    ("conv_du_kernel v44", conv(44, True)), ("conv_du_kernel v44 in place", conv(44, True, True))):
+        print("%-90s %.1f us" % (name, time_ops((L.SatOp * 1)(o), 1, reps)))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "du":
+    bench_du()
