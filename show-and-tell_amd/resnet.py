@@ -257,7 +257,7 @@ class ConvStackProgram:
         # pixels): there the transform touches each 64-channel slice of the input patch ONCE per workgroup (LDS-resident patch,
         # sat_conv_pr.inc) instead of once per tap
         # Measured (bench.py, A/B on one box): 15.37 -> 15.95 k img/s with three stacks in flight, 11.1 -> 11.5 k strictly sequential:
-        # 42 of the 50 normalise+ReLU launches of ResNet-152 disappear.  Default 2; 0 restores the separate launches, 1 fuses
+        # 44 of the 50 normalise+ReLU launches of ResNet-152 disappear.  Default 2; 0 restores the separate launches, 1 fuses
         # everywhere (the in-ring transform of the older kernels where conv_pr_kernel cannot run: the measured loss above).
         fuse_bn1_mode = int(os.environ.get("SAT_FUSE_BN1", "2")) if (training and dtype == L.SAT_BF16) else 0
         fuse_bn1 = fuse_bn1_mode == 1

@@ -25,6 +25,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 sat = importlib.import_module("show-and-tell_amd")
+L = sat._lib
 from oracle import decoder as OD  # noqa: E402
 from oracle import encoder as OE  # noqa: E402
 from oracle import train_step as OT  # noqa: E402
@@ -345,6 +346,50 @@ def test_residual_fusion_into_next_conv1_matches_separate_bn_add(monkeypatch):
     bufs = {k: v.clone() for k, v in buffers.items()}
     ref_bf = OE.resnet_forward_bf16_storage(params, xs[0].cpu(), arch)
     assert _rel(out[0].cpu(), ref_bf) < 0.02
+
+
+def test_residual_fusion_in_place_by_conv_du_kernel_matches_separate_bn_add(monkeypatch):
+    """SAT_FUSE_RESIDUAL=2 (opt-in): inside layer 3 the previous block's bn3 + add + ReLU is formed by conv_du_kernel in the next
+    conv1, y written over the raw conv3 tensor in place; the other layers keep their in-place normalise+add launches.  Same pooled
+    features as the default program to bf16 noise (the conv1 statistics are summed over 64-row tiles there), same launch
+    bookkeeping: 35 normalise+add launches gone; models.py:27."""
+    arch, E = OE.RESNET152, 64
+    gen = torch.Generator().manual_seed(7)
+    params, buffers = OE.init_encoder_params(E, arch, generator=gen, conditioning="trained_like")     # (the He-init stack is chaotic)
+    imgs = torch.randn(8, 3, 224, 224, generator=gen).cuda()
+    monkeypatch.setenv("SAT_FUSE_RESIDUAL", "0")
+    enc0 = _encoder(arch, E, params, buffers, "bf16").train()
+    with torch.no_grad():
+        ref = enc0.pooled_features(imgs).clone()
+    n_plain = next(iter(enc0._programs.values())).n_ops
+    monkeypatch.setenv("SAT_FUSE_RESIDUAL", "2")
+    enc1 = _encoder(arch, E, params, buffers, "bf16").train()
+    with torch.no_grad():
+        got = enc1.pooled_features(imgs)
+    prog = next(iter(enc1._programs.values()))
+    assert n_plain - prog.n_ops == 35                       # the transitions inside layer 3
+    n_dual = sum(1 for i in range(prog.n_ops) if prog.ops[i].kind == L.OP_CONV and prog.ops[i].out1)
+    assert n_dual == 35
+    assert all(prog.ops[i].out1 == prog.ops[i].in0 for i in range(prog.n_ops) if prog.ops[i].kind == L.OP_CONV and prog.ops[i].out1)
+    rel = _rel(got.cpu(), ref.cpu())
+    print("conv_du_kernel program vs default program, pooled features: rel-L2 %.5f" % rel)
+    assert rel < 0.01, rel
+
+
+def test_default_program_fuses_bn1_where_the_patch_kernel_runs():
+    """The default bf16 training program of ResNet-152 (SAT_FUSE_BN1=2): conv2 of every stride-1 bottleneck with 128..512 planes and
+    rows of <= 31 pixels carries bn1 + ReLU itself (conv_pr_kernel's LDS-resident patch) -- 44 of the 50 normalise+ReLU launches are
+    gone (7 + 35 + 2 in layers 2, 3, 4), six remain (layer 1: 64 planes; the stride-2 first blocks of layers 2-4)."""
+    torch.manual_seed(3)
+    enc = sat.EncoderCNN(64, compute_dtype="bf16").cuda().train()
+    with torch.no_grad():
+        enc.pooled_features(torch.randn(4, 3, 224, 224, device="cuda"))
+    prog = next(iter(enc._programs.values()))
+    ops = [prog.ops[i] for i in range(prog.n_ops)]
+    fused3x3 = [o for o in ops if o.kind == L.OP_CONV and o.KH == 3 and o.stat_acc1]
+    assert len(fused3x3) == 44
+    assert all(o.stride == 1 and o.Win <= 31 and 128 <= o.Cout <= 512 for o in fused3x3)
+    assert sum(1 for o in ops if o.kind == L.OP_BN_RELU) == 6
 
 
 def test_lookahead_is_bitwise_identical_at_the_benchmarked_configuration():
