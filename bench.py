@@ -251,6 +251,7 @@ def main():
     dp = sat.DataParallelStep(ts)
     if args.force_dist and os.environ.get("SAT_FORCE_DIST_INIT_ONLY", "0") != "1":
         dp.world = 2          # take the multi-rank code path (async bucket all-reduces) on the single rank
+        dp.cap_lookahead()    # ... with the look-ahead depth that path runs at
     images, caps, lengths = synth_batch(torch, CFG["batch"], CFG["vocab"], CFG["cap_len"], CFG["image"], dev, 123 + rank)
     global_tokens = world * sum(l - 1 for l in lengths)
 
