@@ -119,6 +119,12 @@ class EncoderCNN(nn.Module):
         self.compute_dtype = compute_dtype
         env = os.environ.get("SAT_LOOKAHEAD_DEPTH")
         self.lookahead_depth = int(env) if env else self.LOOKAHEAD_DEPTH.get(arch if isinstance(arch, str) else "", 3)
+        # side streams the stacks in flight are spread over (round robin in prefetch order); None = one per stack in flight.  Fewer
+        # streams than stacks queue a later batch's stack BEHIND an earlier one's on the same hardware queue (it starts the moment
+        # that one ends, without waiting for the host) -- for steps that need a hardware queue for something else (RCCL: trainer.py)
+        env_s = os.environ.get("SAT_LOOKAHEAD_STREAMS")
+        self.lookahead_streams = int(env_s) if env_s else None
+        self._pf_seq = 0
         self._programs = {}      # insertion-ordered: least recently used first (`_program` re-inserts on a hit)
         self._inflight = []      # look-ahead (prefetch): [(images, instance, event, program, weights signature, images._version)]
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
@@ -196,7 +202,9 @@ class EncoderCNN(nn.Module):
         L.require_gpu(images, "images")
         busy = {e[1] for e in self._inflight}
         inst = next(i for i in range(self.lookahead_depth) if i not in busy)
-        stream = lookahead_stream(images.device, inst)
+        n_streams = self.lookahead_streams or self.lookahead_depth
+        stream = lookahead_stream(images.device, inst if n_streams >= self.lookahead_depth else self._pf_seq % n_streams)
+        self._pf_seq += 1
         stream.wait_stream(torch.cuda.current_stream(images.device))   # the images, and this instance's previous consumer
         ready = getattr(images, "_sat_ready_event", None)              # a DevicePrefetcher copy still in flight on its own stream
         if ready is not None:

@@ -373,16 +373,17 @@ class DataParallelStep:
         if self.world > 1:
             self.cap_lookahead()
 
-    LOOKAHEAD_DEPTH_DP = 2
+    LOOKAHEAD_STREAMS_DP = 2
 
     def cap_lookahead(self):
         """With collectives in the step, RCCL's stream is one more concurrently active hardware queue: main + three look-ahead streams +
-        RCCL = five, and the fifth costs 0.45-0.55 ms per step (bench.py --force-dist on one rank, end of round 3: 14.0-14.2 k img/s at
-        depth 3 against 14.8 k at depth 2, where the wrapper costs 2.5 %; without collectives depth 3 wins 15.9 vs 15.2 k).  So the
-        data-parallel step runs the encoder look-ahead at depth 2 unless SAT_LOOKAHEAD_DEPTH says otherwise."""
+        RCCL = five, and the fifth costs 0.45-0.55 ms per step (bench.py --force-dist on one rank, end of round 3: 14.0-14.2 k img/s with
+        three stacks on three streams against 15.9 k without collectives).  So the data-parallel step spreads the (still three)
+        stacks in flight over TWO side streams -- the third queues behind the first on its hardware queue and starts the moment that
+        one ends: 15.05-15.1 k img/s (depth 2 on two streams: 14.85 k; tools/run_gpu_dist_ab.sh).  SAT_LOOKAHEAD_STREAMS overrides."""
         enc = getattr(getattr(self.engine, "model", None), "encoder", None)
-        if enc is not None and hasattr(enc, "lookahead_depth") and not _os.environ.get("SAT_LOOKAHEAD_DEPTH"):
-            enc.lookahead_depth = min(enc.lookahead_depth, self.LOOKAHEAD_DEPTH_DP)
+        if enc is not None and hasattr(enc, "lookahead_depth") and not _os.environ.get("SAT_LOOKAHEAD_STREAMS"):
+            enc.lookahead_streams = min(enc.lookahead_depth, self.LOOKAHEAD_STREAMS_DP)
 
     def step(self, batch, global_tokens, lr=None, next_images=None):
         eng, dist = self.engine, self.dist
