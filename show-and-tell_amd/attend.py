@@ -585,7 +585,7 @@ class ShowAttendTellModel(nn.Module):
         """Greedy search, 20 steps (model2.py:91-111; torch-0.1 keepdim semantics): i64 [B,20].  `states`: None = zeros (what
         eval.py:82-83 passes), a (h, c) pair of [B,H] tensors, or eval.py:89's stacked [2,B,H] tensor."""
         feats, _ = self._encode(images)
-        return self.sample_features(feats, states)
+        return self.sample_features(feats, states).squeeze()      # model2.py:111: [20] at batch 1
 
     @torch.no_grad()
     def sample_features(self, features, states=None, steps=20, start_id=1):
@@ -599,6 +599,9 @@ class ShowAttendTellModel(nn.Module):
         if states is None:
             h, c = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
         else:
+            if len(states) != 2 or any(tuple(s.shape) != (B, H) for s in states):
+                raise ValueError("states must be (h, c), each [B=%d, H=%d] (model2.py:99), got %s"
+                                 % (B, H, [tuple(s.shape) for s in states]))
             h, c = states[0].to(dev).float().contiguous().clone(), states[1].to(dev).float().contiguous().clone()
         h2 = torch.empty(B, H, device=dev)
         proj, X = torch.empty(B, C, device=dev), torch.empty(B, Hin, device=dev)

@@ -72,6 +72,8 @@ def validation_step(model, images, captions, lengths, state=None, end_id=2, beam
         ids = model.sample_beam(images, beam_size=beam_size, end_id=end_id)
     else:
         ids = model.sample(images, state)                               # eval.py:99
+        if ids.dim() == 1:                                              # squeezed at batch 1 (models.py:67): one row
+            ids = ids.view(1, -1)
     return {"loss": loss, "ids": ids, "kept": kept_tokens(ids, end_id)}
 
 

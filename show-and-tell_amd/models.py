@@ -584,20 +584,18 @@ class DecoderRNN(nn.Module):
     @torch.no_grad()
     def sample(self, features, states=None):
         """Greedy search, 20 steps (models.py:56-67; torch-0.1 keepdim semantics): i64 [B,20].
-        `states`: None (zeros, as eval.py:82-83 passes) or (h0, c0) each [num_layers, B, H]."""
+        `states`: None (zeros), (h0, c0) each [num_layers, B, H], or eval.py:82-89's stacked [2, B, H] tensor
+        (`_initial_states`); the result is squeezed like models.py:67 ([20] at batch 1)."""
         lib = L.load()
         features = _f32c(features, "features")
         dev = features.device
         B = features.shape[0]
         H, V, E = self.hidden_size, self.vocab_size, self.embed_size
         st = L.stream()
-        h = [torch.zeros(B, H, device=dev) for _ in range(self.num_layers)]
+        h0, c0 = self._initial_states(states, B, dev)
+        h = [h0[l].clone() for l in range(self.num_layers)]
         h2 = [torch.empty(B, H, device=dev) for _ in range(self.num_layers)]
-        c = [torch.zeros(B, H, device=dev) for _ in range(self.num_layers)]
-        if states is not None and isinstance(states, (tuple, list)) and states[0].dim() == 3:
-            for l in range(self.num_layers):
-                h[l].copy_(states[0][l])
-                c[l].copy_(states[1][l])
+        c = [c0[l].clone() for l in range(self.num_layers)]
         ids = torch.empty(B, 20, dtype=torch.int64, device=dev)
         wsb = lib.sat_vocab_argmax_ws_bytes(B, V)
         ws = torch.empty(wsb // 4, device=dev)
@@ -617,7 +615,34 @@ class DecoderRNN(nn.Module):
             L.check(lib.sat_embed_rows(L.ptr(self.embed.weight), col.data_ptr(), ids.stride(0), B, E, V, L.ptr(xe), st),
                     "sat_embed_rows")
             x = xe
-        return ids
+        return ids.squeeze()                # models.py:67: [20] at batch 1
+
+    def _initial_states(self, states, B, dev):
+        """The LSTM state `sample` starts from (models.py:56,61 hands `states` to nn.LSTM) as two f32 [num_layers, B, H]
+        tensors.  Accepted: None (zeros); `(h0, c0)` each [num_layers, B, H] (nn.LSTM's own form) or, for one layer, [B, H];
+        eval.py:82-89's stacked tensor [2, B, H] (= (h0, c0) of a one-layer LSTM) or [2, num_layers, B, H].  Anything else
+        raises -- nothing is silently replaced by zeros."""
+        Lh, H = self.num_layers, self.hidden_size
+        if states is None:
+            z = torch.zeros(2, Lh, B, H, device=dev)
+            return z[0], z[1]
+        if torch.is_tensor(states):
+            if states.dim() not in (3, 4) or states.shape[0] != 2:
+                raise ValueError("states tensor must be stacked (h0, c0): [2, B, H] or [2, num_layers, B, H], got %s"
+                                 % (tuple(states.shape),))
+            states = (states[0], states[1])
+        if not isinstance(states, (tuple, list)) or len(states) != 2 or not all(torch.is_tensor(s) for s in states):
+            raise TypeError("states must be None, a (h0, c0) pair of tensors or their stacked tensor")
+        out = []
+        for name, s in zip(("h0", "c0"), states):
+            if s.dim() == 2 and Lh == 1:
+                s = s.unsqueeze(0)
+            if tuple(s.shape) != (Lh, B, H):
+                raise ValueError("%s must be [num_layers=%d, B=%d, H=%d]%s, got %s"
+                                 % (name, Lh, B, H, " (or [B, H])" if Lh == 1 else "", tuple(s.shape)))
+            L.require_gpu(s, name)
+            out.append(s.to(dtype=torch.float32).contiguous())
+        return out[0], out[1]
 
     @torch.no_grad()
     def sample_beam(self, features, beam_size=5, end_id=None, steps=20, return_all=False):
@@ -708,7 +733,8 @@ class ShowAndTell(nn.Module):
 
     @torch.no_grad()
     def sample(self, images, state=None):
-        return self.decoder.sample(self.encoder(images), None)
+        """eval.py:93,99 `model.sample(images, state)`: the state is handed to the decoder's LSTM (models.py:56,61)."""
+        return self.decoder.sample(self.encoder(images), state)
 
     @torch.no_grad()
     def sample_beam(self, images, beam_size=5, end_id=None, return_all=False):

@@ -2,7 +2,7 @@
 """Generate tests/golden/G*.npz by running the REFERENCE's own `models.DecoderRNN` (imported from
 /root/reference, build container only) plus train.py's loss / clamp / Adam arithmetic.
 
-    python tests/golden/make_goldens.py            # rewrites tests/golden/G1..G5, G8
+    python tests/golden/make_goldens.py [out_dir]  # rewrites G1, G2, G3, G5, G8, G9 (default: tests/golden)
 
 The reference never travels: only these data files (inputs + expected outputs) are committed.
 `torchvision` is absent offline; `models.py:3` imports it at top level only for the encoder, so an empty
@@ -90,11 +90,12 @@ def run_reference(models, E, H, V, L, B, T, lengths, seed, n_adam=0, lr=1e-3, gr
     return dec, params, feats, out
 
 
-def greedy_reference(dec, feats):
+def greedy_reference(dec, feats, states=None):
     """models.py:56-67 driven through the reference module's own submodules, keepdim restatement
-    (as written it raises on torch 2.x at iteration 2: SURVEY 3.3)."""
+    (as written it raises on torch 2.x at iteration 2: SURVEY 3.3).  `states`: what models.py:56 takes and :61 hands to
+    nn.LSTM -- None or (h0, c0), each [num_layers, B, H]."""
     with torch.no_grad():
-        ids, inputs, states = [], feats.unsqueeze(1), None
+        ids, inputs = [], feats.unsqueeze(1)
         for _ in range(20):
             hiddens, states = dec.lstm(inputs, states)
             outputs = dec.linear(hiddens.squeeze(1))
@@ -104,7 +105,24 @@ def greedy_reference(dec, feats):
         return torch.cat(ids, 1)
 
 
-def eval_case(models, name, seed, B, T, E, H, V, L, lengths, end_id=2):
+def states_case(models, out_dir, name, seed, B, E, H, V, L):
+    """`sample(features, states)` with a NON-ZERO initial state (models.py:56,61): the greedy ids of the reference decoder's own
+    lstm / linear / embed from seeded (h0, c0)."""
+    dec = models_reload(models, E, H, V, L, seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    feats = torch.randn(B, E, generator=g)
+    h0 = torch.randn(L, B, H, generator=g) * 0.5
+    c0 = torch.randn(L, B, H, generator=g) * 0.5
+    ids = greedy_reference(dec, feats, (h0, c0))
+    ids_zero = greedy_reference(dec, feats, None)
+    assert not torch.equal(ids, ids_zero), "the state must matter for this case to pin anything"
+    out = dict(seed=seed, dims=np.array([E, H, V, L, B, 20]), features=feats.numpy(), h0=h0.numpy(), c0=c0.numpy(),
+               greedy_ids=ids.numpy(), greedy_ids_zero_state=ids_zero.numpy())
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **out)
+    print(name, "rows differing from the zero-state ids:", int((ids != ids_zero).any(1).sum()), "of", B)
+
+
+def eval_case(models, out_dir, name, seed, B, T, E, H, V, L, lengths, end_id=2):
     """The validation half of `evaluation` (eval.py:91-93) on the reference decoder: UNSHIFTED captions and FULL lengths --
     `targets = pack(captions, lengths)`, `outputs = model(images, captions, lengths)`, `loss = crit(outputs, targets)` --
     plus the greedy ids of `model.sample` (eval.py:99) and, per row, the number of tokens the id->word loop of
@@ -136,11 +154,13 @@ def eval_case(models, name, seed, B, T, E, H, V, L, lengths, end_id=2):
     out = dict(seed=seed, dims=np.array([E, H, V, L, B, T]), lengths=np.array(lengths), features=feats.numpy(),
                captions=caps.numpy(), logits=logits.numpy(), targets=targets.numpy(), loss=np.float32(loss.item()),
                greedy_ids=ids.numpy(), ids_planted=ids_planted.numpy(), kept_tokens=np.array(keep), end_id=np.array(end_id))
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **out)
     print(name, "loss", loss.item(), "kept", keep)
 
 
-def main():
+def main(out_dir=HERE):
+    HERE = out_dir
+    os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(4)
     models = import_reference_models()
     # G1: small, equal lengths, fwd/bwd + 3 Adam steps
@@ -166,6 +186,11 @@ def main():
     dec5, _, feats5, g5 = run_reference(models, 32, 48, 300, 2, 4, 12, [12, 12, 9, 5], 125, n_adam=1)
     g5["greedy_ids"] = greedy_reference(models_reload(models, 32, 48, 300, 2, 125), feats5).numpy()
     np.savez_compressed(os.path.join(HERE, "G5_dec_L2.npz"), **g5)
+    # G8: the validation forward of eval.py:91-109 (unshifted captions, full lengths)
+    eval_case(models, HERE, "G8_dec_eval_unshifted", 131, 4, 12, 32, 64, 500, 1, [12, 9, 9, 5])
+    # G9: sample() from a non-zero LSTM state, one and two layers
+    states_case(models, HERE, "G9_dec_sample_states_L1", 141, 5, 32, 64, 500, 1)
+    states_case(models, HERE, "G9_dec_sample_states_L2", 142, 3, 32, 48, 300, 2)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
@@ -180,4 +205,4 @@ def models_reload(models, E, H, V, L, seed):
 
 
 if __name__ == "__main__":
-    main()
+    main(*sys.argv[1:2])

@@ -134,11 +134,16 @@ def make(model2, name, hidden, context, vocab, embed, B, T, P, lengths, seed, fe
     out["sample_ids_zero_state"] = reference_sample(m, features, (torch.zeros(B, H), torch.zeros(B, H))).numpy()   # eval.py:82-83
     h0, c0 = m.init_lstm(features)
     out["sample_ids_init_state"] = reference_sample(m, features, (h0.detach(), c0.detach())).numpy()
-    np.savez_compressed(os.path.join(HERE, name), **out)
-    print(name, os.path.getsize(os.path.join(HERE, name)), "loss", loss.item())
+    np.savez_compressed(os.path.join(OUT_DIR[0], name), **out)
+    print(name, os.path.getsize(os.path.join(OUT_DIR[0], name)), "loss", loss.item())
 
 
-def main():
+OUT_DIR = [HERE]
+
+
+def main(out_dir=HERE):
+    OUT_DIR[0] = out_dir
+    os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(4)
     model2 = import_model2()
     # hidden = embed + 512 (the LSTMCell input is cat[embedding, context], model2.py:57-58); context = 512 (expand_as, model2.py:74)
@@ -148,4 +153,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(*sys.argv[1:2])

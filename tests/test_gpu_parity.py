@@ -145,6 +145,39 @@ def test_greedy_decode_ids_bit_exact(golden_dir, name):
     assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])
 
 
+@pytest.mark.parametrize("name", ["G9_dec_sample_states_L1.npz", "G9_dec_sample_states_L2.npz"])
+def test_sample_honours_the_initial_state(golden_dir, name):
+    """models.py:56,61 hands `states` to the LSTM; eval.py:82-89 passes a stacked [2,B,H] tensor.  G9 = the reference decoder's
+    own submodules from a seeded non-zero (h0, c0): bit-exact ids for the tuple form, the stacked form (one layer: [2,B,H];
+    any: [2,L,B,H]), through ShowAndTell-style `sample(features, state)`; any other shape raises instead of decoding from zeros"""
+    g = load(golden_dir, name)
+    dec, params, (E, H, V, Lh, B, T) = golden_setup(g)
+    dec.eval()
+    feats = torch.from_numpy(g["features"]).cuda()
+    h0, c0 = torch.from_numpy(g["h0"]).cuda(), torch.from_numpy(g["c0"]).cuda()
+    ids = dec.sample(feats, (h0, c0))
+    assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])
+    assert np.array_equal(ids.cpu().numpy(), OD.greedy_sample(params, torch.from_numpy(g["features"]), Lh,
+                                                              states=(h0.cpu(), c0.cpu())).numpy())
+    assert np.array_equal(dec.sample(feats, torch.stack([h0, c0])).cpu().numpy(), g["greedy_ids"])      # [2,L,B,H]
+    if Lh == 1:
+        assert np.array_equal(dec.sample(feats, torch.stack([h0[0], c0[0]])).cpu().numpy(), g["greedy_ids"])   # eval.py:89
+        assert np.array_equal(dec.sample(feats, (h0[0], c0[0])).cpu().numpy(), g["greedy_ids"])
+    assert np.array_equal(dec.sample(feats, None).cpu().numpy(), g["greedy_ids_zero_state"])
+    assert np.array_equal(dec.sample(feats, torch.zeros(2, Lh, B, H, device="cuda")).cpu().numpy(), g["greedy_ids_zero_state"])
+    # the state is not modified by the call
+    assert torch.equal(h0.cpu(), torch.from_numpy(g["h0"])) and torch.equal(c0.cpu(), torch.from_numpy(g["c0"]))
+    for bad in ((h0[:, :-1], c0[:, :-1]), (h0,), torch.zeros(3, B, H, device="cuda"), (h0[..., :-1], c0[..., :-1]),
+                torch.zeros(2, B + 1, H, device="cuda")):
+        with pytest.raises((ValueError, TypeError)):
+            dec.sample(feats, bad)
+    with pytest.raises(TypeError):
+        dec.sample(feats, "zeros")
+    # models.py:67 `sampled_ids.squeeze()`: one image gives [20]
+    one = dec.sample(feats[:1], (h0[:, :1], c0[:, :1]))
+    assert one.shape == (20,) and np.array_equal(one.cpu().numpy(), g["greedy_ids"][0])
+
+
 @pytest.mark.parametrize("name", ["G1_dec_fwd_bwd_small.npz", "G3_dec_cfg1_summary.npz", "G5_dec_L2.npz"])
 def test_beam_width_one_reproduces_golden_greedy_ids(golden_dir, name):
     """sample_beam has no reference counterpart (model2.py:113-114 is a stub); width 1 must be the pinned greedy ids"""

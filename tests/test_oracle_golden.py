@@ -141,3 +141,34 @@ def test_validation_forward_unshifted_captions_and_end_truncation(golden_dir):
     assert abs(loss.item() - float(g["loss"])) < 2e-6
     assert np.array_equal(OD.greedy_sample(params, feats, L).numpy(), g["greedy_ids"])
     assert OT.kept_tokens(torch.from_numpy(g["ids_planted"]), int(g["end_id"])) == [int(x) for x in g["kept_tokens"]]
+
+
+@pytest.mark.parametrize("name", ["G9_dec_sample_states_L1.npz", "G9_dec_sample_states_L2.npz"])
+def test_greedy_sample_from_a_nonzero_state(golden_dir, name):
+    """models.py:56,61: `sample(features, states)` hands the state to nn.LSTM (G9: the reference decoder's own lstm / linear /
+    embed driven from a seeded (h0, c0))"""
+    g = load(golden_dir, name)
+    params, (E, H, V, L, B, T) = params_from_seed(g)
+    feats = torch.from_numpy(g["features"])
+    states = (torch.from_numpy(g["h0"]), torch.from_numpy(g["c0"]))
+    assert np.array_equal(OD.greedy_sample(params, feats, L, states=states).numpy(), g["greedy_ids"])
+    assert np.array_equal(OD.greedy_sample(params, feats, L).numpy(), g["greedy_ids_zero_state"])
+    assert not np.array_equal(g["greedy_ids"], g["greedy_ids_zero_state"])
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/models.py"), reason="the reference is only present in the build container")
+def test_committed_goldens_regenerate_from_the_reference(golden_dir, tmp_path):
+    """Every committed fixture is what the committed generator scripts produce from the imported reference TODAY: run both
+    scripts into a scratch directory (child processes: they put the reference on sys.path) and compare array by array."""
+    import subprocess
+    import sys
+    for script in ("make_goldens.py", "make_goldens_attend.py"):
+        subprocess.check_call([sys.executable, os.path.join(golden_dir, script), str(tmp_path)], stdout=subprocess.DEVNULL)
+    made = sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
+    committed = sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz"))
+    assert made == committed                      # no fixture without a recipe, no recipe without its fixture
+    for f in made:
+        a, b = np.load(os.path.join(tmp_path, f)), np.load(os.path.join(golden_dir, f))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (f, k)
