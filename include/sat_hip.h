@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 12
+#define SAT_ABI_VERSION 13
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -265,12 +265,17 @@ int64_t sat_lstm_fwd_ws_bytes(int B, int H);
  * sat_lstm_fwd zeroes it; the persistent launch sets it non-zero when a workgroup gave up waiting for its group (every wait
  * is bounded: co-tenants that keep its workgroups from being resident together).  The tapes and HS of such a call are
  * INVALID: the caller must copy the word out behind the call (hipMemcpyAsync to pinned memory) and treat non-zero as an
- * error -- `show-and-tell_amd.models.LstmWatch` raises RuntimeError and switches the process to per-step launches. */
+ * error -- `show-and-tell_amd.watch.ResidencyWatch` raises RuntimeError and switches the process to per-step launches. */
 int64_t sat_lstm_fwd_status_offset(int B, int H);
 /* process-wide switch of the persistent recurrence (default on); returns the previous setting.  Off: one launch per step. */
 int sat_lstm_persist_enable(int on);
 int64_t sat_lstm_bwd_ws_bytes(int B, int H);          /* minimum */
-/* size that also lets the batched dW_ih / dX GEMMs run split-K when they would leave most CUs idle (N = packed rows) */
+/* size that also lets the batched dW_ih / dX GEMMs run split-K when they would leave most CUs idle (N = packed rows), and the
+ * recurrence as ONE persistent launch.  INVARIANT of the full workspace: its granule-exchange region (a region of its own behind
+ * the split-K slabs) is never cleared per call -- granules carry a per-call epoch tag -- so the CALLER ZEROES THE WORKSPACE ONCE
+ * before its first use, hands the same buffer to later calls, and lets nobody else write into it; a fresh un-zeroed buffer per
+ * call (arbitrary old bit patterns) could, after enough calls, be read as a valid hand-off.  (The library re-zeroes a known
+ * buffer by itself when its 24-bit epoch counter wraps.) */
 int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H);
 /* With the FULL workspace (and the forward's envelope: H in {32,...,512}, T <= 64, ceil(B/8) * H/16 <= CUs) the backward
  * recurrence runs as ONE persistent launch too (SAT_LSTM_PERSIST_BWD=0: one launch per step).  Its STATUS WORD (uint32) sits at
@@ -479,6 +484,18 @@ int sat_kept_tokens(const int64_t* ids, int64_t stride, int B, int T, int64_t en
  */
 int sat_clamp_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
                         float beta2, float eps, float clip, int step, sat_stream_t stream);
+/* The same update behind a device-side guard: `skip_if_nonzero` (device f32 word, may be NULL) is read by the kernel, and a
+ * non-zero value drops the WHOLE update -- p, g, m, v stay bit for bit what they were.  The fused trainer aims it at the step's
+ * fault slot (below), so a step whose persistent LSTM recurrence gave up never reaches the parameters. */
+int sat_clamp_adam_step_guarded(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float clip, int step, const float* skip_if_nonzero,
+                                sat_stream_t stream);
+/* One step's fault flag: *slot = *sticky = (*sticky != 0 || any of the n_words (<= 8) u32 device status words != 0) ? 1.0f : 0.0f
+ * (`status_words`: HOST array of device pointers -- sat_lstm_fwd_status_offset / sat_lstm_bwd_status_offset words of the
+ * workspaces this step's calls ran with; `sticky`: device f32 the caller keeps across steps and clears once it has seen the
+ * fault, may be NULL).  The trainer puts `slot` into the flat gradient buffer's trailing floats, so that in data-parallel
+ * training the flag rides the last bucket's all-reduce(sum) and EVERY rank skips the update of a step one rank lost. */
+int sat_step_fault_flag(const void* const* status_words, int n_words, float* sticky, float* slot, sat_stream_t stream);
 
 /* column sums: out[c] = sum_r x[r*ld + c]  (bias gradients) */
 int sat_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, sat_stream_t stream);

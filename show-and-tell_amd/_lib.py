@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -137,6 +137,8 @@ SIGNATURES = {
     "sat_beam_backtrack": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_kept_tokens": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp]),
     "sat_clamp_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
+    "sat_clamp_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _vp]),
+    "sat_step_fault_flag": (_i, [C.POINTER(_vp), _i, _vp, _vp, _vp]),
     "sat_colsum_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "sat_cast_f32_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "sat_cast_bf16_f32": (_i, [_vp, _vp, _i64, _vp]),

@@ -706,9 +706,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 
 // ------------------------------------------------------------------------------------------------------
 // fused clamp + Adam (torch.optim.Adam single-tensor arithmetic, train.py:88-91,146)
+// `skip`: optional device word (f32); non-zero = some kernel of this step reported a fault (sat_step_fault_flag): the whole
+// update is dropped -- parameters, moments and the gradient buffer stay bit for bit what they were
 __global__ void clamp_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, long n, float beta1, float beta2, float eps, float clip,
-                                  float step_size, float bc2_sqrt) {
+                                  float step_size, float bc2_sqrt, const float* __restrict__ skip) {
+    if (skip && *skip != 0.0f) return;
     const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -1240,8 +1243,38 @@ extern "C" int sat_colsum_f32(const float* x, int64_t ld, int rows, int cols, fl
     return SAT_OK;
 }
 
+// ---- a step's fault flag: OR of the status words its residency-dependent kernels may have set ----
+struct FaultWords { const unsigned* w[8]; int n; };
+__global__ void step_fault_flag_kernel(const FaultWords fw, float* __restrict__ sticky, float* __restrict__ slot) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float f = sticky ? *sticky : 0.0f;
+    for (int i = 0; i < fw.n; ++i)
+        if (__hip_atomic_load(fw.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) f = 1.0f;
+    if (sticky) *sticky = f;
+    *slot = f;
+}
+
+extern "C" int sat_step_fault_flag(const void* const* status_words, int n_words, float* sticky, float* slot, sat_stream_t stream) {
+    if (!slot || n_words < 0 || n_words > 8 || (n_words > 0 && !status_words)) return SAT_ERR_ARG;
+    FaultWords fw = {};
+    fw.n = n_words;
+    for (int i = 0; i < n_words; ++i) {
+        if (!status_words[i]) return SAT_ERR_ARG;
+        fw.w[i] = (const unsigned*)status_words[i];
+    }
+    hipLaunchKernelGGL(step_fault_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fw, sticky, slot);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
 extern "C" int sat_clamp_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
                                    float beta2, float eps, float clip, int step, sat_stream_t stream) {
+    return sat_clamp_adam_step_guarded(p, g, m, v, n, lr, beta1, beta2, eps, clip, step, nullptr, stream);
+}
+
+extern "C" int sat_clamp_adam_step_guarded(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                           float beta2, float eps, float clip, int step, const float* skip_if_nonzero,
+                                           sat_stream_t stream) {
     if (!p || !g || !m || !v || n < 1 || step < 1) return SAT_ERR_ARG;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return SAT_ERR_ARG;
     // bias corrections in double on the host, exactly as torch.optim.Adam does with python floats
@@ -1250,7 +1283,7 @@ extern "C" int sat_clamp_adam_step(float* p, float* g, float* m, float* v, int64
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(clamp_adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v,
-                       (long)n, beta1, beta2, eps, clip, step_size, bc2_sqrt);
+                       (long)n, beta1, beta2, eps, clip, step_size, bc2_sqrt, skip_if_nonzero);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }

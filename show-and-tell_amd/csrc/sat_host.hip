@@ -305,16 +305,28 @@ static int fill_split(long M, long Nn, long K) {
     return (int)(ks < 1 ? 1 : (ks > 8 ? 8 : ks));
 }
 
-// workspace that additionally lets sat_lstm_bwd run its under-filled weight/input-gradient GEMMs split-K
+static int64_t lstm_bwd_exchange_offset(int N, int B, int In, int H) {
+    const int64_t base = sat_lstm_bwd_ws_bytes(B, H);
+    const int64_t dx = (int64_t)fill_split(N, In, 4L * H) * N * In * sizeof(float);
+    const int64_t dw = (int64_t)fill_split(4L * H, In, N) * 4 * H * In * sizeof(float);
+    int64_t m = dx > dw ? dx : dw;
+    if (base > m) m = base;
+    return (m + 255) / 256 * 256;
+}
+
+// workspace that additionally lets sat_lstm_bwd run its under-filled weight/input-gradient GEMMs split-K and its recurrence as
+// ONE persistent launch.  The caller ZEROES it once before its first use and hands the SAME buffer to later calls (or zeroes a
+// new one): the exchange region carries per-call epoch tags instead of being cleared per call.
 extern "C" int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H) {
     const int64_t base = sat_lstm_bwd_ws_bytes(B, H);
     const int64_t dx = (int64_t)fill_split(N, In, 4L * H) * N * In * sizeof(float);
     const int64_t dw = (int64_t)fill_split(4L * H, In, N) * 4 * H * In * sizeof(float);
     int64_t m = dx > dw ? dx : dw;
     if (base > m) m = base;
-    const int64_t pb = sat_lstm_persist_bwd_ws_bytes(B, H);          // granule exchange of the persistent backward recurrence
-    if (pb > m) m = pb;
-    return (m + 255) / 256 * 256 + 64;                               // + the recurrence's status word (last 64 bytes)
+    // [0, m): dh_part / dc_state of the per-step form, then the split-K slabs of the batched GEMMs;
+    // [align(m), + exchange): the granule exchange of the persistent backward recurrence, a region of ITS OWN -- nothing else
+    // writes there (its tags must never meet foreign bit patterns: ADVICE r3); last 64 bytes: the recurrence's status word
+    return lstm_bwd_exchange_offset(N, B, In, H) + (sat_lstm_persist_bwd_ws_bytes(B, H) + 255) / 256 * 256 + 64;
 }
 
 // Byte offset of the backward recurrence's STATUS WORD (uint32) in a workspace of sat_lstm_bwd_ws_bytes_full bytes: zeroed by every
@@ -351,7 +363,8 @@ static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, co
     if (ws_bytes >= full) {
         unsigned* status = (unsigned*)((char*)workspace + (full - 64));
         if (persist_bwd && sat_lstm_persist_bwd_ws_bytes(B, H) > 0 && sat_lstm_persist_ok(B, H, T, device_cu_count())) {
-            SAT_TRY(sat_lstm_persist_bwd_launch(dHS, GA, CS, w_hh, DG, batch_sizes, T, H, workspace, status, s));
+            SAT_TRY(sat_lstm_persist_bwd_launch(dHS, GA, CS, w_hh, DG, batch_sizes, T, H,
+                                                (char*)workspace + lstm_bwd_exchange_offset((int)N, B, In, H), status, s));
             recurrence_done = true;
         } else {
             e = hipMemsetAsync(status, 0, 64, s);

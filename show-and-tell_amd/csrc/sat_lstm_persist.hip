@@ -21,6 +21,8 @@
 #include "sat_internal.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 namespace {
 
@@ -475,11 +477,27 @@ int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* 
     a.dbg_stall = (ds && ds[0] == '2') ? 1 : 0;
     a.prefix[0] = 0;
     for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
-    static unsigned epoch = 0;
-    a.epoch = (++epoch) & 0x00ffffffu;
-    if (a.epoch == 0) a.epoch = epoch = 1;
+    // Tags are epoch * 128 + step + 1 with a process-wide call counter, so the exchange is never cleared per call.  Invariant
+    // (sat_hip.h): the caller zeroed the buffer before its first use and nobody else writes there.  When the 24-bit counter
+    // wraps, tags of 2^24 calls ago could match again: every buffer is then cleared once, at its next use (generation check).
+    static std::mutex mu;
+    static std::unordered_map<void*, unsigned> seen;     // exchange buffer -> generation it was last known clean in
+    static unsigned epoch = 0, generation = 1;
+    bool clear = false;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (++epoch >= (1u << 24)) { epoch = 1; ++generation; }
+        a.epoch = epoch;
+        auto it = seen.find(xch);
+        if (it == seen.end()) seen.emplace(xch, generation);
+        else if (it->second != generation) { it->second = generation; clear = true; }
+    }
     hipError_t e = hipMemsetAsync(err, 0, 64, s);
     if (e != hipSuccess) return (int)e;
+    if (clear) {
+        e = hipMemsetAsync(xch, 0, (size_t)(sat_lstm_persist_bwd_ws_bytes(B, H) - 64), s);
+        if (e != hipSuccess) return (int)e;
+    }
     const bool token = sat_resident_token_in_use() != 0;
     if (token) SAT_TRY(sat_resident_token_acquire(a.err, s));
     const dim3 grid(groups * members), block(256);

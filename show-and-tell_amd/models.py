@@ -272,29 +272,31 @@ class EncoderCNN(nn.Module):
 
 # ------------------------------------------------------------------------------------------------------
 # decoder
-class LstmWatch:
+def _watch_lstm(dev, ws, offset):
     """The persistent LSTM recurrence (`sat_lstm_persist.hip`) needs all its workgroups resident at once and bounds every
     hand-off wait; when a wait runs out the kernel sets the STATUS WORD of its workspace and drains -- the tapes and `HS` of that
     call are garbage.  `watch.ResidencyWatch` reads the word back behind every call and raises RuntimeError (at the latest one
-    call later; `TrainStep.check_ids()` polls at once) after switching the process to one launch per step
-    (`sat_lstm_persist_enable(0)`), which needs no co-residency."""
-
-    @staticmethod
-    def get(device):
-        return _LstmWatchView(ResidencyWatch.get(device))
+    call later) after switching the process to one launch per step (`sat_lstm_persist_enable(0)`), which needs no co-residency.
+    ws: the uint8 workspace the call just ran with; offset: sat_lstm_fwd_status_offset / sat_lstm_bwd_status_offset."""
+    ResidencyWatch.get(dev).submit(ws[offset:offset + 4].view(torch.int32), "the persistent LSTM recurrence",
+                                   lambda: L.load().sat_lstm_persist_enable(0))
 
 
-class _LstmWatchView:
-    def __init__(self, watch):
-        self.watch = watch
+_WS_CACHE = {}
 
-    def submit(self, ws, offset):
-        """ws: the uint8 workspace tensor sat_lstm_fwd just ran with; offset: sat_lstm_fwd_status_offset"""
-        self.watch.submit(ws[offset:offset + 4].view(torch.int32), "the persistent LSTM recurrence",
-                          lambda: L.load().sat_lstm_persist_enable(0))
 
-    def poll(self, block=False):
-        self.watch.poll(block)
+def _persistent_ws(dev, nbytes, tag):
+    """A ZEROED uint8 workspace that the same (device, stream, size, role) gets again on every call: the persistent backward
+    recurrence tags its exchange granules per call instead of clearing 17 MB per step, which needs a buffer that was zero before
+    its first use and that nobody else writes (include/sat_hip.h, sat_lstm_bwd_ws_bytes_full) -- a fresh `torch.empty` per call
+    holds arbitrary old bits."""
+    key = (str(dev), int(nbytes), tag, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None:
+        if len(_WS_CACHE) >= 16:
+            _WS_CACHE.pop(next(iter(_WS_CACHE)))
+        ws = _WS_CACHE[key] = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+    return ws
 
 
 class IdGuard:
@@ -373,10 +375,14 @@ class _Weight(nn.Module):
             self.bias = nn.Parameter(torch.zeros(bias))
 
 
-def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, captions, pi, logits=None, ce=None, mixed_ws=None):
+def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, captions, pi, logits=None, ce=None, mixed_ws=None,
+                          lstm_ws=None):
     """embed+cat+pack -> L x LSTM -> vocab logits (models.py:49-53).  Returns (logits, tapes).
     `ce` = dict(targets, inv_denom, lse, row_loss, loss_out, ws): the projection and the cross entropy (train.py:143) run as
-    ONE fused op (`sat_vocab_ce_fwd`: the loss never re-reads the logits)."""
+    ONE fused op (`sat_vocab_ce_fwd`: the loss never re-reads the logits).
+    `lstm_ws`: per layer (forward workspace, backward workspace) uint8 tensors the CALLER owns and watches (`TrainStep`: it
+    folds their status words into its step's fault flag); None: workspaces of this module, each call's status word handed to
+    `watch.ResidencyWatch`."""
     dev = features.device
     E = embed_w.shape[1]
     V = lin_w.shape[0]
@@ -403,7 +409,8 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
         HP = torch.empty(N, H, device=dev)
         cst = torch.empty(B, H, device=dev)
         wsb = lib.sat_lstm_fwd_ws_bytes(B, H)            # hidden-state exchange of the persistent recurrence
-        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        li = len(tapes["layers"])
+        ws = lstm_ws[li][0] if lstm_ws is not None else torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         if mixed_ws is not None:          # bf16 throughput mode: the x-gates GEMM on the bf16 matrix pipe
             L.check(lib.sat_lstm_fwd_bf16(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), pi.bs_c, T, In, H,
                                           L.ptr(GA), L.ptr(CS), L.ptr(HS), L.ptr(HP), L.ptr(cst), L.ptr(ws), wsb, L.ptr(mixed_ws),
@@ -412,8 +419,8 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
             L.check(lib.sat_lstm_fwd(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), pi.bs_c, T, In, H,
                                      L.ptr(GA), L.ptr(CS), L.ptr(HS), L.ptr(HP), L.ptr(cst), L.ptr(ws), wsb, st), "sat_lstm_fwd")
         soff = lib.sat_lstm_fwd_status_offset(B, H)
-        if soff >= 0 and wsb > 0:
-            LstmWatch.get(dev).submit(ws, soff)          # the recurrence's status word: raises (at the latest one call later)
+        if soff >= 0 and wsb > 0 and lstm_ws is None:
+            _watch_lstm(dev, ws, soff)                   # the recurrence's status word: raises (at the latest one call later)
         tapes["layers"].append((GA, CS, HP))
         tapes["X"].append(HS)
         inp = HS
@@ -436,7 +443,8 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
     return logits, tapes
 
 
-def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi, grads_out, on_stage=None, ce=None, mixed_ws=None):
+def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi, grads_out, on_stage=None, ce=None, mixed_ws=None,
+                           lstm_ws=None):
     """Backward of decoder_forward_tapes.  `dlogits`: f32 [N, ld] with ld = V rounded up to 4 and zero pad columns.  grads_out: dict name -> preallocated f32 tensor to fill:
     'embed', ('w_ih',l), ('w_hh',l), ('b_ih',l), ('b_hh',l), 'lin_w', 'lin_b', 'features'.
     on_stage(i) is called when gradient group i is final (0 vocab projection, 1 LSTM) -- the data-parallel
@@ -471,7 +479,12 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
         DG = torch.empty(N, 4 * H, device=dev)
         dX = torch.empty(N, In, device=dev)
         wsb = lib.sat_lstm_bwd_ws_bytes_full(N, B, In, H) if _LSTM_SPLITK else lib.sat_lstm_bwd_ws_bytes(B, H)
-        ws = torch.empty(wsb // 4, device=dev)
+        if lstm_ws is not None:
+            ws = lstm_ws[l][1]
+        elif _LSTM_SPLITK:                     # the full workspace must be zero before its first use and ours alone (sat_hip.h)
+            ws = _persistent_ws(dev, wsb, ("lstm_bwd", l))
+        else:
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         if mixed_ws is not None:
             L.check(lib.sat_lstm_bwd_bf16(L.ptr(dH), L.ptr(tapes["X"][l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(GA), L.ptr(CS),
                                           L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
@@ -483,9 +496,8 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
                                      L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
                                      L.ptr(grads_out[("w_hh", l)]), L.ptr(grads_out[("b_ih", l)]),
                                      L.ptr(grads_out[("b_hh", l)]), L.ptr(dX), L.ptr(ws), wsb, st), "sat_lstm_bwd")
-        if _LSTM_SPLITK:                       # full workspace: the backward recurrence may have run persistently -- its status word
-            soff = lib.sat_lstm_bwd_status_offset(N, B, In, H)
-            LstmWatch.get(dev).submit(ws.view(torch.uint8), soff)
+        if _LSTM_SPLITK and lstm_ws is None:   # full workspace: the backward recurrence may have run persistently -- its status word
+            _watch_lstm(dev, ws, lib.sat_lstm_bwd_status_offset(N, B, In, H))
         dH = dX
     if on_stage is not None:
         on_stage(1)

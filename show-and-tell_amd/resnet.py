@@ -627,8 +627,10 @@ class ConvStackProgram:
                     for i in range(self.n_ops):
                         if self.ops[i].kind == L.OP_CONV:
                             table[self._tune_key(self.ops[i])] = int(self.ops[i].variant)
-                    with open(tune_file, "w") as f:
+                    tmp = "%s.%d.tmp" % (tune_file, os.getpid())          # whole-file replace: other ranks may be reading it
+                    with open(tmp, "w") as f:
                         json.dump(table, f, indent=0, sort_keys=True)
+                    os.replace(tmp, tune_file)
 
     @staticmethod
     def _tune_key(o):

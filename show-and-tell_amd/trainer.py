@@ -68,7 +68,8 @@ class FlatParams:
                 off += _pad4(p.numel())
             self.buckets.append((start, off))
         self.n = off
-        # 4 trailing floats: slot 0 carries this rank's loss term through the last bucket's all-reduce
+        # 4 trailing floats: slot 0 carries this rank's loss term through the last bucket's all-reduce, slot 1 the step's fault
+        # flag (TrainStep._fault_flag: non-zero on EVERY rank after the reduction when any rank's persistent LSTM launch gave up)
         self.loss_slot = off
         self.buckets[-1] = (self.buckets[-1][0], off + 4)
         self.params = torch.zeros(off, device=dev)
@@ -105,6 +106,10 @@ class TrainStep:
         # "bf16": vocab projection + its gradient GEMMs on the bf16 matrix pipe (the throughput mode); "f32": exact-f32 MFMA
         self.decoder_gemm_dtype = "bf16" if (_DECODER_BF16 and model.encoder.compute_dtype == "bf16") else "f32"
         self._params_list = [p for _, p in self._trainable()]
+        # sticky device-side fault word of this engine (sat_step_fault_flag): set by a step whose persistent LSTM recurrence gave
+        # up, cleared by the host once it has raised for it; while it is set every clamp + Adam launch drops its update
+        self._fault_sticky = torch.zeros(1, device=self.flat.params.device)
+        self.fault_slot = self.flat.grads[self.flat.loss_slot + 1:self.flat.loss_slot + 2]
 
     # -- encoder look-ahead ---------------------------------------------------------------------------
     def prefetch_encoder(self, images):
@@ -169,6 +174,23 @@ class TrainStep:
                 xhat=torch.empty(B, E, device=dev), rstd=torch.empty(E, device=dev),
                 head_ws=torch.empty(max(wsb // 4, B * E), device=dev), d_feat=torch.empty(B, E, device=dev),
                 pooled=torch.empty(B, F, device=dev))
+            # LSTM workspaces this engine owns for good: zeroed once (the backward's exchange region is tagged per call, never
+            # cleared: sat_hip.h), their status words folded into the step's fault flag below
+            bufs["lstm_ws"], words = [], []
+            for l in range(dec.num_layers):
+                In = E if l == 0 else dec.hidden_size
+                fb, bb = lib.sat_lstm_fwd_ws_bytes(B, dec.hidden_size), lib.sat_lstm_bwd_ws_bytes_full(N, B, In, dec.hidden_size)
+                fws = torch.zeros(max(fb, 16), dtype=torch.uint8, device=dev)
+                bws = torch.zeros(bb, dtype=torch.uint8, device=dev)
+                bufs["lstm_ws"].append((fws, bws))
+                fo = lib.sat_lstm_fwd_status_offset(B, dec.hidden_size)
+                if fo >= 0 and fb > 0:
+                    words.append(fws.data_ptr() + fo)
+                words.append(bws.data_ptr() + lib.sat_lstm_bwd_status_offset(N, B, In, dec.hidden_size))
+            if len(words) > 8:
+                raise ValueError("at most 4 LSTM layers (8 status words per step)")
+            import ctypes as _C
+            bufs["fault_words"] = ((_C.c_void_p * len(words))(*words), len(words))
         # targets = pack(captions[:,1:], lengths-1)                           train.py:135
         L.check(lib.sat_pack_targets(captions.data_ptr(), captions.stride(0), L.ptr(pi.prefix_dev), pi.T, N,
                                      L.ptr(bufs["targets"]), st), "sat_pack_targets")
@@ -210,7 +232,8 @@ class TrainStep:
                 bufs["lstm_mixed_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
             mixed_ws = bufs["lstm_mixed_ws"]
         logits, tapes = decoder_forward_tapes(lib, feats_in, dec.embed.weight, layers, dec.linear.weight,
-                                              dec.linear.bias, captions[:, :-1], pi, logits=bufs["logits"], ce=ce, mixed_ws=mixed_ws)
+                                              dec.linear.bias, captions[:, :-1], pi, logits=bufs["logits"], ce=ce, mixed_ws=mixed_ws,
+                                              lstm_ws=bufs["lstm_ws"])
         if ce is None:
             # ---- loss + d(loss)/d(logits) in place (train.py:143) ----
             L.check(lib.sat_ce_rows(L.ptr(logits), logits.stride(0), L.ptr(bufs["targets"]), N, V, float(inv_denom), 1,
@@ -222,7 +245,7 @@ class TrainStep:
             for short, n in (("w_ih", "weight_ih"), ("w_hh", "weight_hh"), ("b_ih", "bias_ih"), ("b_hh", "bias_hh")):
                 g[(short, l)] = flat.grad("decoder.lstm.%s_l%d" % (n, l))
         decoder_backward_tapes(lib, logits, tapes, dec.embed.weight, layers, dec.linear.weight, pi, g,
-                               on_stage=on_bucket_ready, ce=ce, mixed_ws=mixed_ws)
+                               on_stage=on_bucket_ready, ce=ce, mixed_ws=mixed_ws, lstm_ws=bufs["lstm_ws"])
         if not cached_features:
             fc, bn = enc.resnet.fc, enc.bn
             L.check(lib.sat_fc_bn1d_bwd(L.ptr(bufs["d_feat"]), L.ptr(pooled), L.ptr(bufs["xhat"]), L.ptr(bufs["rstd"]),
@@ -234,26 +257,50 @@ class TrainStep:
         # this step's encoder outputs (views of step-owned buffers, overwritten by the next step): the parity tests at the
         # benchmarked configuration read them
         self.last_pooled, self.last_features = pooled, feats_in
+        # the step's fault flag (one 1-thread launch): OR of the status words of this step's persistent LSTM launches and of the
+        # engine's sticky word, into slot 1 of the trailing floats -- it rides the last bucket's all-reduce, and clamp + Adam
+        # read it on the device (optimizer_step): a step that any rank lost never reaches the parameters of any rank
+        words, nw = bufs["fault_words"]
+        L.check(lib.sat_step_fault_flag(words, nw, L.ptr(self._fault_sticky), L.ptr(self.fault_slot), st), "sat_step_fault_flag")
         if on_bucket_ready is not None:
             on_bucket_ready(2)   # encoder head + embedding gradients (and the loss slot) are final
         return loss_slot
 
     def check_ids(self):
         """Block until the device-side verdicts of the last submitted batch are known: raises IndexError on a bad caption id,
-        RuntimeError when the persistent LSTM recurrence gave up (`models.LstmWatch`)."""
+        RuntimeError when a persistent LSTM recurrence gave up (`watch.ResidencyWatch`; see `optimizer_step`)."""
         self.model.decoder.id_guard().poll(block=True)
         from .watch import ResidencyWatch
         ResidencyWatch.get(self.model.decoder.linear.weight.device).poll(block=True)
 
+    FAULT_NOTE = ("the parameter update of that step and of every step submitted since was SKIPPED on the device (on every rank in "
+                  "data-parallel training): parameters and Adam moments are exactly those before the faulted step and the step "
+                  "count has been rolled back; repeat the batches")
+
+    def _on_fault(self, step_before):
+        """host side of a raised fault: per-step launches from now on, step count back to where the first dropped update found
+        it (the updates in between were dropped on the device), sticky word cleared so that updates resume"""
+        self.lib.sat_lstm_persist_enable(0)
+        self.step_count = step_before
+        self._fault_sticky.zero_()
+
     def optimizer_step(self, lr=None):
-        """clip_gradient + Adam (train.py:145-146) as one launch over the flat buffers."""
+        """clip_gradient + Adam (train.py:145-146) as one launch over the flat buffers, GUARDED on the device by the step's
+        fault flag: when a persistent LSTM launch of this step (any rank's, after the all-reduce) gave up waiting for its
+        workgroups, the launch drops the whole update -- the garbage gradients never reach parameters or moments -- and so does
+        every later one until the host has seen the flag (sticky), raised RuntimeError (at the latest on the next submit;
+        `check_ids()` at once) and rolled the step count back."""
+        before = self.step_count
         self.step_count += 1
         f = self.flat
-        L.check(self.lib.sat_clamp_adam_step(L.ptr(f.params), L.ptr(f.grads), L.ptr(f.m), L.ptr(f.v), f.n,
-                                             float(self.lr if lr is None else lr), self.betas[0], self.betas[1],
-                                             self.eps, float(self.grad_clip), self.step_count, L.stream()),
-                "sat_clamp_adam_step")
+        L.check(self.lib.sat_clamp_adam_step_guarded(L.ptr(f.params), L.ptr(f.grads), L.ptr(f.m), L.ptr(f.v), f.n,
+                                                     float(self.lr if lr is None else lr), self.betas[0], self.betas[1],
+                                                     self.eps, float(self.grad_clip), self.step_count, L.ptr(self.fault_slot),
+                                                     L.stream()), "sat_clamp_adam_step_guarded")
         torch.autograd.graph.increment_version(self._params_list)     # written through raw pointers: bump `_version` like torch would
+        from .watch import ResidencyWatch
+        ResidencyWatch.get(f.params.device).submit(self.fault_slot.view(torch.int32), "a persistent LSTM recurrence of a training step",
+                                                   lambda: self._on_fault(before), note=self.FAULT_NOTE)
 
     # -- optimizer checkpoint interchange (SURVEY 8f.4; the reference's load_optimizer is an empty stub, ------
     #    train.py:60-64, and only model.state_dict() is saved, train.py:191-193) ---------------------------

@@ -25,8 +25,15 @@ class ResidencyWatch:
         self.pending = []           # (slot, event, what, on_error), oldest first
         self.slot = 0
 
-    def submit(self, word, what, on_error=None):
-        """word: a 1-element int32 device view of the status word the call that was just enqueued on the current stream may set"""
+    # what an exception says about the model's state when the caller gave no note of its own: the status word is seen one call
+    # later at the latest, and whatever consumed the call's outputs in between -- a torch optimizer step after
+    # `loss.backward()` -- has used them.  `trainer.TrainStep` gates its update on the device instead and says so.
+    DEFAULT_NOTE = ("the outputs of that call are invalid, and anything computed from them since -- an optimizer step taken "
+                    "after loss.backward() included -- has used them: restore the parameters from a checkpoint")
+
+    def submit(self, word, what, on_error=None, note=None):
+        """word: a 1-element int32 device view of the status word the call that was just enqueued on the current stream may set;
+        note: what the exception tells the user about parameters / optimizer state (DEFAULT_NOTE)"""
         self.poll(block=False)
         while len(self.pending) >= self.DEPTH:
             self._retire(block=True)
@@ -35,10 +42,10 @@ class ResidencyWatch:
         self.host[slot:slot + 1].copy_(word, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending.append((slot, ev, what, on_error))
+        self.pending.append((slot, ev, what, (on_error, note)))
 
     def _retire(self, block):
-        slot, ev, what, on_error = self.pending[0]
+        slot, ev, what, (on_error, note) = self.pending[0]
         if block:
             ev.synchronize()
         elif not ev.query():
@@ -51,9 +58,9 @@ class ResidencyWatch:
             self.pending.clear()
             if on_error is not None:
                 on_error()
-            raise RuntimeError("show-and-tell_amd: %s timed out waiting for its workgroups to be resident together (status %d: other "
-                               "work shares the device); the outputs of that call are invalid.  Later calls use the form without "
-                               "a device-wide wait" % (what, code))
+            raise RuntimeError("show-and-tell_amd: %s timed out waiting for its workgroups to be resident together (status 0x%x: other "
+                               "work shares the device); %s.  Later calls use the form without a device-wide wait"
+                               % (what, code & 0xffffffff, note or self.DEFAULT_NOTE))
         return True
 
     def poll(self, block=False):

@@ -199,3 +199,52 @@ def test_full_model_two_ranks_nccl_equals_oracle_per_shard(tmp_path):
     """the same check over RCCL (backend 'nccl'), one rank per GPU: bucketed async all-reduce on views of the flat
     gradient buffer, the loss slot riding in bucket 2, rank-local autotune"""
     _check_full(tmp_path, "nccl")
+
+
+def _bench(args, env_extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SAT_TUNE_FILE"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1200)
+def test_bench_py_gpus2_runs_its_real_multi_rank_branch_on_one_device():
+    """The driver's SCALE run is `bench.py --gpus N` on a node this build never sees: run the REAL N = 2 child tree here (spawned
+    ranks, process group, rank-0-first autotune, DataParallelStep with its bucket all-reduces and the look-ahead spread over two
+    streams, barrier + MAX-over-ranks timing, one JSON line) -- both ranks on the one device, transport gloo instead of RCCL
+    (SAT_BENCH_BACKEND / SAT_BENCH_SHARE_DEVICE; RCCL refuses two ranks on one device).  Everything but the transport is the
+    code the 8-GPU run executes (train.py:43-44's nn.DataParallel replaced by one process per GPU)."""
+    import math
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline"],
+                 {"SAT_BENCH_BACKEND": "gloo", "SAT_BENCH_SHARE_DEVICE": "1"})
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    cfg = out["config"]
+    assert cfg["global_batch"] == 128 and cfg["parallelism"] == "dp2" and cfg["backend"] == "gloo"
+    assert cfg["lookahead_depth"] == 3 and cfg["lookahead_streams"] == 2          # DataParallelStep.cap_lookahead took effect
+    assert "on 2 side streams" in cfg["schedule"]
+    assert math.isfinite(cfg["final_loss"]) and 8.5 < cfg["final_loss"] < 9.6      # ~ ln(10000) after three steps
+    assert out["value"] > 0 and abs(out["value"] - 128 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-2
+    assert out["scaling"] == "weak" and out["metric"].startswith("images/sec")
+    assert "f32_parity_mode" not in out and "cpu_baseline" not in out              # rank-0-only extras stay off at N > 1
+    assert 0 < out["roofline"]["frac"] < 1
+
+
+@pytest.mark.timeout(1200)
+def test_bench_py_decode_workload_shards_by_image_over_two_ranks():
+    """configs[4] at N = 2 on the one device: every rank decodes its own 64 images (no collective inside the decode), captions/sec
+    is the whole job's"""
+    out = _bench(["--gpus", "2", "--workload", "decode", "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline"],
+                 {"SAT_BENCH_BACKEND": "gloo", "SAT_BENCH_SHARE_DEVICE": "1"})
+    assert out["n_gpus"] == 2 and out["unit"] == "captions/sec" and out["config"]["global_batch"] == 128
+    assert out["config"]["beam_size"] == 5 and out["config"]["features_finite"] is True
+    assert out["config"]["ids_shape"] == [64, 20] and out["value"] > 0

@@ -1106,7 +1106,7 @@ def test_fixed_point_statistics_hold_for_small_magnitude_channels(lib):
 
 def test_persistent_lstm_timeout_is_reported_not_swallowed(lib, monkeypatch):
     """ADVICE r2 / VERDICT r2 (robustness 10): a spin timeout inside the persistent recurrence sets the workspace's status word;
-    `models.LstmWatch` reads it back behind the call and raises, and the process falls back to one launch per step.
+    `watch.ResidencyWatch` reads it back behind the call and raises, and the process falls back to one launch per step.
     SAT_LSTM_DEBUG_STALL=1 makes workgroup 0 withhold its hidden state, SAT_LSTM_SPIN_LIMIT shortens the wait (models.py:52)."""
     import importlib
     sat = importlib.import_module("show-and-tell_amd")
@@ -1116,7 +1116,7 @@ def test_persistent_lstm_timeout_is_reported_not_swallowed(lib, monkeypatch):
     feats = torch.randn(16, 32, device="cuda")
     caps = torch.randint(4, 100, (16, 9), device="cuda")
     lengths = [10] * 16
-    watch = M.LstmWatch.get(feats.device)
+    watch = sat.watch.ResidencyWatch.get(feats.device)
     with torch.no_grad():
         want = dec(feats, caps, lengths).clone()
         watch.poll(block=True)                                   # clean run: nothing raised
@@ -1137,6 +1137,62 @@ def test_persistent_lstm_timeout_is_reported_not_swallowed(lib, monkeypatch):
         again = dec(feats, caps, lengths).clone()                 # persistent again, clean
         watch.poll(block=True)
         assert torch.equal(again, want)
+
+
+@pytest.mark.parametrize("stall", ["1", "2"])
+def test_a_stalled_train_step_never_reaches_the_parameters(lib, monkeypatch, stall):
+    """ADVICE r3: a persistent LSTM launch that gives up (forward: SAT_LSTM_DEBUG_STALL=1, backward: =2) leaves garbage gradients;
+    `TrainStep` folds the status words into the step's fault flag ON THE DEVICE (sat_step_fault_flag) and clamp + Adam read it
+    (sat_clamp_adam_step_guarded): parameters, Adam moments and the step count must be bit for bit those before the faulted step
+    -- also for a step submitted after it and before the host has seen the flag -- the RuntimeError must say so, and training
+    continues with per-step launches.  train.py:144-146 / models.py:52"""
+    import importlib
+    sat = importlib.import_module("show-and-tell_amd")
+    torch.manual_seed(3)
+    model = sat.ShowAndTell(32, 64, 150, 1, arch=dict(layers=(1, 1, 1, 1), width=8), compute_dtype="f32").cuda().train()
+    ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+    g = torch.Generator().manual_seed(5)
+    B = 16
+    images = torch.randn(B, 3, 64, 64, generator=g).cuda()
+    caps = torch.randint(4, 150, (B, 10), generator=g).cuda()
+    caps[:, 0], caps[:, -1] = 1, 2
+    lengths = [10] * B
+    try:
+        ts.step(images, caps, lengths)
+        ts.step(images, caps, lengths)
+        ts.check_ids()                                           # two clean steps
+        before = [t.clone() for t in (ts.flat.params, ts.flat.m, ts.flat.v)]
+        count = ts.step_count
+        monkeypatch.setenv("SAT_LSTM_DEBUG_STALL", stall)
+        monkeypatch.setenv("SAT_LSTM_SPIN_LIMIT", "128")
+        fwd = ts.forward_backward((images, caps, lengths), 1.0 / (B * 9))        # the faulted step ...
+        ts.optimizer_step()
+        monkeypatch.delenv("SAT_LSTM_DEBUG_STALL")
+        monkeypatch.delenv("SAT_LSTM_SPIN_LIMIT")
+        del fwd
+        # ... and a clean one behind it, submitted without looking (forward_backward / optimizer_step do not block): sticky flag
+        ts.forward_backward((images, caps, lengths), 1.0 / (B * 9))
+        with pytest.raises(RuntimeError, match="SKIPPED on the device"):
+            ts.optimizer_step()
+            ts.check_ids()
+        torch.cuda.synchronize()
+        for a, b in zip(before, (ts.flat.params, ts.flat.m, ts.flat.v)):
+            assert torch.equal(a, b)                              # nothing of the faulted step (or the one behind it) got through
+        assert ts.step_count == count
+        assert lib.sat_lstm_persist_enable(0) == 0                # the process now runs one launch per step
+        ts.step(images, caps, lengths)                            # training goes on, updates flow again
+        ts.check_ids()
+        assert ts.step_count == count + 1 and not torch.equal(before[0], ts.flat.params)
+        # ... and equals the step a never-faulted engine takes from the same state (per-step launches on both sides)
+        torch.manual_seed(3)
+        model2 = sat.ShowAndTell(32, 64, 150, 1, arch=dict(layers=(1, 1, 1, 1), width=8), compute_dtype="f32").cuda().train()
+        ts2 = sat.TrainStep(model2, lr=1e-3, grad_clip=0.1)
+        for _ in range(3):
+            ts2.step(images, caps, lengths)
+        ts2.check_ids()
+        assert (ts2.flat.params - ts.flat.params).abs().max().item() < 1e-4      # persistent vs per-step recurrence: another summation order
+    finally:
+        lib.sat_lstm_persist_enable(1)
 
 
 @pytest.mark.parametrize("variant", [28, 29, 30])
@@ -1417,4 +1473,4 @@ def test_lstm_bwd_persistent_recurrence_equals_per_step_launches(lib, B, T, In, 
         monkeypatch.setenv("SAT_LSTM_DEBUG_STALL", "2")
         monkeypatch.setenv("SAT_LSTM_SPIN_LIMIT", "128")
         _, status = run(full)
-        assert status != 0                       # reported, not swallowed (models.LstmWatch raises on it)
+        assert status != 0                       # reported, not swallowed (watch.ResidencyWatch raises on it)
