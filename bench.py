@@ -103,16 +103,22 @@ def synth_batch(torch, B, V, T, H, device, seed):
     return images.to(device), caps.to(device), [T] * B
 
 
-def conv_in_sequence_us(torch, model, images, reps=3):
+def conv_in_sequence_us(torch, model, images, reps=3, groups=1):
     """Duration of every implicit-GEMM conv launch of the stack (the dominant kernel) measured IN SEQUENCE: the whole
     encoder program runs in order (BatchNorm kernels between the convs, as in the step) and each conv launch reports
     its own dispatch begin/end timestamps (HIP events attached to the launch on the stream it runs on) -- the same
     quantity rocprofv3 --kernel-trace lists per launch.  Returns (sum of conv durations per pass in ms, launches)."""
-    prog = model.encoder._program(images)
-    prog.run_timed(images)                                 # warm
+    if groups > 1:
+        # the program the timed steps really run: `groups` look-ahead batches per launch (EncoderCNN.prefetch_many); an instance of
+        # its own, so nothing of the model's running statistics moves (deferred updates that are never applied)
+        prog = model.encoder._program(images, instance="g_bench", groups=groups)
+        arg = [images] + [images.clone() for _ in range(groups - 1)]
+    else:
+        prog, arg = model.encoder._program(images), images
+    prog.run_timed(arg)                                    # warm
     tot, n = 0.0, 0
     for _ in range(reps):
-        _, us = prog.run_timed(images)
+        _, us = prog.run_timed(arg)
         tot += sum(us)
         n = len(us)
     return tot / reps * 1e-3, n
@@ -445,19 +451,26 @@ def attach_traffic(out):
         out["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % os.path.relpath(TRAFFIC_FILE, ROOT)
 
 
-def conv_roofline(torch, sat, model, images, wl, what):
-    conv_ms, n_conv = conv_in_sequence_us(torch, model, images)
+def conv_roofline(torch, sat, model, images, wl, what, groups=1):
+    """`groups` > 1: the grouped program of the look-ahead (every launch covers `groups` batches): algorithmic flops per launch
+    and launch durations are those of the launches the timed steps run"""
+    conv_ms, n_conv = conv_in_sequence_us(torch, model, images, groups=groups)
     if wl["arch"] == "inception_v3":
         conv_flops = 2.0 * INCEPTION_V3_CONV_MACS * wl["batch"]
     else:
         conv_flops = sat.conv_flops(sat.RESNET152, wl["image"], wl["image"]) * wl["batch"]
+    conv_flops *= groups
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "bf16 implicit-GEMM conv launches (%d per %s: conv_glds_kernel ring variants, conv_xp_kernel for the expansion 1x1 convs, conv_pr_kernel for the 3x3 convs; autotuned per geometry)" % (n_conv, what),
+    if groups > 1:
+        what = "pass of the grouped program = %d batches of %d images" % (groups, wl["batch"])
+    return {"bound": "mfma", "batches_per_launch": groups,
+            "kernel": "bf16 implicit-GEMM conv launches (%d per %s: conv_glds_kernel ring variants, conv_xp_kernel for the expansion 1x1 convs, conv_pr_kernel for the 3x3 convs; autotuned per geometry)" % (n_conv, what),
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "algorithmic_gflop_per_launch": round(conv_flops / n_conv / 1e9, 3),
             "avg_launch_us": round(conv_ms * 1e3 / n_conv, 2),
-            "algorithmic_gflop_per_step": round(conv_flops / 1e9, 1), "ms_per_step_in_kernel": round(conv_ms, 3),
+            "algorithmic_gflop_per_step": round(conv_flops / groups / 1e9, 1), "ms_per_step_in_kernel": round(conv_ms / groups, 3),
+            "ms_per_program_pass_in_kernel": round(conv_ms, 3),
             "how": "per-launch dispatch timestamps (HIP events attached to each conv launch), whole encoder program in sequence, mean of 3 passes"}
 
 
@@ -541,7 +554,8 @@ def main():
     # (EncoderCNN.prefetch).  Warm-up leaves nothing in flight, so the timed region holds exactly K conv-stack passes and K
     # decoder passes: pipeline fill (step 1's stack runs alone, on the main stream) and drain are inside it.
     depth = model.encoder.lookahead_depth
-    n_streams = model.encoder.lookahead_streams or depth
+    groups = model.encoder.lookahead_groups if not wl["arch"] else 1          # batches per grouped program run (ResNet stacks)
+    n_streams = model.encoder.lookahead_streams or max(1, depth // groups)
     nb = depth + 1
     batches = [images] + [synth_batch(torch, wl["batch"], wl["vocab"], wl["cap_len"], wl["image"], dev, 977 * (k + 1) + rank)[0]
                           for k in range(nb - 1)]
@@ -582,16 +596,22 @@ def main():
                        "precision": "conv stack bf16 MFMA / f32 accumulate; vocab projection + its gradients and the LSTM's batched GEMMs on the bf16 MFMA pipe from bf16 operand copies (f32 accumulate, f32 logits / outputs / master weights); LSTM recurrence, head, CE, Adam f32.  "
                                     "Stated CE tolerance of this mode against the f32 CPU oracle: %.0e (tests/test_gpu_parity_full.py; measured 6e-5 ... 8.5e-4); the 1e-4 bar of north_star is met by the f32 parity mode (`f32_parity_mode` below)" % BF16_CE_TOL,
                        "ce_tolerance_vs_f32_oracle": BF16_CE_TOL,
-                       "schedule": ("encoder look-ahead depth %d on %d side stream%s: the frozen conv stacks of batches i+1..i+%d run on side streams next to each other and under batch i's head/decoder/backward/Adam%s; "
+                       "schedule": ("encoder look-ahead depth %d on %d side stream%s: the frozen conv stacks of batches i+1..i+%d run on side streams next to each other and under batch i's head/decoder/backward/Adam%s%s; "
                                     "K conv passes + K decoder passes inside the timed region, fill and drain included"
                                     % (depth, n_streams, "" if n_streams == 1 else "s", depth,
-                                       " (the data-parallel step spreads them over fewer streams than stacks: the collective's stream needs a hardware queue, trainer.DataParallelStep.cap_lookahead)" if n_streams < depth else "")) if args.lookahead
+                                       (", %d batches per grouped program run (every launch of the stack covers %d batches, per-batch BatchNorm statistics: bit-identical per batch)" % (groups, groups)) if groups > 1 else "",
+                                       " (the data-parallel step spreads the runs over fewer streams: the collective's stream needs a hardware queue, trainer.DataParallelStep.cap_lookahead)" if n_streams < max(1, depth // groups) else "")) if args.lookahead
                                    else "strictly sequential steps",
                        "lookahead_depth": depth if args.lookahead else 0, "lookahead_streams": n_streams if args.lookahead else 0,
+                       "lookahead_groups": groups if args.lookahead else 0,
                        "backend": (backend if backend != "nccl" else "nccl (RCCL)") if use_dist else None,
                        "final_loss": round(final_loss, 4)},
-            "roofline": conv_roofline(torch, sat, model, images, wl, "step"),
+            "roofline": conv_roofline(torch, sat, model, images, wl, "step", groups if args.lookahead else 1),
         }
+        if groups > 1 and args.lookahead:
+            # the same figure for the ungrouped program (one batch per launch: what a strictly sequential step runs)
+            seq = conv_roofline(torch, sat, model, images, wl, "step", 1)
+            out["roofline"]["one_batch_per_launch"] = {k: seq[k] for k in ("achieved", "frac", "avg_launch_us", "ms_per_step_in_kernel")}
         if args.workload == "train":
             attach_traffic(out)
         else:

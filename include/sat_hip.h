@@ -63,16 +63,6 @@ enum {
     SAT_OP_MAXPOOL3S2 = 10,/* out = maxpool 3x3 / stride 2 / no padding of in0 (NHWC, Cout channels; ldc = output row pitch) */
     SAT_OP_AVGPOOL3 = 11,  /* out = avgpool 3x3 / stride 1 / pad 1, count_include_pad (divide by 9) of in0 (NHWC, Cout channels) */
     SAT_OP_MAXPOOL2 = 9,   /* out = maxpool 2x2 / stride 2 of in0 (NHWC; Hin, Win even; Cout channels): VGG16, model2.py:15-16 */
-    SAT_OP_CONV3_FUSED = 12,/* bf16, training: the expansion conv of an identity-residual bottleneck + its train-mode BatchNorm + residual
-                            * add + ReLU in ONE launch (sat_conv3_fused.hip): out = relu(bn3(conv1x1(relu(bn2(in0)))) + in1).
-                            * in0 = RAW conv2 output [M][Cin], w [Cout][Cin], in1 = block input [M][Cout], out [M][Cout];
-                            * stat_acc1 / gamma1 / beta1 / running_*1 = conv2's integer sums and bn2 (input side);
-                            * stat_acc / gamma / beta / running_* = this conv's sums and bn3 (output side); count, momentum, eps;
-                            * scale_out = uint32[2] sync words (zero before first use), shift_out = uint32 sticky error word
-                            * (non-zero: a grid-barrier wait ran out, the outputs of that run are INVALID -- read it back).
-                            * Accumulators stay in registers across a grid-wide statistics barrier, so every workgroup must be
-                            * resident: sat_conv3_fused_ok(M, Cout, Cin) tells whether the device can (Cin = 256, Cout % 512 == 0,
-                            * ceil(M/128) * Cout/512 <= CUs); the launch runs under the process-wide residency token. */
     SAT_OP_BN_EVAL_BATCH = 8 /* eval mode: in0 = DEVICE array of `count` sat_bn_eval_item; every item's (scale, shift)
                               * from its running statistics in ONE launch (replaces one BN_FINALIZE per layer); eps */
 };
@@ -140,43 +130,26 @@ typedef struct sat_op {
     const float* beta1;
     float* running_mean1;
     float* running_var1;
-    /* SAT_OP_CONV, bf16, training, dense 1x1: dual-source input.  out1 != NULL => the A operand is
-     * y = relu(in0*scale + shift + in1) -- the previous bottleneck's bn3 (scale0/shift0, or derived from stat_acc1 like
-     * the single-source input fusion), residual add (in1, shaped like in0) and ReLU, torchvision Bottleneck.forward under
-     * models.py:27 -- formed in LDS, and y is also stored to out1 (shaped like in0: the next block's residual).  Replaces
-     * the SAT_OP_BN_ADD_RELU launch between two bottlenecks. */
-    void* out1;
-    /* Sharded statistics accumulators: stat_acc is int64 [2 parities][stat_shards][2][C] (0 or 1 = unsharded, else a power of
-     * two <= 8).  A SAT_OP_CONV adds its tile's sums into shard (workgroup id % stat_shards) -- 8x less contention per word,
-     * so layers with up to ~1600 row tiles can use the integer atomics instead of per-tile slabs + a reducer launch -- and
-     * every consumer sums the shards when it derives (scale, shift) (integer sums: still order independent).  stat_shards1
-     * describes stat_acc1 the same way. */
-    int32_t stat_shards;
-    int32_t stat_shards1;
+    void* reserved_ptr;       /* (was out1: the dual-source conv input, removed in ABI 13 -- measured a loss) */
+    int32_t reserved1[2];     /* (were stat_shards / stat_shards1: sharded accumulators, removed in ABI 13 -- a measured wash) */
     /* SAT_OP_CONV extras for Inception-style stacks (BASELINE configs[3]): flags bit 1 (SAT_CONV_PADW) = the padding differs per
      * axis: `pad` is the vertical one, pad_w the horizontal one (1x7 / 7x1 / 1x3 / 3x1 kernels); ldc = row pitch of `out` in
      * elements (0 = Cout): a conv / activation may write its channels into a slice of a wider (concatenated) NHWC tensor.
      * SAT_OP_BN_RELU honours ldc the same way for its output. */
     int32_t pad_w;
-    int32_t reserved0;
+    /* GROUPED program (bf16, training): groups = G > 1 runs G independent BATCHES in every launch of the op (grid.y = group) --
+     * the frozen conv stack of G look-ahead batches as ONE program, half (1/G) the launch boundaries and twice (G x) the
+     * workgroups per launch.  N stays the batch of ONE group; every per-batch buffer is G consecutive copies of the ungrouped
+     * one: in0 / in1 / out [G][N][H][W][C] (out: G x N*Hout*Wout rows of pitch ldc), stat_partial [G][tiles_m][2][Cout],
+     * stat_acc / stat_acc1 [G][2 parities][2][C], running_mean / running_var of a DEFERRED program (sat_bn_running_apply)
+     * [G][2][C] (mean row, then variance row: running_var == running_mean + C).  Weights, gamma / beta are shared.  Each group
+     * keeps its own batch statistics and is, instruction for instruction, the ungrouped launch on its batch.  Honoured by
+     * SAT_OP_CONV, SAT_OP_BN_FINALIZE (acc mode), SAT_OP_BN_RELU, SAT_OP_BN_ADD_RELU, SAT_OP_BN_RELU_MAXPOOL; SAT_OP_IMAGE_PREP
+     * and SAT_OP_AVGPOOL are per image: give them N = G * batch.  0 / 1 = ungrouped. */
+    int32_t groups;
     int64_t ldc;
 } sat_op;
 #define SAT_CONV_PADW 2
-/* Two-pass conv with output-side BatchNorm (training, bf16; the expansion conv of a bottleneck, models.py:27):
- *   pass 1, flags | SAT_CONV_STATS_ONLY: the conv runs, its BatchNorm sums leave as usual (stat_acc / stat_partial), and NO
- *     output tile is written;
- *   pass 2, flags | SAT_CONV_OUT_BN: the same conv again; `stat_acc` is now READ (this step's parity) and gamma / beta /
- *     running_mean / running_var / count / momentum / eps describe the OUTPUT's BatchNorm: the epilogue derives (scale, shift)
- *     as SAT_OP_BN_ADD_RELU would, stores out = [relu (flags bit 0)](bf16(conv) * scale + shift [+ in1]) -- bit-identical to
- *     conv -> SAT_OP_BN_ADD_RELU -- updates the running statistics and clears the other parity.
- * The raw conv tensor never exists in memory: one write and one read of it, and the normalise + add launch, are traded for a
- * second pass over a short-K conv whose operands sit in the L2. */
-#define SAT_CONV_STATS_ONLY 4
-#define SAT_CONV_OUT_BN 8
-
-int sat_conv3_fused_ok(int64_t M, int Cout, int Cin);
-/* diagnostics: device buffer [grid][8] uint64 that later fused launches fill with per-workgroup phase time stamps (NULL: off) */
-int sat_conv3_fused_debug(void* stamps);   /* 1: SAT_OP_CONV3_FUSED can run this geometry on the current device */
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
 /* same, with the step parity (0/1) that selects the half of every stat_acc buffer in use */
 /* Deferred running statistics.  A program built with its sat_op running_mean / running_var pointers aimed at PRIVATE, zeroed
@@ -206,6 +179,12 @@ int sat_conv_tiles_m(int64_t M);
  * the tuner runs): like every other entry point, this one allocates no device memory. */
 int sat_conv_autotune(sat_op* ops /*[host]*/, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
                       sat_stream_t stream);
+/* What fixes the BITS of the BatchNorm column sums a kernel variant (sat_op.variant, 1-based) leaves: two variants with the
+ * same signature give bit-identical statistics (the conv output is bit-identical across the ring variants anyway).  The tuner
+ * picks a grouped op's variant among those of its ungrouped twin's signature, so that every batch of a grouped launch gets,
+ * bit for bit, what the ungrouped launch gives it; callers that load a saved tuning table can check the same.  -1: no such
+ * variant. */
+int sat_conv_variant_signature(int variant);
 /* Diagnostics, NOT the hot path (creates events, synchronises `stream`): run ops[0..n) once, in order, and return in
  * op_us[i] [host] the duration in microseconds of every bf16 SAT_OP_CONV launch taken from its own dispatch
  * timestamps (what rocprofv3 --kernel-trace reports for that launch); 0 for the other ops.  bench.py uses it for the
@@ -330,22 +309,13 @@ int sat_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, flo
                      int M, int N, int K, int ksplit, int64_t slab_stride, sat_stream_t stream);
 /* out bf16 [C][ldo] = in^T for in f32 [R][ldi]; columns [R, ldo) zero (ldo % 4 == 0) */
 int sat_transpose_f32_bf16(const float* in, int64_t ldi, int R, int C, void* out, int64_t ldo, sat_stream_t stream);
-/* FUSED vocab projection + cross entropy (models.py:53 + train.py:53,143): the projection GEMM's epilogue emits per-row
- * (max, sum exp) partials next to the logits, a small combine kernel turns them into lse[n] and row_loss[n] = lse - logit[target]
- * (it reads ONE logit per row), loss_out[0] = inv_denom * sum(row_loss).  The logits are written once and never re-read by
- * the loss.  Pad columns [V, ldl) are not written (zero-fill the buffer once when ldl > V, as for sat_vocab_logits_fwd). */
+/* Vocab projection + cross entropy (models.py:53 + train.py:53,143) as ONE call, exact f32: logits = Hs w^T + b, then
+ * row_loss[n] = logsumexp(logits[n]) - logits[n][targets[n]], loss_out[0] = inv_denom * sum(row_loss), and the logits are
+ * overwritten IN PLACE with d(loss)/d(logits) = (softmax - onehot) * inv_denom, ready for sat_vocab_ce_bwd (= sat_vocab_logits_fwd
+ * followed by sat_ce_rows with write_grad).  ldl >= V; pad columns [V, ldl) are left alone (zero-fill once when ldl > V). */
 int sat_vocab_ce_fwd(const float* Hs /*[N,H]*/, const float* w /*[V,H]*/, const float* b /*[V]*/, const int64_t* targets /*[N]*/,
-                     int N, int H, int V, float inv_denom, float* logits /*[N,ldl]*/, int64_t ldl, float* lse /*[N] out*/,
-                     float* row_loss /*[N]*/, float* loss_out /*[1] or NULL*/, float* workspace, int64_t ws_bytes, sat_stream_t stream);
-int64_t sat_vocab_ce_fwd_ws_bytes(int N, int V);
-/* ... and its backward (train.py:144) WITHOUT materialising d(loss)/d(logits): both gradient GEMMs form
- * (softmax - onehot) * inv_denom from the stored logits + lse + targets while loading their operand, and the weight-gradient
- * GEMM accumulates the bias gradient on the way: the logits make 1 write + 2 reads per step instead of 2 writes + 4 reads.
- * ldl % 4 == 0, pad columns hold anything (they are masked). */
-int sat_vocab_ce_bwd_fused(const float* logits, int64_t ldl, const float* lse, const int64_t* targets, float inv_denom,
-                           const float* Hs, const float* w, int N, int H, int V, float* dw /*[V,H]*/, float* db /*[V]*/,
-                           float* dHs /*[N,H]*/, float* workspace, int64_t ws_bytes, sat_stream_t stream);
-int64_t sat_vocab_ce_bwd_fused_ws_bytes(int N, int H, int V);
+                     int N, int H, int V, float inv_denom, float* logits /*[N,ldl]*/, int64_t ldl,
+                     float* row_loss /*[N]*/, float* loss_out /*[1]*/, sat_stream_t stream);
 /* backward of the projection given dlogits: dW[V,H], db[V], dHs[N,H] */
 int sat_vocab_ce_bwd(const float* dlogits /*[N,ldl]*/, int64_t ldl, const float* Hs, const float* w, int N, int H, int V,
                      float* dw, float* db, float* dHs, float* workspace, int64_t ws_bytes, sat_stream_t stream);

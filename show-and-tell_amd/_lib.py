@@ -16,9 +16,7 @@ OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_M
 OP_BN_EVAL_BATCH = 8
 OP_MAXPOOL2 = 9
 OP_MAXPOOL3S2, OP_AVGPOOL3 = 10, 11
-OP_CONV3_FUSED = 12
 CONV_PADW = 2
-CONV_STATS_ONLY, CONV_OUT_BN = 4, 8
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -51,9 +49,9 @@ class SatOp(C.Structure):
         ("momentum", C.c_float), ("eps", C.c_float),
         ("variant", C.c_int32), ("flags", C.c_int32),
         ("stat_acc", _vp), ("stat_acc1", _vp), ("gamma1", _vp), ("beta1", _vp),
-        ("running_mean1", _vp), ("running_var1", _vp), ("out1", _vp),
-        ("stat_shards", C.c_int32), ("stat_shards1", C.c_int32),
-        ("pad_w", C.c_int32), ("reserved0", C.c_int32), ("ldc", C.c_int64),
+        ("running_mean1", _vp), ("running_var1", _vp), ("reserved_ptr", _vp),
+        ("reserved1", C.c_int32 * 2),
+        ("pad_w", C.c_int32), ("groups", C.c_int32), ("ldc", C.c_int64),
     ]
 
 
@@ -69,8 +67,7 @@ SIGNATURES = {
     "sat_graph_destroy": (_i, [_vp]),
     "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
     "sat_conv_tiles_m": (_i, [_i64]),
-    "sat_conv3_fused_ok": (_i, [_i64, _i, _i]),
-    "sat_conv3_fused_debug": (_i, [_vp]),
+    "sat_conv_variant_signature": (_i, [_i]),
     "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp, _i64, _vp]),
     "sat_run_ops_timed": (_i, [C.POINTER(SatOp), _i, _i, _vp, C.POINTER(C.c_float)]),
     "sat_validate_ids": (_i, [_vp, _i64, _i, _i, _i64, _i64, _vp, _vp]),
@@ -95,10 +92,7 @@ SIGNATURES = {
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_vocab_logits_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "sat_ce_rows": (_i, [_vp, _i64, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
-    "sat_vocab_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "sat_vocab_ce_fwd_ws_bytes": (_i64, [_i, _i]),
-    "sat_vocab_ce_bwd_fused": (_i, [_vp, _i64, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "sat_vocab_ce_bwd_fused_ws_bytes": (_i64, [_i, _i, _i]),
+    "sat_vocab_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _vp]),
     "sat_vocab_bf16_ws_bytes": (_i64, [_i, _i, _i]),
     "sat_vocab_ce_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "sat_vocab_ce_bwd_bf16": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),

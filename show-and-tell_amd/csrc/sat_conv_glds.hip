@@ -47,14 +47,13 @@ struct ConvArgs {
     int linear;     // 1x1 / stride 1 / no padding on a dense NHWC tensor: output row m reads input pixel m
     // training-mode BatchNorm statistics, atomic form: fixed-point column sums (sum, sum of squares) added with 64-bit
     // INTEGER atomics into acc[2][N].  Integer addition is associative, so the totals are bitwise reproducible
-    // whatever the arrival order; the consumer kernel (bn_act / maxpool) turns them into scale/shift itself, which
-    // removes the separate finalize launch.  Used when there are few M-tiles (<= ~400 adds per word).
+    // whatever the arrival order; the consumer kernel (bn_act / maxpool / the next conv) turns them into scale/shift itself,
+    // which removes the separate finalize launch.  Used when there are few M-tiles (<= ~400 adds per word).
     long long* acc;
-    int acc_shards;          // acc is [acc_shards][2][N]: workgroup b adds into shard b % acc_shards
-    int in_shards;           // in_acc / in_acc_clear are [in_shards][2][Cin]: summed when the table is derived
-    // Input-side fusion (1x1 convs): the A operand is the RAW output of the previous conv and its BatchNorm + ReLU is
-    // applied to each landed LDS stage in place, so the normalised tensor never exists in HBM.  The (scale, shift)
-    // table comes precomputed (in_scale/in_shift) or is derived here from the previous conv's integer sums (in_acc).
+    // Input-side fusion: the A operand is the RAW output of the previous conv and its BatchNorm + ReLU is applied to the
+    // staged operand in LDS, so the normalised tensor never exists in HBM (1x1 convs: every landed stage of the ring kernel,
+    // the register panel of conv_xp_kernel; 3x3: the LDS-resident patch of conv_pr_kernel).  The (scale, shift) table comes
+    // precomputed (in_scale/in_shift) or is derived here from the previous conv's integer sums (in_acc).
     const float* in_scale;
     const float* in_shift;
     const long long* in_acc;      // [2][Cin], this step's parity
@@ -64,7 +63,7 @@ struct ConvArgs {
     float* in_running_mean;
     float* in_running_var;
     double in_count;
-    double in_inv;           // 1 / (2^22 * in_count) (conv_xp_kernel: the division happens on the host)
+    double in_inv;           // 1 / (2^22 * in_count) (conv_xp_kernel / conv_pr_kernel: the division happens on the host)
     float in_momentum, in_eps;
     int in_affine;
     // Output-side fusion (inference: BatchNorm is a fixed per-channel affine): out = [relu](acc*out_scale[n] +
@@ -73,30 +72,11 @@ struct ConvArgs {
     const float* out_shift;
     const bf16_t* residual;  // [M][ldc] like C, or NULL
     int out_relu;
-    // Output-side BatchNorm with BATCH statistics (training, second pass of a two-pass conv3: SAT_CONV_OUT_BN): the statistics
-    // of THIS conv's output were accumulated by an earlier stats-only launch of the same conv (SAT_CONV_STATS_ONLY) into
-    // out_acc; the epilogue derives (scale, shift) from them exactly as the normalise+add kernel would (bn_table_from_acc) and
-    // stores out = [relu](bf16(acc) * scale + shift [+ residual]) -- the raw conv tensor never exists in memory and the separate
-    // normalise + add + ReLU launch (one read of it, one read of the residual, one write) disappears.
-    const long long* out_acc;     // [shards][2][N], this step's parity, or NULL
-    long long* out_acc_clear;     // other parity (cleared by the tile_m == 0 workgroups) or NULL
-    int out_shards;
-    const float* out_gamma;
-    const float* out_beta;
-    float* out_running_mean;
-    float* out_running_var;
-    int stats_only;          // SAT_CONV_STATS_ONLY: the launch ends after the statistics (no output tile is staged or stored)
-    // Dual-source input (1x1 convs, training): the A operand is y = relu(A*in_scale + in_shift + R) -- the previous
-    // bottleneck's bn3 + residual add + ReLU (models.py:27, torchvision Bottleneck.forward's `out += identity; relu`)
-    // applied to each landed LDS stage from TWO LDS-DMA sources (A = raw conv3 output, R = the block input), so the
-    // separate normalise+add launch and its re-read disappear; the tile_n == 0 workgroups also store y (the next
-    // residual) to Y.  R, Y: [M][ldy] like A.
-    const bf16_t* R;
-    bf16_t* Y;
-    long ldy;
     int ct;                  // conv_xp_kernel: column tiles per workgroup
-    unsigned long long* stamps;   // conv_xp_kernel diagnostics: [workgroup][8] s_memtime stamps of lane 0, or NULL
-    int dbg;                 // diagnostics only (SAT_CONV_DBG): 1 = no loads, 2 = no MFMA, 4 = no epilogue, 8 = expansion (1x1, N = 4 Cin) convs store nothing
+    // GROUPED launch (sat_op.groups > 1, blockIdx.y = group): G independent batches with the SAME weights in one launch -- every
+    // per-batch pointer moves by its group stride (elements of its own type), nothing else changes: each group is the very
+    // instruction sequence of the ungrouped launch on its batch (same tiles, same summation order, own statistics)
+    long gs_a, gs_c, gs_partial, gs_acc, gs_in_acc, gs_in_run;
 };
 // fixed-point scale of the atomic statistics is SAT_STAT_SCALE (sat_internal.h)
 constexpr double kStatScale = SAT_STAT_SCALE;
@@ -135,45 +115,53 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // PF: consumers prefetch the first MFMA fragments of K-step kt+1 during the last MFMAs of K-step kt, so no LDS read
 // latency is exposed behind the per-K-step barrier; the loaders' counted wait then has to cover K-step kt+1 at
 // barrier kt (one in-flight K-step fewer than the ring could hold, hence S >= 4).
-// DUAL: two-source A operand (ConvArgs::R/Y); BM: tile rows (128; 64 for the wide dual tiles, whose A side is the
-// expensive one: two sources and an in-LDS pass, so it is kept short and the tile covers all of N instead).
-// XA: single-source input affine (BatchNorm + ReLU of the operand) in the PIPELINED form of the dual kernel -- the transform
-// of stage kt+1 is issued around the MFMAs of stage kt, one barrier per K-step -- and for ANY uniform geometry: on a 3x3
-// conv a per-row tap mask keeps the zero padding zero (relu(0*s+t) is not 0).
-template <int BN, int S, int NW, bool UNIFORM, bool SPEC = false, bool PF = false, int BM = 128, bool DUAL = false, bool XA = false>
-__global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
+// BM: tile rows (128 or 64).
+// grouped launches: group g = blockIdx.y works on its own batch -- per-batch pointers shifted by the group strides of ConvArgs
+__device__ __forceinline__ ConvArgs group_args(const ConvArgs& q) {
+    ConvArgs p = q;
+    const long g = blockIdx.y;
+    if (g) {
+        p.A += g * q.gs_a;
+        p.C += g * q.gs_c;
+        if (p.residual) p.residual += g * q.gs_c;
+        if (p.stat_partial) p.stat_partial += g * q.gs_partial;
+        if (p.acc) p.acc += g * q.gs_acc;
+        if (p.in_acc) p.in_acc += g * q.gs_in_acc;
+        if (p.in_acc_clear) p.in_acc_clear += g * q.gs_in_acc;
+        if (p.in_running_mean) { p.in_running_mean += g * q.gs_in_run; p.in_running_var += g * q.gs_in_run; }
+    }
+    return p;
+}
+
+template <int BN, int S, int NW, bool UNIFORM, bool SPEC = false, bool PF = false, int BM = 128>
+__global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p_) {
+    const ConvArgs p = group_args(p_);
     constexpr int BK = 64, NT = NW * 64;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES + (DUAL ? A_BYTES : 0);
-    constexpr int R_OFF = A_BYTES + B_BYTES;               // DUAL: the residual source's half of a stage
-    // DUAL: waves 0..NW/2-1 issue ALL the LDS-DMA and own the counted vmcnt; waves NW/2.. issue the global stores of y --
-    // a wave's memory counter is in order, so a store acknowledgement (~1-2 us under load) must never sit in front of the
-    // prefetch a wave is waiting for.  Every wave transforms and computes.
-    constexpr int LW = (SPEC || DUAL) ? NW / 2 : NW;      // waves that issue the LDS-DMA
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int LW = SPEC ? NW / 2 : NW;                // waves that issue the LDS-DMA
     constexpr int CW = SPEC ? NW / 2 : NW;                // waves that own accumulators
     // consumer wave grid: 4 waves: 2x2;  8 waves: 4(M)x2(N) for the 128x64 tile, 2(M)x4(N) otherwise
     constexpr int WGM = (CW == 4) ? 2 : ((BM == 128 && BN == 64) ? 4 : 2);
     constexpr int WGN = CW / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int NAI = BM / 8 / LW, NBI = BN / 8 / LW;   // LDS-DMA pieces (8 rows x 128 B) per loader wave per stage
-    constexpr int LPW = NAI + NBI + (DUAL ? NAI : 0);
-    static_assert(!DUAL || (UNIFORM && !SPEC && !PF), "the dual-source transform lives in the plain unified-wave loop");
-    static_assert(!XA || (UNIFORM && !SPEC && !PF && !DUAL && S >= 3), "pipelined input affine: unified waves, a landed stage ahead");
+    constexpr int LPW = NAI + NBI;
     constexpr int D = S - 1;                               // K-steps kept in flight
     constexpr int WAITN = LPW * (PF ? D - 2 : D - 1);      // loader pieces that may still be in flight at a barrier
     static_assert(!PF || S >= 4, "fragment prefetch needs one more landed stage");
     constexpr int CROW = BN * 2 + 16;                      // bf16 C-tile row stride in LDS (epilogue)
     static_assert(BM * CROW + 4 * WGM * BN * 4 <= S * STAGE, "epilogue tile + stat scratch must fit the ring");
     static_assert(TM >= 1 && TN >= 1 && NAI >= 1 && NBI >= 1, "bad tile/wave split");
-    constexpr int TAB_BYTES = 2 * (DUAL ? 2048 : 512) * 4;  // input-BN (scale, shift) table: up to 512 (2048) input channels
+    constexpr int TAB_BYTES = 2 * 512 * 4;                 // input-BN (scale, shift) table: up to 512 input channels
     __shared__ __attribute__((aligned(16))) char smem[S * STAGE + TAB_BYTES];   // ONE LDS object (ring + table)
     float* in_tab = (float*)(smem + S * STAGE);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_loader = SPEC ? (wave >= CW) : (DUAL ? wave < LW : true);
+    const bool is_loader = SPEC ? (wave >= CW) : true;
     const bool is_consumer = SPEC ? (wave < CW) : true;
-    const int lw = SPEC ? (is_loader ? wave - CW : 0) : (DUAL ? (is_loader ? wave : 0) : wave);      // loader index
+    const int lw = SPEC ? (is_loader ? wave - CW : 0) : wave;      // loader index
     const int cw = is_consumer ? wave : 0;                          // consumer index
     const int wm = cw / WGN, wn = cw % WGN;
     const int r = lane & 31, h = lane >> 5;
@@ -233,13 +221,6 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         b_ptr[i] = b_ok[i] ? p.B + ((long)gn * p.ldb + b_c[i]) : zero;
     }
     const int nk = (p.K + BK - 1) / BK;
-    // DUAL: the residual source walks K exactly like A (same rows, same chunk swizzle)
-    const bf16_t* r_ptr[NAI];
-#pragma unroll
-    for (int i = 0; i < NAI; ++i) {
-        const int grow = m0 + lw * (NAI * 8) + i * 8 + (lane >> 3);
-        r_ptr[i] = (DUAL && grow < p.M) ? p.R + ((long)grow * p.ldy + a_c[i]) : zero;
-    }
     // linear (1x1) walk: per-lane pointers advance by one K-step; invalid rows stay on the zero word
     int a_step[NAI], b_step[NBI];
     const bf16_t* b_walk[NBI];
@@ -252,7 +233,6 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     int is_kt = 0, is_tap = 0, is_cb = 0, is_kh = 0, is_kw = 0;
 
     auto issue = [&](int buf) {
-        if (p.dbg & 1) { ++is_kt; return; }
         char* sA = smem + buf * STAGE;
         char* sB = sA + A_BYTES;
         const int kt = is_kt;
@@ -265,11 +245,6 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int i = 0; i < NBI; ++i)
                     __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sB + (lw * (NBI * 8) + i * 8) * 128), 16, 0, 0);
-                if constexpr (DUAL) {
-#pragma unroll
-                    for (int i = 0; i < NAI; ++i)
-                        __builtin_amdgcn_global_load_lds((gptr_t)zero, (lptr_t)(sA + R_OFF + (lw * (NAI * 8) + i * 8) * 128), 16, 0, 0);
-                }
                 ++is_kt;
                 return;
             }
@@ -285,13 +260,6 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 for (int i = 0; i < NBI; ++i) {
                     __builtin_amdgcn_global_load_lds((gptr_t)b_walk[i], (lptr_t)(sB + (lw * (NBI * 8) + i * 8) * 128), 16, 0, 0);
                     b_walk[i] += b_step[i];
-                }
-                if constexpr (DUAL) {
-#pragma unroll
-                    for (int i = 0; i < NAI; ++i) {
-                        __builtin_amdgcn_global_load_lds((gptr_t)r_ptr[i], (lptr_t)(sA + R_OFF + (lw * (NAI * 8) + i * 8) * 128), 16, 0, 0);
-                        r_ptr[i] += a_step[i];
-                    }
                 }
                 ++is_kt;
                 return;
@@ -367,11 +335,7 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         for (int c = tid; c < p.Cin; c += NT) {
             float sc, sh;
             if (p.in_acc) {
-                long long s1 = 0, s2 = 0;
-                for (int sh = 0; sh < p.in_shards; ++sh) {           // integer sums: any order gives the same total
-                    s1 += p.in_acc[(long)sh * 2 * p.Cin + c];
-                    s2 += p.in_acc[(long)sh * 2 * p.Cin + p.Cin + c];
-                }
+                const long long s1 = p.in_acc[c], s2 = p.in_acc[p.Cin + c];
                 const double mean = (double)s1 * inv;
                 double var = (double)s2 * inv - mean * mean;
                 if (var < 0.0) var = 0.0;
@@ -385,11 +349,10 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                         p.in_running_mean[c] = (float)((1.0 - p.in_momentum) * p.in_running_mean[c] + p.in_momentum * (double)(float)mean);
                         p.in_running_var[c] = (float)((1.0 - p.in_momentum) * p.in_running_var[c] + p.in_momentum * (double)(float)unbiased);
                     }
-                    if (p.in_acc_clear)
-                        for (int sh = 0; sh < p.in_shards; ++sh) {
-                            p.in_acc_clear[(long)sh * 2 * p.Cin + c] = 0;
-                            p.in_acc_clear[(long)sh * 2 * p.Cin + p.Cin + c] = 0;
-                        }
+                    if (p.in_acc_clear) {
+                        p.in_acc_clear[c] = 0;
+                        p.in_acc_clear[p.Cin + c] = 0;
+                    }
                 }
             } else {
                 sc = p.in_scale[c];
@@ -413,20 +376,10 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                 bf16x8 v = *(const bf16x8*)(sA + row * 128 + pos * 16);
                 const f32x4 s0 = *(const f32x4*)(in_tab + c0), s1 = *(const f32x4*)(in_tab + c0 + 4);
                 const f32x4 t0 = *(const f32x4*)(in_tab + p.Cin + c0), t1 = *(const f32x4*)(in_tab + p.Cin + c0 + 4);
-                if constexpr (DUAL) {
-                    const bf16x8 z = *(const bf16x8*)(sA + R_OFF + row * 128 + pos * 16);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e] + (float)z[e], 0.0f);
-                        v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e] + (float)z[e + 4], 0.0f);
-                    }
-                    if (tile_n == 0) *(bf16x8*)(p.Y + (long)(m0 + row) * p.ldy + c0) = v;     // the next block's residual
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e], 0.0f);
-                        v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e], 0.0f);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e], 0.0f);
+                    v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e], 0.0f);
                 }
                 *(bf16x8*)(sA + row * 128 + pos * 16) = v;
             }
@@ -434,92 +387,6 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes are done ...
         __builtin_amdgcn_s_barrier();                         // ... and everybody's (raw barrier: the ring stays in flight)
         asm volatile("" ::: "memory");
-    };
-
-    // DUAL, software pipelined: the transform of stage kt+1 is split around the MFMAs of stage kt -- its LDS reads go out
-    // first, the arithmetic / LDS write / global store of y follow the matrix work -- so the only per-K-step barrier is
-    // the ring's own and a wave's VALU pass overlaps its SIMD partner's MFMAs
-    constexpr int NCH = (DUAL || XA) ? BM * 8 / NT : 1;
-    bf16x8 dv[NCH], dz[NCH];
-    unsigned t_mask[NCH];                 // XA: bit t = tap t of this thread's row j is inside the image
-    if constexpr (XA) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int grow = m0 + ((tid + j * NT) >> 3);
-            t_mask[j] = 0u;
-            if (grow < p.M) {
-                if (p.linear) {
-                    t_mask[j] = 1u;
-                } else {
-                    const int hw = p.Hout * p.Wout;
-                    const int n = grow / hw;
-                    const int rem = grow - n * hw;
-                    const int ho = rem / p.Wout;
-                    const int wo = rem - ho * p.Wout;
-                    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.padw;
-                    for (int kh = 0; kh < p.KH; ++kh)
-                        for (int kw = 0; kw < p.KW; ++kw) {
-                            const bool in = ((unsigned)(hi0 + kh) < (unsigned)p.Hin) && ((unsigned)(wi0 + kw) < (unsigned)p.Win);
-                            t_mask[j] |= (in ? 1u : 0u) << (kh * p.KW + kw);
-                        }
-                }
-            }
-        }
-    }
-    auto dual_load = [&](int buf) {
-        const char* sA = smem + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int q = tid + j * NT;
-            const int row = q >> 3, pos = q & 7;
-            dv[j] = *(const bf16x8*)(sA + row * 128 + pos * 16);
-            if constexpr (DUAL) dz[j] = *(const bf16x8*)(sA + R_OFF + row * 128 + pos * 16);
-        }
-    };
-    // cbase: first input channel of the stage (DUAL / 1x1: kt * 64; 3x3: the tap's channel block); tap: the stage's filter tap
-    auto dual_finish = [&](int buf, int cbase, int tap) {
-        char* sA = smem + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int q = tid + j * NT;
-            const int row = q >> 3, pos = q & 7;
-            bool live = m0 + row < p.M;
-            if constexpr (XA) live = ((t_mask[j] >> tap) & 1u) != 0u;       // padded taps (and rows past M) stay exact zeros
-            if (live) {
-                const int c0 = cbase + ((pos ^ ((row >> 1) & 7)) << 3);
-                const f32x4 s0 = *(const f32x4*)(in_tab + c0), s1 = *(const f32x4*)(in_tab + c0 + 4);
-                const f32x4 t0 = *(const f32x4*)(in_tab + p.Cin + c0), t1 = *(const f32x4*)(in_tab + p.Cin + c0 + 4);
-                bf16x8 v = dv[j];
-                if constexpr (DUAL) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e] + (float)dz[j][e], 0.0f);
-                        v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e] + (float)dz[j][e + 4], 0.0f);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = (bf16_t)fmaxf((float)v[e] * s0[e] + t0[e], 0.0f);
-                        v[e + 4] = (bf16_t)fmaxf((float)v[e + 4] * s1[e] + t1[e], 0.0f);
-                    }
-                }
-                *(bf16x8*)(sA + row * 128 + pos * 16) = v;
-            }
-        }
-    };
-    // y (the next block's residual) leaves through the store waves: they re-read the finished A half of the stage
-    auto dual_store_y = [&](int buf, int kt) {
-        const char* sA = smem + buf * STAGE;
-        constexpr int NSW = DUAL ? NT - LW * 64 : NT;      // threads in the store waves
-#pragma unroll
-        for (int j = 0; j < BM * 8 / NSW; ++j) {
-            const int q = (tid - LW * 64) + j * NSW;
-            const int row = q >> 3, pos = q & 7;
-            if (m0 + row < p.M) {
-                const int c0 = kt * BK + ((pos ^ ((row >> 1) & 7)) << 3);
-                *(u32x4*)(p.Y + (long)(m0 + row) * p.ldy + c0) = *(const u32x4*)(sA + row * 128 + pos * 16);
-            }
-        }
     };
 
     auto compute = [&](int buf) {
@@ -593,50 +460,10 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             for (int kt = 0; kt < nk; ++kt) {
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");        // no LDS read may be hoisted above the barrier
-                if (!(p.dbg & 2)) {
-                    if constexpr (PF) compute_pf(buf, kt == 0);
-                    else compute(buf);
-                }
+                if constexpr (PF) compute_pf(buf, kt == 0);
+                else compute(buf);
                 buf = (buf + 1 == S) ? 0 : buf + 1;
             }
-        }
-    } else if constexpr (DUAL || XA) {
-        static_assert(S >= 3, "the pipelined transform needs a landed stage ahead of the one being computed");
-        // channel block / tap of the stage being transformed (scalar walk, like the loader's)
-        int xf_cb = 0, xf_tap = 0;
-        auto xf_next = [&]() {
-            xf_cb += BK;
-            if (!p.linear && xf_cb >= p.Cin) { xf_cb = 0; ++xf_tap; }
-        };
-        constexpr int WAITD = LPW * (D - 2);     // pieces that may still be in flight once stage kt+1 must have landed
-        if (is_loader) {
-#pragma unroll
-            for (int s = 0; s < D; ++s) issue(s);
-            wait_vmcnt<LPW*(D - 1)>();           // stage 0 (mine) ...
-        }
-        __builtin_amdgcn_s_barrier();            // ... and everybody's
-        asm volatile("" ::: "memory");
-        dual_load(0);
-        dual_finish(0, xf_cb, xf_tap);
-        xf_next();
-        int buf = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my transform writes of stage kt (and LDS reads) are done
-            if (is_loader) wait_vmcnt<WAITD>();                    // my pieces of stage kt+1 have landed
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            int nbuf = buf + D;
-            if (nbuf >= S) nbuf -= S;
-            if (is_loader) issue(nbuf);                            // stage kt+D -> the slot stage kt-1 occupied
-            const int tbuf = (buf + 1 == S) ? 0 : buf + 1;
-            const bool more = kt + 1 < nk;
-            if (more) dual_load(tbuf);
-            if constexpr (DUAL) {
-                if (!is_loader && tile_n == 0) dual_store_y(buf, kt);  // stage kt is final: y goes out under the MFMAs
-            }
-            if (!(p.dbg & 2)) compute(buf);
-            if (more) { dual_finish(tbuf, xf_cb, xf_tap); xf_next(); }
-            buf = tbuf;
         }
     } else {
 #pragma unroll
@@ -650,10 +477,10 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
             if (nbuf >= S) nbuf -= S;
             issue(nbuf);
             if constexpr (PF) {
-                if (!(p.dbg & 2)) compute_pf(buf, kt == 0);
+                compute_pf(buf, kt == 0);
             } else {
                 if (p.in_affine) affine_stage(buf, kt);
-                if (!(p.dbg & 2)) compute(buf);
+                compute(buf);
             }
             buf = (buf + 1 == S) ? 0 : buf + 1;
         }
@@ -661,7 +488,6 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     // drain the dummy prefetches and let every wave finish its last reads before the ring is reused
     wait_vmcnt<0>();
     __syncthreads();
-    if (p.dbg & 4) return;                       // diagnostics: no epilogue
 
     // ---- epilogue 1: BatchNorm partial column sums from the f32 accumulators ----
     float* red = (float*)(smem + BM * CROW);     // [WGM][2][BN] floats, placed after the C tile
@@ -697,64 +523,8 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
                     s += red[(g * 2 + 0) * BN + c];
                     q += red[(g * 2 + 1) * BN + c];
                 }
-                long long* dst = p.acc + (long)(bid & (p.acc_shards - 1)) * 2 * p.N;
-                atomicAdd((unsigned long long*)(dst + col), (unsigned long long)__double2ll_rn((double)s * kStatScale));
-                atomicAdd((unsigned long long*)(dst + p.N + col), (unsigned long long)__double2ll_rn((double)q * kStatScale));
-            }
-        }
-    }
-    if (p.stats_only) {      // first pass of a two-pass conv: the statistics are all this launch produces
-        if (p.stat_partial) {
-            __syncthreads();
-            for (int c = tid; c < BN; c += NT) {
-                const int col = n0 + c;
-                if (col < p.N) {
-                    float s = 0.0f, q = 0.0f;
-#pragma unroll
-                    for (int g = 0; g < WGM; ++g) {
-                        s += red[(g * 2 + 0) * BN + c];
-                        q += red[(g * 2 + 1) * BN + c];
-                    }
-                    p.stat_partial[((long)tile_m * 2 + 0) * p.N + col] = s;
-                    p.stat_partial[((long)tile_m * 2 + 1) * p.N + col] = q;
-                }
-            }
-        }
-        return;
-    }
-    // second pass of a two-pass conv: (scale, shift) of the OUTPUT's BatchNorm from the integer sums the first pass left --
-    // the arithmetic of bn_table_from_acc, one lane per column; table in LDS behind the C tile (no statistics leave this launch)
-    const bool out_bn = p.out_acc != nullptr;
-    if (out_bn && is_consumer && wm == 0 && h == 0) {
-        const double inv = 1.0 / (kStatScale * p.in_count);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int lc = wn * WN + j * 32 + r, col = n0 + lc;
-            if (col < p.N) {
-                long long s1 = 0, s2 = 0;
-                for (int sh = 0; sh < p.out_shards; ++sh) {
-                    s1 += p.out_acc[(long)sh * 2 * p.N + col];
-                    s2 += p.out_acc[(long)sh * 2 * p.N + p.N + col];
-                }
-                const double mean = (double)s1 * inv;
-                double var = (double)s2 * inv - mean * mean;
-                if (var < 0.0) var = 0.0;
-                const float invstd = 1.0f / sqrtf((float)var + p.in_eps);
-                const float sc = p.out_gamma[col] * invstd;
-                red[lc] = sc;
-                red[BN + lc] = p.out_beta[col] - (float)mean * sc;
-                if (tile_m == 0) {
-                    if (p.out_running_mean) {
-                        const double unbiased = p.in_count > 1.0 ? var * p.in_count / (p.in_count - 1.0) : var;
-                        p.out_running_mean[col] = (float)((1.0 - p.in_momentum) * p.out_running_mean[col] + p.in_momentum * (double)(float)mean);
-                        p.out_running_var[col] = (float)((1.0 - p.in_momentum) * p.out_running_var[col] + p.in_momentum * (double)(float)unbiased);
-                    }
-                    if (p.out_acc_clear)
-                        for (int sh = 0; sh < p.out_shards; ++sh) {
-                            p.out_acc_clear[(long)sh * 2 * p.N + col] = 0;
-                            p.out_acc_clear[(long)sh * 2 * p.N + p.N + col] = 0;
-                        }
-                }
+                atomicAdd((unsigned long long*)(p.acc + col), (unsigned long long)__double2ll_rn((double)s * kStatScale));
+                atomicAdd((unsigned long long*)(p.acc + p.N + col), (unsigned long long)__double2ll_rn((double)q * kStatScale));
             }
         }
     }
@@ -794,32 +564,13 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
         }
     }
     constexpr int CPR = BN / 8;                  // 16-byte chunks per C row
-    if ((p.dbg & 8) && p.KH == 1 && p.N == 4 * p.Cin) return;      // diagnostics: what a bottleneck would cost without its raw conv3 tensor
 #pragma unroll
     for (int it = 0; it < BM * CPR / NT; ++it) {
         const int qid = tid + it * NT;
         const int row = qid / CPR, cc = qid - row * CPR;
         const int grow = m0 + row, gcol = n0 + cc * 8;
         if (grow < p.M && gcol < p.N) {           // N % 8 == 0: a chunk is all in or all out
-            if (out_bn) {
-                // the normalise (+ add) + ReLU kernel's arithmetic on the bf16-rounded conv output, from LDS: bit-identical to
-                // conv -> store -> bn_act_kernel (x * scale + shift + z, ReLU, one rounding)
-                const bf16x8 c = *(const bf16x8*)(smem + row * CROW + cc * 16);
-                const f32x4 s0 = *(const f32x4*)(red + cc * 8), s1 = *(const f32x4*)(red + cc * 8 + 4);
-                const f32x4 t0 = *(const f32x4*)(red + BN + cc * 8), t1 = *(const f32x4*)(red + BN + cc * 8 + 4);
-                bf16x8 z;
-                if (p.residual) z = *(const bf16x8*)(p.residual + (long)grow * p.ldc + gcol);
-                bf16x8 o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v0 = (float)c[k] * s0[k] + t0[k], v1 = (float)c[k + 4] * s1[k] + t1[k];
-                    if (p.residual) { v0 += (float)z[k]; v1 += (float)z[k + 4]; }
-                    if (p.out_relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
-                    o[k] = (bf16_t)v0;
-                    o[k + 4] = (bf16_t)v1;
-                }
-                store16_wt(p.C + (long)grow * p.ldc + gcol, *(const u32x4*)&o);
-            } else if (p.residual) {              // out = [relu](affine(acc) + residual), 16 bytes of each per thread
+            if (p.residual) {                     // out = [relu](affine(acc) + residual), 16 bytes of each per thread
                 const bf16x8 c = *(const bf16x8*)(smem + row * CROW + cc * 16);
                 const bf16x8 z = *(const bf16x8*)(p.residual + (long)grow * p.ldc + gcol);
                 bf16x8 o;
@@ -837,19 +588,15 @@ __global__ __launch_bounds__(NW * 64) void conv_glds_kernel(const ConvArgs p) {
     }
 }
 
-template <int BN, int S, int NW, bool SPEC = false, bool PF = false, int BM = 128, bool DUAL = false, bool XA = false>
-int launch_glds(ConvArgs& a, hipStream_t s) {
+template <int BN, int S, int NW, bool SPEC = false, bool PF = false, int BM = 128>
+int launch_glds(ConvArgs& a, int groups, hipStream_t s) {
     const int tm = sat_cdiv(a.M, BM), tn = sat_cdiv(a.N, BN);
     a.tiles_n = tn;
     const bool uniform = (a.Cin % 64 == 0) && (a.KH * a.KW <= 32);
-    const dim3 grid(tm * tn), block(NW * 64);
+    const dim3 grid(tm * tn, groups), block(NW * 64);
     hipEvent_t e0 = t_ev_start, e1 = t_ev_stop;     // armed: timed diagnostic launch (same kernel, same grid, + the packet's timestamps)
     t_ev_start = t_ev_stop = nullptr;
-    if constexpr (DUAL || XA) {
-        if (!uniform) return SAT_ERR_UNSUPPORTED;
-        if (e0) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM, DUAL, XA>), grid, block, 0, s, e0, e1, 0, a);
-        else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM, DUAL, XA>), grid, block, 0, s, a);
-    } else if (uniform) {
+    if (uniform) {
         if (e0) hipExtLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((conv_glds_kernel<BN, S, NW, true, SPEC, PF, BM>), grid, block, 0, s, a);
     } else {
@@ -860,84 +607,73 @@ int launch_glds(ConvArgs& a, hipStream_t s) {
     return SAT_OK;
 }
 
-int tune_env(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
-// kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows, dual-source A).
-// LDS = S * (BM/8 + BN/8 [+ BM/8]) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, dual, xa, xp, pr, du; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; du: conv_du_kernel
+// kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows).
+// LDS = S * (BM/8 + BN/8) KB (+ the table) decides workgroups per CU.
+struct Variant { int bn, s, nw, spec, pf, bm, xp, pr; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel
 constexpr Variant kVariants[] = {
-    {128, 4, 8, 0, 0, 128, 0}, {128, 3, 8, 0, 0, 128, 0}, {128, 2, 8, 0, 0, 128, 0}, {64, 4, 8, 0, 0, 128, 0}, {64, 3, 8, 0, 0, 128, 0},
-    {64, 2, 8, 0, 0, 128, 0}, {128, 4, 4, 0, 0, 128, 0}, {128, 2, 4, 0, 0, 128, 0}, {64, 3, 4, 0, 0, 128, 0}, {64, 2, 4, 0, 0, 128, 0},
-    {128, 4, 8, 1, 0, 128, 0}, {128, 3, 8, 1, 0, 128, 0}, {128, 2, 8, 1, 0, 128, 0}, {64, 4, 8, 1, 0, 128, 0}, {64, 3, 8, 1, 0, 128, 0},   // 4 consumer + 4 loader waves
-    {128, 4, 8, 1, 1, 128, 0}, {128, 4, 8, 0, 1, 128, 0}, {128, 4, 4, 0, 1, 128, 0}, {64, 4, 8, 1, 1, 128, 0}, {64, 4, 8, 0, 1, 128, 0},
-    {64, 4, 4, 0, 1, 128, 0},                                                                                                       // fragment prefetch
-    {256, 3, 8, 0, 0, 64, 1}, {256, 3, 8, 0, 0, 64, 1}, {128, 3, 8, 0, 0, 128, 1}, {128, 3, 8, 0, 0, 128, 1}, {128, 3, 8, 0, 0, 64, 1},
-    {128, 4, 8, 0, 0, 64, 1},                                                                                                       // dual-source A (bn3 + add + ReLU of the previous block)
-    {256, 2, 8, 0, 0, 128, 0}, {256, 3, 8, 0, 0, 128, 0}, {256, 3, 8, 0, 0, 64, 0},                                                   // wide tiles
-    {128, 3, 8, 0, 0, 64, 0}, {128, 2, 8, 0, 0, 64, 0},                                                                             // 64-row tiles: 2 workgroups per CU on the N = 256 layers
-    {128, 3, 8, 0, 0, 128, 0, 1}, {128, 4, 8, 0, 0, 128, 0, 1}, {64, 3, 8, 0, 0, 128, 0, 1}, {64, 4, 8, 0, 0, 128, 0, 1},
-    {128, 3, 8, 0, 0, 64, 0, 1}, {128, 4, 8, 0, 0, 64, 0, 1}, {256, 3, 8, 0, 0, 128, 0, 1},                                          // pipelined input affine (any uniform geometry)
-    {128, 5, 4, 0, 0, 128, 0, 0, 1}, {128, 5, 4, 0, 0, 128, 0, 0, 2}, {128, 5, 4, 0, 0, 128, 0, 0, 4},                               // register-resident A panel (expansion 1x1 convs, sat_conv_xp.inc)
-    {128, 6, 8, 1, 0, 128, 0, 0, 0, 1},                                                                                             // LDS-resident input patch (3x3 / stride 1, sat_conv_pr.inc)
-    {256, 6, 8, 1, 0, 64, 1, 0, 0, 0, 1},                                                                                           // dual-source 1x1 reduction, loader-side transform (sat_conv_du.inc)
+    {128, 4, 8, 0, 0, 128}, {128, 3, 8, 0, 0, 128}, {128, 2, 8, 0, 0, 128}, {64, 4, 8, 0, 0, 128}, {64, 3, 8, 0, 0, 128},
+    {64, 2, 8, 0, 0, 128}, {128, 4, 4, 0, 0, 128}, {128, 2, 4, 0, 0, 128}, {64, 3, 4, 0, 0, 128}, {64, 2, 4, 0, 0, 128},
+    {128, 4, 8, 1, 0, 128}, {128, 3, 8, 1, 0, 128}, {128, 2, 8, 1, 0, 128}, {64, 4, 8, 1, 0, 128}, {64, 3, 8, 1, 0, 128},   // 4 consumer + 4 loader waves
+    {128, 4, 8, 1, 1, 128}, {128, 4, 8, 0, 1, 128}, {128, 4, 4, 0, 1, 128}, {64, 4, 8, 1, 1, 128}, {64, 4, 8, 0, 1, 128},
+    {64, 4, 4, 0, 1, 128},                                                                                               // fragment prefetch
+    {256, 2, 8, 0, 0, 128}, {256, 3, 8, 0, 0, 128}, {256, 3, 8, 0, 0, 64},                                               // wide tiles
+    {128, 3, 8, 0, 0, 64}, {128, 2, 8, 0, 0, 64},                                                                        // 64-row tiles: 2 workgroups per CU on the N = 256 layers
+    {128, 5, 4, 0, 0, 128, 1}, {128, 5, 4, 0, 0, 128, 2}, {128, 5, 4, 0, 0, 128, 4},                                     // register-resident A panel (expansion 1x1 convs, sat_conv_xp.inc)
+    {128, 6, 8, 1, 0, 128, 0, 1},                                                                                        // LDS-resident input patch (3x3 / stride 1, sat_conv_pr.inc)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+constexpr int kVariantPr = 29;
 
 #include "sat_conv_xp.inc"
 #include "sat_conv_pr.inc"
-#include "sat_conv_du.inc"
 
-int launch_variant(int v, ConvArgs& a, hipStream_t s) {
+int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
     switch (v) {
-        case 0: return launch_glds<128, 4, 8>(a, s);
-        case 1: return launch_glds<128, 3, 8>(a, s);
-        case 2: return launch_glds<128, 2, 8>(a, s);
-        case 3: return launch_glds<64, 4, 8>(a, s);
-        case 4: return launch_glds<64, 3, 8>(a, s);
-        case 5: return launch_glds<64, 2, 8>(a, s);
-        case 6: return launch_glds<128, 4, 4>(a, s);
-        case 7: return launch_glds<128, 2, 4>(a, s);
-        case 8: return launch_glds<64, 3, 4>(a, s);
-        case 9: return launch_glds<64, 2, 4>(a, s);
-        case 10: return launch_glds<128, 4, 8, true>(a, s);
-        case 11: return launch_glds<128, 3, 8, true>(a, s);
-        case 12: return launch_glds<128, 2, 8, true>(a, s);
-        case 13: return launch_glds<64, 4, 8, true>(a, s);
-        case 14: return launch_glds<64, 3, 8, true>(a, s);
-        case 15: return launch_glds<128, 4, 8, true, true>(a, s);
-        case 16: return launch_glds<128, 4, 8, false, true>(a, s);
-        case 17: return launch_glds<128, 4, 4, false, true>(a, s);
-        case 18: return launch_glds<64, 4, 8, true, true>(a, s);
-        case 19: return launch_glds<64, 4, 8, false, true>(a, s);
-        case 20: return launch_glds<64, 4, 4, false, true>(a, s);
-        case 21: return launch_glds<256, 3, 8, false, false, 64, true>(a, s);
-        case 22: return launch_glds<256, 3, 8, false, false, 64, true>(a, s);
-        case 23: return launch_glds<128, 3, 8, false, false, 128, true>(a, s);
-        case 24: return launch_glds<128, 3, 8, false, false, 128, true>(a, s);
-        case 25: return launch_glds<128, 3, 8, false, false, 64, true>(a, s);
-        case 26: return launch_glds<128, 4, 8, false, false, 64, true>(a, s);
-        case 27: return launch_glds<256, 2, 8, false, false, 128>(a, s);
-        case 28: return launch_glds<256, 3, 8, false, false, 128>(a, s);
-        case 29: return launch_glds<256, 3, 8, false, false, 64>(a, s);
-        case 30: return launch_glds<128, 3, 8, false, false, 64>(a, s);
-        case 31: return launch_glds<128, 2, 8, false, false, 64>(a, s);
-        case 32: return launch_glds<128, 3, 8, false, false, 128, false, true>(a, s);
-        case 33: return launch_glds<128, 4, 8, false, false, 128, false, true>(a, s);
-        case 34: return launch_glds<64, 3, 8, false, false, 128, false, true>(a, s);
-        case 35: return launch_glds<64, 4, 8, false, false, 128, false, true>(a, s);
-        case 36: return launch_glds<128, 3, 8, false, false, 64, false, true>(a, s);
-        case 37: return launch_glds<128, 4, 8, false, false, 64, false, true>(a, s);
-        case 38: return launch_glds<256, 3, 8, false, false, 128, false, true>(a, s);
-        case 39: return launch_xp(a, 1, s);
-        case 40: return launch_xp(a, 2, s);
-        case 41: return launch_xp(a, 4, s);
-        case 42: return launch_pr(a, s);
-        case 43: return launch_du(a, s);
+        case 0: return launch_glds<128, 4, 8>(a, groups, s);
+        case 1: return launch_glds<128, 3, 8>(a, groups, s);
+        case 2: return launch_glds<128, 2, 8>(a, groups, s);
+        case 3: return launch_glds<64, 4, 8>(a, groups, s);
+        case 4: return launch_glds<64, 3, 8>(a, groups, s);
+        case 5: return launch_glds<64, 2, 8>(a, groups, s);
+        case 6: return launch_glds<128, 4, 4>(a, groups, s);
+        case 7: return launch_glds<128, 2, 4>(a, groups, s);
+        case 8: return launch_glds<64, 3, 4>(a, groups, s);
+        case 9: return launch_glds<64, 2, 4>(a, groups, s);
+        case 10: return launch_glds<128, 4, 8, true>(a, groups, s);
+        case 11: return launch_glds<128, 3, 8, true>(a, groups, s);
+        case 12: return launch_glds<128, 2, 8, true>(a, groups, s);
+        case 13: return launch_glds<64, 4, 8, true>(a, groups, s);
+        case 14: return launch_glds<64, 3, 8, true>(a, groups, s);
+        case 15: return launch_glds<128, 4, 8, true, true>(a, groups, s);
+        case 16: return launch_glds<128, 4, 8, false, true>(a, groups, s);
+        case 17: return launch_glds<128, 4, 4, false, true>(a, groups, s);
+        case 18: return launch_glds<64, 4, 8, true, true>(a, groups, s);
+        case 19: return launch_glds<64, 4, 8, false, true>(a, groups, s);
+        case 20: return launch_glds<64, 4, 4, false, true>(a, groups, s);
+        case 21: return launch_glds<256, 2, 8, false, false, 128>(a, groups, s);
+        case 22: return launch_glds<256, 3, 8, false, false, 128>(a, groups, s);
+        case 23: return launch_glds<256, 3, 8, false, false, 64>(a, groups, s);
+        case 24: return launch_glds<128, 3, 8, false, false, 64>(a, groups, s);
+        case 25: return launch_glds<128, 2, 8, false, false, 64>(a, groups, s);
+        case 26: return launch_xp(a, 1, groups, s);
+        case 27: return launch_xp(a, 2, groups, s);
+        case 28: return launch_xp(a, 4, groups, s);
+        case 29: return launch_pr(a, groups, s);
         default: return SAT_ERR_ARG;
     }
+}
+
+// What fixes the BITS of a variant's BatchNorm column sums (the conv output itself is bit-identical across ring variants and
+// conv_xp_kernel: same MFMA, same K order): the kernel family and, for the ring kernel, the tile rows and the consumer wave
+// grid (rows summed per lane, then the M-waves in order).  Two variants with the same signature leave the same statistics, so a
+// grouped launch may pick any variant of its ungrouped twin's signature and stay bit-identical to it per batch.
+int stat_signature(int v) {
+    const Variant& k = kVariants[v];
+    if (k.pr) return 2000;
+    if (k.xp) return 1000;
+    const int cw = k.spec ? k.nw / 2 : k.nw;
+    const int wgm = (cw == 4) ? 2 : ((k.bm == 128 && k.bn == 64) ? 4 : 2);
+    return k.bm * 8 + wgm;
 }
 
 ConvArgs make_args(const sat_op* op) {
@@ -945,10 +681,8 @@ ConvArgs make_args(const sat_op* op) {
     a.A = (const bf16_t*)op->in0; a.B = (const bf16_t*)op->w; a.C = (bf16_t*)op->out;
     a.stat_partial = op->stat_partial;
     a.acc = (long long*)op->stat_acc;
-    a.acc_shards = op->stat_shards > 1 ? op->stat_shards : 1;
-    a.in_shards = op->stat_shards1 > 1 ? op->stat_shards1 : 1;
     a.in_affine = 0;
-    if (op->scale0 || op->stat_acc1) {          // BatchNorm + ReLU of the INPUT fused into the A staging (1x1 convs)
+    if (op->scale0 || op->stat_acc1) {          // BatchNorm + ReLU of the INPUT fused into the A staging
         a.in_affine = 1;
         a.in_scale = op->scale0; a.in_shift = op->shift0;
         a.in_acc = (const long long*)op->stat_acc1;
@@ -957,20 +691,7 @@ ConvArgs make_args(const sat_op* op) {
         a.in_count = (double)op->count; a.in_momentum = op->momentum; a.in_eps = op->eps;
     }
     a.out_scale = op->scale1; a.out_shift = op->shift1;        // inference epilogue: affine (+ residual) (+ ReLU)
-    a.stats_only = (op->flags & SAT_CONV_STATS_ONLY) ? 1 : 0;
-    if (op->flags & SAT_CONV_OUT_BN) {                         // second pass of a two-pass conv: stat_acc is READ here
-        a.acc = nullptr; a.stat_partial = nullptr;
-        a.out_acc = (const long long*)op->stat_acc;
-        a.out_shards = op->stat_shards > 1 ? op->stat_shards : 1;
-        a.out_gamma = op->gamma; a.out_beta = op->beta;
-        a.out_running_mean = op->running_mean; a.out_running_var = op->running_var;
-        a.in_count = (double)op->count; a.in_momentum = op->momentum; a.in_eps = op->eps;
-    }
-    if (op->out1) {                                            // dual-source A: in1 is the residual SOURCE, out1 the side output
-        a.R = (const bf16_t*)op->in1; a.Y = (bf16_t*)op->out1; a.ldy = op->Cin;
-    } else {
-        a.residual = (const bf16_t*)op->in1;
-    }
+    a.residual = (const bf16_t*)op->in1;
     a.out_relu = op->flags & 1;
     a.M = op->N * op->Hout * op->Wout; a.N = op->Cout; a.K = op->KH * op->KW * op->Cin;
     a.ldb = a.K; a.ldc = (op->ldc >= op->Cout) ? op->ldc : op->Cout;
@@ -980,40 +701,27 @@ ConvArgs make_args(const sat_op* op) {
     a.sN = op->sN; a.sH = op->sH; a.sW = op->sW;
     a.linear = (op->KH == 1 && op->KW == 1 && op->stride == 1 && op->pad == 0 && a.padw == 0 && op->Hout == op->Hin &&
                 op->Wout == op->Win && op->sH == (long)op->Win * op->sW && op->sN == (long)op->Hin * op->sH) ? 1 : 0;
-    static const int dbg = tune_env("SAT_CONV_DBG", 0);
-    a.dbg = dbg;
-    static const int no_linear = tune_env("SAT_CONV_NO_LINEAR", 0);
-    if (no_linear) a.linear = 0;
+    // grouped launch: every per-batch buffer is `groups` consecutive copies of the ungrouped one (include/sat_hip.h, sat_op.groups)
+    a.gs_a = (long)op->N * op->sN;
+    a.gs_c = (long)a.M * a.ldc;
+    a.gs_partial = (long)op->tiles_m * 2 * a.N;
+    a.gs_acc = 4L * a.N;                        // [2 parities][2][N]
+    a.gs_in_acc = 4L * a.Cin;
+    a.gs_in_run = 2L * a.Cin;                   // [mean row][var row]
     return a;
 }
 
-// a variant the kernel can run for these arguments (the in-LDS input transform lives in the plain unified-wave loop)
-bool du_enabled() {
-    static const int no_du = tune_env("SAT_CONV_NO_DU", 0);      // A/B switch: conv_du_kernel is never offered
-    return !no_du;
-}
-
-bool pr_enabled() {
-    static const int no_pr = tune_env("SAT_CONV_NO_PR", 0);      // A/B switch: conv_pr_kernel is never offered
-    return !no_pr;
-}
+int op_groups(const sat_op* op) { return op->groups > 1 ? op->groups : 1; }
 
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
-    if (k.pr) return pr_enabled() && pr_ok(a);
-    if (k.du) return du_enabled() && du_ok(a);
-    if (a.R && (const void*)a.Y == (const void*)a.A) return false;      // y written over the raw operand: conv_du_kernel only
-    if (k.xp) {
-        static const int no_xp = tune_env("SAT_CONV_NO_XP", 0);      // A/B switch: the tuner never offers conv_xp_kernel
-        return !no_xp && xp_ok(a, k.xp);
-    }
+    if (k.pr) return pr_ok(a);
+    if (k.xp) return xp_ok(a, k.xp);
     if (k.bn >= 128 && a.N <= 64) return false;
     if (k.bn == 256 && a.N <= 128) return false;
-    if ((k.spec || k.pf) && a.in_affine) return false;
-    if ((k.dual != 0) != (a.R != nullptr)) return false;             // dual-source ops run dual kernels and nothing else
-    if (k.xa && (!a.in_affine || a.R || !((a.Cin % 64 == 0) && (a.KH * a.KW <= 32)))) return false;
-    if (!k.xa && !k.dual && a.in_affine && !a.linear) return false;  // the un-pipelined in-LDS transform is 1x1-only (no tap mask)
+    if ((k.spec || k.pf) && a.in_affine) return false;               // the in-LDS input transform lives in the plain unified-wave loop
+    if (a.in_affine && !a.linear) return false;                      // ... and is 1x1-only (no tap mask): 3x3 convs fuse it in conv_pr_kernel
     if (k.bm != 128 && a.stat_partial) return false;                 // the per-tile statistics slabs are 128-row tiles
     return true;
 }
@@ -1021,57 +729,53 @@ bool variant_ok(int v, const ConvArgs& a) {
 int heuristic_variant(const ConvArgs& a) {
     // 128x128 with a deep ring when it still leaves >= 2 tiles per CU and K is long enough to use the ring;
     // otherwise 128x64 with a shallower ring (more workgroups per CU to overlap prologue/epilogue phases)
-    if (a.R && du_enabled() && du_ok(a)) return 43;
-    if (a.R) return a.N > 128 ? 21 : 25;          // dual-source: 64-row tiles covering all of N where N <= 256
-    // 3x3 with a fused input BatchNorm: the LDS-resident patch where it can run (what the builder fuses bn1 for), else the pipelined in-ring transform
-    if (a.in_affine && !a.linear) return (pr_enabled() && pr_ok(a)) ? 42 : (a.N > 64 ? 32 : 34);
+    if (a.in_affine && !a.linear) return kVariantPr;      // 3x3 with a fused input BatchNorm: the LDS-resident patch (the builder fuses bn1 only where it can run)
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const int nk = sat_cdiv(a.K, 64);
     if (a.N > 64 && t128 >= 512) return nk <= 4 ? 2 : 0;
     return nk <= 4 ? 5 : 4;
 }
 
+// argument checks + parity / group bookkeeping shared by the launch and the tuner
+int prepare_args(const sat_op* op, int parity, ConvArgs& a) {
+    if (op->Cout % 8) return SAT_ERR_UNSUPPORTED;
+    a = make_args(op);
+    if (a.acc) a.acc += (long)parity * 2 * a.N;                          // [2 parities][2][N]
+    if ((a.out_scale != nullptr) != (a.out_shift != nullptr)) return SAT_ERR_ARG;
+    if (a.residual && (!a.out_scale || (const void*)a.residual == (const void*)a.C)) return SAT_ERR_ARG;
+    if (a.out_scale && (a.stat_partial || a.acc)) return SAT_ERR_ARG;     // batch statistics and a fixed affine exclude each other
+    if (a.in_affine) {
+        if (a.Cin > 512 || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;
+        if (a.in_acc) {
+            if (!a.in_gamma || !a.in_beta || a.in_count < 1) return SAT_ERR_ARG;
+            long long* base = (long long*)op->stat_acc1;       // [2 parities][2][Cin]
+            a.in_acc = base + (long)parity * 2 * a.Cin;
+            a.in_acc_clear = base + (long)(1 - parity) * 2 * a.Cin;
+        } else if (!a.in_scale || !a.in_shift) {
+            return SAT_ERR_ARG;
+        }
+        if (!a.linear && !pr_ok(a)) return SAT_ERR_UNSUPPORTED;
+    }
+    if (op_groups(op) > 1) {
+        // grouped: batch statistics only (a fixed affine needs no groups: eval-mode batches simply concatenate), running
+        // statistics in the per-group [mean row][var row] log layout
+        if (a.out_scale || a.residual || (a.in_affine && !a.in_acc)) return SAT_ERR_UNSUPPORTED;
+        if (a.in_running_mean && a.in_running_var != a.in_running_mean + a.Cin) return SAT_ERR_ARG;
+        if (a.stat_partial && op->tiles_m < sat_cdiv(a.M, 128)) return SAT_ERR_ARG;
+        if (op_groups(op) > 65535) return SAT_ERR_ARG;
+    }
+    return SAT_OK;
+}
+
 }  // namespace
 
 // bf16 SAT_OP_CONV; arguments already validated by sat_conv_launch
 int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
-    if (op->Cout % 8) return SAT_ERR_UNSUPPORTED;
-    ConvArgs a = make_args(op);
-    if ((a.acc_shards & (a.acc_shards - 1)) || a.acc_shards > 8 || (a.in_shards & (a.in_shards - 1)) || a.in_shards > 8) return SAT_ERR_ARG;
-    if (a.acc) a.acc += (long)parity * a.acc_shards * 2 * a.N;          // [2 parities][shards][2][N]
-    if (a.out_acc) {
-        if (!a.out_gamma || !a.out_beta || a.in_count < 1 || a.out_scale || (a.out_shards & (a.out_shards - 1)) || a.out_shards > 8)
-            return SAT_ERR_ARG;
-        long long* base = (long long*)op->stat_acc;
-        a.out_acc = base + (long)parity * a.out_shards * 2 * a.N;
-        a.out_acc_clear = base + (long)(1 - parity) * a.out_shards * 2 * a.N;
-        if (a.residual && (const void*)a.residual == (const void*)a.C) return SAT_ERR_ARG;
-    }
-    if (a.stats_only && !(a.acc || a.stat_partial)) return SAT_ERR_ARG;
-    if ((a.out_scale != nullptr) != (a.out_shift != nullptr)) return SAT_ERR_ARG;
-    if (a.residual && !a.out_acc && (!a.out_scale || (const void*)a.residual == (const void*)a.C)) return SAT_ERR_ARG;
-    if (a.out_scale && (a.stat_partial || a.acc)) return SAT_ERR_ARG;     // batch statistics and a fixed affine exclude each other
-    if (a.R) {
-        // dual-source A: needs the input affine (the previous bn3), a dense 1x1 geometry and room for the table
-        if (!a.in_affine || !a.linear || a.Cin > 2048 || (a.Cin % 64) || !a.Y || a.out_scale) return SAT_ERR_UNSUPPORTED;
-        if ((const void*)a.Y == (const void*)a.R || (const void*)a.Y == (const void*)a.C) return SAT_ERR_ARG;
-        // y over the raw operand (in place): only the kernel whose one workgroup per row tile reads each operand stage before it stores y there
-        if ((const void*)a.Y == (const void*)a.A && !(du_enabled() && du_ok(a))) return SAT_ERR_ARG;
-    }
-    if (a.in_affine) {
-        if (a.Cin > (a.R ? 2048 : 512) || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;
-        if (a.in_acc) {
-            if (!a.in_gamma || !a.in_beta || a.in_count < 1) return SAT_ERR_ARG;
-            long long* base = (long long*)op->stat_acc1;       // [2 parities][2][Cin]
-            a.in_acc = base + (long)parity * a.in_shards * 2 * a.Cin;
-            a.in_acc_clear = base + (long)(1 - parity) * a.in_shards * 2 * a.Cin;
-        } else if (!a.in_scale || !a.in_shift) {
-            return SAT_ERR_ARG;
-        }
-    }
+    ConvArgs a;
+    SAT_TRY(prepare_args(op, parity, a));
     int v = (op->variant > 0 && op->variant <= kNumVariants) ? op->variant - 1 : heuristic_variant(a);
     if (!variant_ok(v, a)) v = heuristic_variant(a);      // e.g. the in-LDS transforms live in the plain unified-wave loop
-    return launch_variant(v, a, s);
+    return launch_variant(v, a, op_groups(op), s);
 }
 
 #include <map>
@@ -1081,14 +785,59 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
 
 constexpr int kTuneTab = 2048;      // channels of the tuner's neutral (scale 1, shift 0) input-BatchNorm table
 
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int> TuneKey;
+static std::map<TuneKey, int> g_tune_cache;
+static std::mutex g_tune_mu;                       // the per-geometry result cache is shared by every caller thread
+
+static TuneKey tune_key(const sat_op* op, int groups) {
+    return TuneKey(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
+                   ((op->stat_partial || op->stat_acc) ? 1 : 0) + ((op->scale0 || op->stat_acc1) ? 2 : 0) +
+                       (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0), groups);
+}
+
+// time every variant the kernel can run for `op` as a launch of `groups` groups (only variants of statistics signature
+// `want_sig` when >= 0); returns the fastest in *best_v.  Tuning launches write the op's own output buffer and touch no
+// statistics / running buffers.
+static int tune_one(const sat_op* op, int groups, int want_sig, int reps, float* scratch, hipEvent_t e0, hipEvent_t e1, hipStream_t s,
+                    bool verbose, int* best_v) {
+    ConvArgs a = make_args(op);
+    a.acc = nullptr;
+    if (a.in_affine) {           // ... nor derive from / clear the live accumulators: the neutral table stands in
+        a.in_acc = nullptr; a.in_acc_clear = nullptr; a.in_running_mean = nullptr; a.in_running_var = nullptr;
+        a.in_scale = scratch; a.in_shift = scratch + kTuneTab;
+        if (a.Cin > 512 || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;
+    }
+    float best = 1e30f;
+    *best_v = heuristic_variant(a);
+    int rc = SAT_OK;
+    for (int v = 0; v < kNumVariants && rc == SAT_OK; ++v) {
+        if (!variant_ok(v, a)) continue;
+        if (want_sig >= 0 && stat_signature(v) != want_sig) continue;
+        float tmin = 1e30f;
+        for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
+            if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+            for (int r = 0; r < reps && rc == SAT_OK; ++r) rc = launch_variant(v, a, groups, s);
+            if (rc != SAT_OK) break;
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
+            if (round >= 1 && ms / reps < tmin) tmin = ms / reps;      // per launch
+        }
+        if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d G=%d v%d(%d,%d,%d,%s) %.2f us\n", a.M, a.N, a.K, groups, v, kVariants[v].bn,
+                             kVariants[v].s, kVariants[v].nw, kVariants[v].spec ? (kVariants[v].pf ? "spec+pf" : "spec") : (kVariants[v].pf ? "pf" : "-"), tmin * 1e3f);
+        if (tmin < best) { best = tmin; *best_v = v; }
+    }
+    if (verbose && rc == SAT_OK)
+        fprintf(stderr, "tune M=%d N=%d K=%d G=%d -> v%d %.2f us (%.0f TFLOP/s)\n", a.M, a.N, a.K, groups, *best_v, best * 1e3f,
+                2.0 * groups * a.M * a.N * a.K / (best * 1e-3) / 1e12);
+    return rc;
+}
+
 extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
                                  sat_stream_t stream) {
     if (!ops || n_ops < 0 || reps < 1) return SAT_ERR_ARG;
     if (!scratch || scratch_bytes < (int64_t)(2 * kTuneTab * sizeof(float))) return SAT_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int> Key;
-    static std::map<Key, int> cache;
-    static std::mutex cache_mu;                       // the per-geometry result cache is shared by every caller thread
     const bool verbose = getenv("SAT_TUNE_VERBOSE") != nullptr;
     // neutral input-BatchNorm table (scale 1, shift 0) in the CALLER's scratch: the library allocates nothing
     if (hipMemsetD32Async((hipDeviceptr_t)scratch, 0x3f800000, kTuneTab, s) != hipSuccess ||
@@ -1096,112 +845,49 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
         return SAT_ERR_UNSUPPORTED;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SAT_ERR_UNSUPPORTED;
-    // SAT_TUNE_COPIES=n (default 1 = each candidate alone): time every candidate as n copies in flight on n streams -- the regime
-    // of EncoderCNN.prefetch, where several batches' stacks run next to each other: rewards tiles that leave room for a
-    // neighbour (LDS, CU count) and fewer staged bytes per flop rather than the shortest solo launch.  n = 2: +2 % on the
-    // look-ahead step, but the kernel ALONE loses 3-4 % (0.142 against 0.149 of peak) and the choice gets noisier (and arbitrary
-    // under a profiler that serialises the streams), so it is opt-in.  Needs GPU_MAX_HW_QUEUES > the streams in use, or the
-    // extra streams alias the caller's hardware queue and the copies serialise.  Tuning launches write the op's own output
-    // buffer with identical values from every copy and touch no statistics.
-    const char* copies_env = getenv("SAT_TUNE_COPIES");
-    int copies = copies_env ? atoi(copies_env) : 1;
-    if (const char* pe = getenv("SAT_TUNE_PAIRED")) copies = pe[0] == '1' ? 2 : 1;      // older switch
-    if (copies < 1) copies = 1;
-    if (copies > 4) copies = 4;
-    hipStream_t sx[3] = {nullptr, nullptr, nullptr};
-    for (int c = 1; c < copies; ++c)
-        if (hipStreamCreateWithFlags(&sx[c - 1], hipStreamNonBlocking) != hipSuccess) return SAT_ERR_UNSUPPORTED;
-    hipEvent_t ex[3] = {nullptr, nullptr, nullptr};
-    for (int c = 1; c < copies; ++c)
-        if (hipEventCreate(&ex[c - 1]) != hipSuccess) return SAT_ERR_UNSUPPORTED;
-    // SAT_TUNE_COLD=1: every timed launch reads an input tensor that was just REWRITTEN (a fill of the op's own input buffer ahead of
-    // it, outside the timed span: the launch's dispatch timestamps) -- the state the conv meets in the program, where its producer
-    // ran a moment ago and nothing it reads is warm in its XCD's L2 from a previous launch of itself.  Back-to-back replays of one
-    // launch favour shallow rings (everything hits L2); in the program the 1x1 reductions of layer 3 take 18 us, not the 13 us the
-    // warm replay promises.
-    static const int cold = tune_env("SAT_TUNE_COLD", 0);
     int rc = SAT_OK;
     for (int i = 0; i < n_ops && rc == SAT_OK; ++i) {
         sat_op* op = ops + i;
         if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) continue;
-        const Key key(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
-                      ((op->stat_partial || op->stat_acc) ? 1 : 0) + ((op->scale0 || op->stat_acc1) ? 2 : 0) +
-                          (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0) + (op->out1 ? 16 : 0) + ((op->flags & SAT_CONV_OUT_BN) ? 32 : 0) +
-                          ((op->flags & SAT_CONV_STATS_ONLY) ? 64 : 0));
+        const int groups = op_groups(op);
+        // the ungrouped geometry first (grouped ops: its choice fixes the statistics signature the grouped launch must keep, so
+        // that every batch of a group gets, bit for bit, what the ungrouped launch gives it)
+        int v1 = -1;
         {
-            std::lock_guard<std::mutex> lk(cache_mu);
-            auto it = cache.find(key);
-            if (it != cache.end()) { op->variant = it->second; continue; }
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            auto it = g_tune_cache.find(tune_key(op, 1));
+            if (it != g_tune_cache.end()) v1 = it->second - 1;
         }
-        ConvArgs a = make_args(op);
-        a.acc = nullptr;             // tuning launches must not touch the statistics / running buffers
-        if (a.out_acc) {             // ... output-side BatchNorm: read this step's sums as they are, update / clear nothing
-            a.out_acc = (const long long*)op->stat_acc;
-            a.out_acc_clear = nullptr; a.out_running_mean = nullptr; a.out_running_var = nullptr;
+        if (v1 < 0) {
+            rc = tune_one(op, 1, -1, reps, scratch, e0, e1, s, verbose, &v1);
+            if (rc == SAT_ERR_UNSUPPORTED) { rc = SAT_OK; continue; }
+            if (rc != SAT_OK) break;
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            g_tune_cache[tune_key(op, 1)] = v1 + 1;
         }
-        if (a.in_affine) {           // ... nor derive from / clear the live accumulators: the neutral table stands in
-            a.in_acc = nullptr; a.in_acc_clear = nullptr; a.in_running_mean = nullptr;
-            a.in_scale = scratch; a.in_shift = scratch + kTuneTab;
-            if (a.Cin > (a.R ? 2048 : 512) || (a.Cin % 64) || (a.KH * a.KW > 32)) continue;
-        }
-        float best = 1e30f;
-        int best_v = heuristic_variant(a);
-        for (int v = 0; v < kNumVariants; ++v) {
-            if (!variant_ok(v, a)) continue;
-            float tmin = 1e30f;
-            if (cold && copies == 1) {
-                const size_t in_bytes = (size_t)(op->sN > 0 ? op->sN : (long)op->Hin * op->Win * op->Cin) * op->N * sizeof(bf16_t);
-                for (int round = 0; round < 4 && rc == SAT_OK; ++round) {   // round 0 = warm-up, then best of 3 (each the mean of reps launches)
-                    float sum = 0.f;
-                    for (int r = 0; r < reps && rc == SAT_OK; ++r) {
-                        if (hipMemsetAsync((void*)op->in0, 0, in_bytes, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-                        sat_conv_arm_timer(e0, e1);
-                        rc = launch_variant(v, a, s);
-                        if (rc != SAT_OK) break;
-                        float ms = 0.f;
-                        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-                        sum += ms;
-                    }
-                    if (round >= 1 && sum / reps < tmin) tmin = sum / reps;
-                }
-            } else
-            for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
-                if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-                for (int c = 1; c < copies; ++c)
-                    if (hipStreamWaitEvent(sx[c - 1], e0, 0) != hipSuccess) rc = SAT_ERR_UNSUPPORTED;
-                for (int r = 0; r < reps && rc == SAT_OK; ++r) {
-                    rc = launch_variant(v, a, s);
-                    for (int c = 1; c < copies && rc == SAT_OK; ++c) rc = launch_variant(v, a, sx[c - 1]);
-                }
-                for (int c = 1; c < copies; ++c)
-                    if (hipEventRecord(ex[c - 1], sx[c - 1]) != hipSuccess || hipStreamWaitEvent(s, ex[c - 1], 0) != hipSuccess)
-                        rc = SAT_ERR_UNSUPPORTED;
-                if (rc != SAT_OK) break;
-                if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
-                if (round >= 1 && ms / (reps * copies) < tmin) tmin = ms / (reps * copies);      // per launch
-            }
-            if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d v%d(%d,%d,%d,%s) %.2f us\n", a.M, a.N, a.K, v, kVariants[v].bn,
-                                 kVariants[v].s, kVariants[v].nw, kVariants[v].spec ? (kVariants[v].pf ? "spec+pf" : "spec") : (kVariants[v].pf ? "pf" : "-"), tmin * 1e3f);
-            if (tmin < best) { best = tmin; best_v = v; }
-        }
-        if (verbose) fprintf(stderr, "tune M=%d N=%d K=%d -> v%d %.2f us (%.0f TFLOP/s)\n", a.M, a.N, a.K, best_v, best * 1e3f,
-                             2.0 * a.M * a.N * a.K / (best * 1e-3) / 1e12);
+        if (groups == 1) { op->variant = v1 + 1; continue; }
+        int vg = -1;
         {
-            std::lock_guard<std::mutex> lk(cache_mu);
-            cache[key] = best_v + 1;
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            auto it = g_tune_cache.find(tune_key(op, groups));
+            if (it != g_tune_cache.end()) vg = it->second - 1;
         }
-        op->variant = best_v + 1;
+        if (vg < 0) {
+            rc = tune_one(op, groups, stat_signature(v1), reps, scratch, e0, e1, s, verbose, &vg);
+            if (rc != SAT_OK) break;
+            if (stat_signature(vg) != stat_signature(v1)) vg = v1;      // (the heuristic default of tune_one when nothing qualified)
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            g_tune_cache[tune_key(op, groups)] = vg + 1;
+        }
+        op->variant = vg + 1;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    for (int c = 0; c < 3; ++c) {
-        if (ex[c]) (void)hipEventDestroy(ex[c]);
-        if (sx[c]) {
-            (void)hipStreamSynchronize(sx[c]);
-            (void)hipStreamDestroy(sx[c]);
-        }
-    }
     return rc;
+}
+
+// the statistics signature of a variant number as stored in sat_op.variant (1-based; 0 / out of range: -1): callers that load a
+// saved tuning table check that a grouped op's variant matches its ungrouped twin's
+extern "C" int sat_conv_variant_signature(int variant) {
+    return (variant >= 1 && variant <= kNumVariants) ? stat_signature(variant - 1) : -1;
 }

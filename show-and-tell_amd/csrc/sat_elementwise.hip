@@ -11,12 +11,12 @@ namespace {
 
 constexpr int EW_BLOCK = 256;
 inline int ew_grid(long n_items) {
-    static long cap = 0;
+    long cap;
     // 768 workgroups (3 per CU), measured under the encoder look-ahead (tools/run_gpu_bn_ab.sh, round 3): with three stacks in
     // flight the HBM-bound BatchNorm passes of one stack run beside the convs of the others, and a grid that takes fewer wave
     // slots per CU leaves those convs their CUs: 2048 / 1024 / 768 / 512 / 384 = 13.55 / 13.8 / 14.0 / 13.95 k img/s (with the
     // non-temporal operand loads 13.75 / 14.2 / 14.27 / 14.3 / 14.3 k); the sequential step does not move until 384 (6.36 -> 6.49 ms)
-    if (cap == 0) { const char* e = getenv("SAT_EW_GRID_CAP"); cap = e ? atol(e) : 768; if (cap < 1) cap = 768; }
+    cap = 768;
     long b = (n_items + EW_BLOCK - 1) / EW_BLOCK;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));   // cap and grid-stride the rest
 }
@@ -153,6 +153,8 @@ __global__ __launch_bounds__(1024) void bn_slab_to_acc_kernel(const float* __res
     __shared__ double ss[FIN_G][32], sq[FIN_G][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    partial += (long)blockIdx.z * tiles_m * 2 * C;           // grouped program: group = blockIdx.z, [G][tiles_m][2][C] slabs,
+    acc += (long)blockIdx.z * 4 * C;                         // [G][2 parities][2][C] accumulators
     const int t0 = blockIdx.y * SLAB_TILES_PER_WG;
     const int t1 = (t0 + SLAB_TILES_PER_WG < tiles_m) ? t0 + SLAB_TILES_PER_WG : tiles_m;
     double s = 0.0, q = 0.0;
@@ -215,24 +217,30 @@ __global__ __launch_bounds__(256) void bn_running_apply_kernel(const sat_bn_runn
 struct BnSrc {
     const float* scale;
     const float* shift;
-    const long long* acc;     // [shards][2][C] (this step's parity)
-    long long* acc_clear;     // [shards][2][C] (other parity) or NULL
-    int shards;
+    const long long* acc;     // [2][C] (this step's parity)
+    long long* acc_clear;     // [2][C] (other parity) or NULL
     const float* gamma;
     const float* beta;
     float* running_mean;
     float* running_var;
 };
 
+// grouped program (sat_op.groups): group g's statistics live g blocks further on -- accumulators [G][2 parities][2][C], the
+// deferred running-statistics log [G][2][C]
+__device__ __forceinline__ BnSrc bn_group(BnSrc b, long g, int C) {
+    if (g) {
+        if (b.acc) b.acc += g * 4 * C;
+        if (b.acc_clear) b.acc_clear += g * 4 * C;
+        if (b.running_mean) { b.running_mean += g * 2 * C; b.running_var += g * 2 * C; }
+    }
+    return b;
+}
+
 __device__ __forceinline__ void bn_table_from_acc(const BnSrc& b, int C, double count, float momentum, float eps,
                                                   float* sc, float* sh) {
     const double inv = 1.0 / (SAT_STAT_SCALE * count);      // one f64 division per thread, none per channel
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        long long s1 = 0, s2 = 0;
-        for (int sh = 0; sh < b.shards; ++sh) {              // integer sums: order independent
-            s1 += b.acc[(long)sh * 2 * C + c];
-            s2 += b.acc[(long)sh * 2 * C + C + c];
-        }
+        const long long s1 = b.acc[c], s2 = b.acc[C + c];
         const double mean = (double)s1 * inv;
         double var = (double)s2 * inv - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -246,8 +254,7 @@ __device__ __forceinline__ void bn_table_from_acc(const BnSrc& b, int C, double 
                 b.running_mean[c] = (float)((1.0 - momentum) * b.running_mean[c] + momentum * (double)(float)mean);
                 b.running_var[c] = (float)((1.0 - momentum) * b.running_var[c] + momentum * (double)(float)unbiased);
             }
-            if (b.acc_clear)
-                for (int sh = 0; sh < b.shards; ++sh) { b.acc_clear[(long)sh * 2 * C + c] = 0; b.acc_clear[(long)sh * 2 * C + C + c] = 0; }
+            if (b.acc_clear) { b.acc_clear[c] = 0; b.acc_clear[C + c] = 0; }
         }
     }
 }
@@ -258,9 +265,15 @@ __device__ __forceinline__ void bn_table_from_acc(const BnSrc& b, int C, double 
 // `out` may alias `in0` (in-place normalise: every chunk is read before it is written, by the thread that writes it).
 template <typename T, bool ADD, bool NT = false>
 __global__ void bn_act_kernel(const T* in0, const T* __restrict__ in1, T* out,
-                              const BnSrc b0, const BnSrc b1, int has_b1, double count, float momentum, float eps,
+                              const BnSrc b0_, const BnSrc b1_, int has_b1, double count, float momentum, float eps,
                               long nchunks, int C) {
     constexpr int V = Vec<T>::N;
+    // grouped program: group = blockIdx.y works on its own batch (nchunks chunks further on) with its own statistics
+    const long grp = blockIdx.y;
+    in0 += grp * nchunks * V;
+    if constexpr (ADD) in1 += grp * nchunks * V;
+    out += grp * nchunks * V;
+    const BnSrc b0 = bn_group(b0_, grp, C), b1 = bn_group(b1_, grp, C);
     extern __shared__ __attribute__((aligned(16))) float tab[];      // [4][C] when a table is derived here
     const float* s0 = b0.scale;
     const float* t0 = b0.shift;
@@ -395,9 +408,13 @@ __global__ void bn_relu_strided_kernel(const T* __restrict__ in, T* __restrict__
 
 // out[n][ho][wo][c] = max_{3x3, stride 2, pad 1} relu(in*s + t)
 template <typename T>
-__global__ void bn_relu_maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, const BnSrc b, double count,
+__global__ void bn_relu_maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, const BnSrc b_, double count,
                                        float momentum, float eps, int N, int Hin, int Win, int C, int Hout, int Wout) {
     constexpr int V = Vec<T>::N;
+    const long grp = blockIdx.y;                             // grouped program: group = blockIdx.y, N = the batch of ONE group
+    in += grp * N * Hin * Win * C;
+    out += grp * N * Hout * Wout * C;
+    const BnSrc b = bn_group(b_, grp, C);
     extern __shared__ __attribute__((aligned(16))) float tab[];      // [2][C] when the table is derived here
     const float* s = b.scale;
     const float* t = b.shift;
@@ -938,13 +955,14 @@ int sat_bn_finalize_launch(const sat_op* op, int parity, hipStream_t s) {
         // the same fixed-point integer accumulators the few-tile convs feed directly, and the consuming kernel derives
         // (scale, shift) itself: ~3 us of wide parallel work instead of a 5-11 us latency-bound tail of 2-16 workgroups.
         if (!op->stat_partial || op->tiles_m < 1 || op->Cout < 1) return SAT_ERR_ARG;
-        const int sh = op->stat_shards > 1 ? op->stat_shards : 1;      // the reducer adds into shard 0 of this parity's block
-        long long* acc = (long long*)op->stat_acc + (long)parity * sh * 2 * op->Cout;
-        hipLaunchKernelGGL(bn_slab_to_acc_kernel, dim3(sat_cdiv(op->Cout, 32), sat_cdiv(op->tiles_m, SLAB_TILES_PER_WG)),
+        long long* acc = (long long*)op->stat_acc + (long)parity * 2 * op->Cout;
+        const int groups = op->groups > 1 ? op->groups : 1;
+        hipLaunchKernelGGL(bn_slab_to_acc_kernel, dim3(sat_cdiv(op->Cout, 32), sat_cdiv(op->tiles_m, SLAB_TILES_PER_WG), groups),
                            dim3(1024), 0, s, op->stat_partial, op->tiles_m, op->Cout, acc);
         SAT_LAUNCH_CHECK();
         return SAT_OK;
     }
+    if (op->groups > 1) return SAT_ERR_UNSUPPORTED;          // grouped programs keep their statistics as integer sums
     if (!op->gamma || !op->beta || !op->scale_out || !op->shift_out) return SAT_ERR_ARG;
     if (op->training && !op->stat_partial) return SAT_ERR_ARG;
     if (!op->training && (!op->running_mean || !op->running_var)) return SAT_ERR_ARG;
@@ -969,10 +987,9 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
     size_t lds = 0;
     if (op->stat_acc) {              // statistics arrive as integer sums: derive the table in the kernel
         if (!op->gamma || !op->beta || op->count < 1) return SAT_ERR_ARG;
-        long long* base = (long long*)op->stat_acc;          // [2 parities][shards][2][C]
-        b0.shards = op->stat_shards > 1 ? op->stat_shards : 1;
-        b0.acc = base + (long)parity * b0.shards * 2 * C;
-        b0.acc_clear = base + (long)(1 - parity) * b0.shards * 2 * C;
+        long long* base = (long long*)op->stat_acc;          // [2 parities][2][C]
+        b0.acc = base + (long)parity * 2 * C;
+        b0.acc_clear = base + (long)(1 - parity) * 2 * C;
         b0.gamma = op->gamma; b0.beta = op->beta; b0.running_mean = op->running_mean; b0.running_var = op->running_var;
         lds = (size_t)4 * C * sizeof(float);
     } else if (!op->scale0 || !op->shift0) {
@@ -982,9 +999,8 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
         if (op->stat_acc1) {
             if (!op->gamma1 || !op->beta1 || op->count < 1) return SAT_ERR_ARG;
             long long* base = (long long*)op->stat_acc1;
-            b1.shards = op->stat_shards1 > 1 ? op->stat_shards1 : 1;
-            b1.acc = base + (long)parity * b1.shards * 2 * C;
-            b1.acc_clear = base + (long)(1 - parity) * b1.shards * 2 * C;
+            b1.acc = base + (long)parity * 2 * C;
+            b1.acc_clear = base + (long)(1 - parity) * 2 * C;
             b1.gamma = op->gamma1; b1.beta = op->beta1; b1.running_mean = op->running_mean1; b1.running_var = op->running_var1;
             lds = (size_t)4 * C * sizeof(float);
             has_b1 = 1;
@@ -997,48 +1013,37 @@ static int bn_act_launch_t(const sat_op* op, bool add, int parity, hipStream_t s
     // thread count a multiple of the chunks per pixel (channel chunk invariant per thread)
     const int cch = C / V;
     int grid = ew_grid(nch);
-    if (lds) {          // every workgroup derives the affine table first: fewer, fatter workgroups amortise that prologue
-        static int cap = 0;
-        if (cap == 0) { const char* e = getenv("SAT_BN_DERIVE_GRID"); cap = e ? atoi(e) : 2048; if (cap < 1) cap = 2048; }
-        if (grid > cap) grid = cap;
-    }
+    if (lds && grid > 2048) grid = 2048;   // every workgroup derives the affine table first: fewer, fatter workgroups amortise that prologue
+    if (op->groups > 1 && grid >= 2 * op->groups) grid /= op->groups;      // grouped: the same number of workgroups in total (ew_grid's cap is about wave slots per CU)
     if (cch > EW_BLOCK && (cch % EW_BLOCK) == 0) {
         const int g0 = cch / EW_BLOCK;
         grid = grid / g0 * g0;
         if (grid < g0) grid = g0;
     }
-    // Workgroup size of the table-deriving launches (SAT_BN_BLOCK): every workgroup turns the integer sums of ALL C channels into
-    // (scale, shift) first -- f64 arithmetic, ~90 vector instructions per channel -- so at 256 threads a 1024-channel
-    // normalise+add spends ~360 instructions per thread there, on every one of its 768 workgroups, before it streams.  The same
-    // threads in 4x fewer, 4x larger workgroups derive each channel 4x less often.
-    // Measured (round 3, bench.py): strictly sequential steps 6.14 -> 6.02 ms at 512 (6.05 at 1024); with three stacks in flight the
-    // prologue hides under the neighbours' work either way (4.39 vs 4.40 ms) and 1024 loses 2 %: default 512.
-    static const int bn_block = getenv("SAT_BN_BLOCK") ? atoi(getenv("SAT_BN_BLOCK")) : 512;
+    // Workgroup size of the table-deriving launches: every workgroup turns the integer sums of ALL C channels into (scale, shift)
+    // first -- f64 arithmetic, ~90 vector instructions per channel -- so at 256 threads a 1024-channel normalise+add spends ~360
+    // instructions per thread there, on every one of its 768 workgroups, before it streams.  The same threads in 2x fewer, 2x
+    // larger workgroups derive each channel 2x less often.  Measured (round 3, bench.py): strictly sequential steps 6.14 -> 6.02 ms
+    // at 512 (6.05 at 1024); with three stacks in flight the prologue hides under the neighbours' work either way.
+    constexpr int kBnBlock = 512;
     int block = EW_BLOCK;
-    if (lds && (bn_block == 512 || bn_block == 1024) && (bn_block % cch) == 0 && grid >= bn_block / EW_BLOCK) {
-        block = bn_block;
-        grid = grid / (bn_block / EW_BLOCK);
+    if (lds && (kBnBlock % cch) == 0 && grid >= kBnBlock / EW_BLOCK) {
+        block = kBnBlock;
+        grid = grid / (kBnBlock / EW_BLOCK);
     }
+    const int groups = op->groups > 1 ? op->groups : 1;
+    if (groups > 1 && !op->stat_acc) return SAT_ERR_UNSUPPORTED;       // a grouped program has per-group batch statistics
+    if (groups > 1 && ((b0.running_mean && b0.running_var != b0.running_mean + C) ||
+                       (b1.running_mean && b1.running_var != b1.running_mean + C))) return SAT_ERR_ARG;
     const double count = (double)op->count;
     // The normalise+add kernel reads its two operands with NON-TEMPORAL loads: both are dead after it (the raw conv3 tensor, and
     // the block input that y replaces), so they need not displace the other stacks' live tensors from the Infinity Cache.
-    // Measured under look-ahead (round 3): +1.2-2.9 % at every grid size (13.55 -> 13.75 k at 2048 workgroups, 14.0 -> 14.27 k at
-    // 768); SAT_BN_NT=0 restores plain loads, =2 also reads the normalise+ReLU kernel's operand that way.
-    static const int bn_nt = getenv("SAT_BN_NT") ? atoi(getenv("SAT_BN_NT")) : 1;
-    if (!add && bn_nt >= 2) {
-        hipLaunchKernelGGL((bn_act_kernel<T, false, true>), dim3(grid), dim3(block), lds, s, (const T*)op->in0, (const T*)nullptr,
-                           (T*)op->out, b0, b1, 0, count, op->momentum, op->eps, nch, C);
-        SAT_LAUNCH_CHECK();
-        return SAT_OK;
-    }
-    if (add && bn_nt)
-        hipLaunchKernelGGL((bn_act_kernel<T, true, true>), dim3(grid), dim3(block), lds, s, (const T*)op->in0, (const T*)op->in1,
-                           (T*)op->out, b0, b1, has_b1, count, op->momentum, op->eps, nch, C);
-    else if (add)
-        hipLaunchKernelGGL((bn_act_kernel<T, true>), dim3(grid), dim3(block), lds, s, (const T*)op->in0, (const T*)op->in1,
+    // Measured under look-ahead (round 3): +1.2-2.9 % at every grid size (13.55 -> 13.75 k at 2048 workgroups, 14.0 -> 14.27 k at 768).
+    if (add)
+        hipLaunchKernelGGL((bn_act_kernel<T, true, true>), dim3(grid, groups), dim3(block), lds, s, (const T*)op->in0, (const T*)op->in1,
                            (T*)op->out, b0, b1, has_b1, count, op->momentum, op->eps, nch, C);
     else
-        hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(grid), dim3(block), lds, s, (const T*)op->in0, (const T*)nullptr,
+        hipLaunchKernelGGL((bn_act_kernel<T, false>), dim3(grid, groups), dim3(block), lds, s, (const T*)op->in0, (const T*)nullptr,
                            (T*)op->out, b0, b1, 0, count, op->momentum, op->eps, nch, C);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
@@ -1055,9 +1060,8 @@ static int bn_relu_strided_launch_t(const sat_op* op, int parity, hipStream_t s)
     if (op->stat_acc) {
         if (!op->gamma || !op->beta || op->count < 1) return SAT_ERR_ARG;
         long long* base = (long long*)op->stat_acc;
-        b.shards = op->stat_shards > 1 ? op->stat_shards : 1;
-        b.acc = base + (long)parity * b.shards * 2 * C;
-        b.acc_clear = base + (long)(1 - parity) * b.shards * 2 * C;
+        b.acc = base + (long)parity * 2 * C;
+        b.acc_clear = base + (long)(1 - parity) * 2 * C;
         b.gamma = op->gamma; b.beta = op->beta; b.running_mean = op->running_mean; b.running_var = op->running_var;
         lds = (size_t)2 * C * sizeof(float);
     } else if (!op->scale0 || !op->shift0) {
@@ -1088,9 +1092,8 @@ int sat_bn_relu_maxpool_launch(const sat_op* op, int parity, hipStream_t s) {
     if (op->stat_acc) {
         if (!op->gamma || !op->beta || op->count < 1) return SAT_ERR_ARG;
         long long* base = (long long*)op->stat_acc;
-        b.shards = op->stat_shards > 1 ? op->stat_shards : 1;
-        b.acc = base + (long)parity * b.shards * 2 * C;
-        b.acc_clear = base + (long)(1 - parity) * b.shards * 2 * C;
+        b.acc = base + (long)parity * 2 * C;
+        b.acc_clear = base + (long)(1 - parity) * 2 * C;
         b.gamma = op->gamma; b.beta = op->beta; b.running_mean = op->running_mean; b.running_var = op->running_var;
         lds = (size_t)2 * C * sizeof(float);
         if (lds > 64 * 1024) return SAT_ERR_UNSUPPORTED;
@@ -1098,16 +1101,19 @@ int sat_bn_relu_maxpool_launch(const sat_op* op, int parity, hipStream_t s) {
         return SAT_ERR_ARG;
     }
     const double count = (double)op->count;
+    const int groups = op->groups > 1 ? op->groups : 1;
+    if (groups > 1 && (!op->stat_acc || (b.running_mean && b.running_var != b.running_mean + C))) return SAT_ERR_ARG;
     if (op->dtype == SAT_BF16) {
         if (C % 8) return SAT_ERR_ARG;
         const long total = (long)op->N * op->Hout * op->Wout * (C / 8);
         if (total >= (1L << 31)) return SAT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_BLOCK), lds, s, (const bf16_t*)op->in0,
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(ew_grid(total), groups), dim3(EW_BLOCK), lds, s, (const bf16_t*)op->in0,
                            (bf16_t*)op->out, b, count, op->momentum, op->eps, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
     } else {
         if (C % 4) return SAT_ERR_ARG;
         const long total = (long)op->N * op->Hout * op->Wout * (C / 4);
         if (total >= (1L << 31)) return SAT_ERR_UNSUPPORTED;
+        if (groups > 1) return SAT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), lds, s, (const float*)op->in0,
                            (float*)op->out, b, count, op->momentum, op->eps, op->N, op->Hin, op->Win, C, op->Hout, op->Wout);
     }

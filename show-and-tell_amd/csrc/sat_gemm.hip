@@ -36,28 +36,14 @@ struct GemmArgs {
     int tiles_n;
     int ksplit;          // gridDim.y: K-steps are dealt to ksplit slices, slice z writes C + z*slab_stride
     long slab_stride;
-    // Fused vocab projection + CE (models.py:53 + train.py:53,143).  XF = 1 (epilogue): besides C the kernel emits, per
-    // output row and per (tile column, wave column), the max and the sum of exp(x - max) over that wave's columns ->
-    // lse_part[row][2*tiles_n][2]; a tiny combine kernel turns them into the row's log-sum-exp, so the CE never re-reads
-    // the logits.  XF = 2 (operand): the A operand is the softmax gradient of the stored logits, formed on the fly --
-    // a = (exp(x - lse[row]) - (col == target[row])) * inv_denom, 0 beyond the V valid columns -- so d(loss)/d(logits) is
-    // never written; with AMODE = AM_KM (dW = dlogits^T Hs) the kernel also accumulates the column sums of that operand
-    // = the bias gradient (tile column 0 writes them).
-    float* lse_part;
-    const float* lse;
-    const int64_t* targets;
-    float inv_denom;
-    int xf_cols;         // V: valid columns of the logits
-    float* colsum_out;   // XF = 2, AM_KM: [M] bias gradient
 };
 
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef f32x4 type; };
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
 
-template <typename T, int BM, int BN, int AMODE, int BMODE, int XF = 0>
+template <typename T, int BM, int BN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
-    static_assert(XF == 0 || sizeof(T) == 4, "the CE fusions are f32");
     constexpr int CH = 16 / (int)sizeof(T);    // elements per 16-byte chunk
     constexpr int BK = 128 / (int)sizeof(T);   // elements of K per step
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -123,24 +109,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     u32x4 ra[NA], rb[NB];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    // XF = 2: AM_ROW -- the row's log-sum-exp and target are K-invariant; AM_KM -- running column sums of the operand
-    float xf_lse[NA];
-    int xf_tgt[NA];
-    float xf_colsum[NA][4];
-    int xf_kt = 0;
-    if constexpr (XF == 2) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            xf_lse[i] = 0.0f; xf_tgt[i] = -1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xf_colsum[i][e] = 0.0f;
-            if constexpr (AMODE == AM_ROW) {
-                const int grow = m0 + (tid >> 3) + i * 32;
-                if (grow < p.M) { xf_lse[i] = p.lse[grow]; xf_tgt[i] = (int)p.targets[grow]; }
-            }
-        }
-    }
-
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
         // ---- A ----
@@ -178,13 +146,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 const int k = k0 + krow, m = m0 + mc * CH;
                 const bool ok = (k < p.K) && (m < p.M);
                 ra[i] = ok ? *(const u32x4*)(Ag + (long)k * p.lda + m) : zero4;
-                if constexpr (XF == 2) {          // k = packed token: its log-sum-exp / target travel with the tile
-                    xf_lse[i] = (k < p.K) ? p.lse[k] : 0.0f;
-                    xf_tgt[i] = (k < p.K) ? (int)p.targets[k] : -1;
-                }
             }
         }
-        xf_kt = kt;
         // ---- B ----
         if constexpr (BMODE == BMODE_NT) {
             const int kk = k0 + kc * CH;
@@ -206,35 +169,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     };
 
     auto store_tiles = [&]() {
-        if constexpr (XF == 2) {
-            // the softmax gradient is formed HERE -- after the MFMAs of the previous K-step, right before the LDS store -- so
-            // the global loads above stay in flight under the matrix work
-            const int k0 = xf_kt * BK;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                f32x4 v = *(f32x4*)&ra[i];
-                if constexpr (AMODE == AM_ROW) {          // rows = packed tokens, k = vocab column
-                    const int kk = k0 + kc * CH;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int col = kk + e;
-                        v[e] = (a_base[i] >= 0 && col < p.xf_cols)
-                                   ? (expf(v[e] - xf_lse[i]) - (col == xf_tgt[i] ? 1.0f : 0.0f)) * p.inv_denom : 0.0f;
-                    }
-                } else {                                  // AM_KM: k = packed token, m = vocab column
-                    const int qid = tid + i * 256;
-                    const int krow = qid / (BM / CH), mc = qid - krow * (BM / CH);
-                    const int k = k0 + krow, m = m0 + mc * CH;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int col = m + e;
-                        v[e] = (k < p.K && col < p.xf_cols) ? (expf(v[e] - xf_lse[i]) - (col == xf_tgt[i] ? 1.0f : 0.0f)) * p.inv_denom : 0.0f;
-                        xf_colsum[i][e] += v[e];
-                    }
-                }
-                ra[i] = *(u32x4*)&v;
-            }
-        }
         if constexpr (AMODE != AM_KM) {
 #pragma unroll
             for (int i = 0; i < NA; ++i)
@@ -346,69 +280,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
     }
 
-    if constexpr (XF == 1) {
-        // per row: max and sum exp(x - max) over THIS wave's WN columns (bias included, columns >= N excluded); the 32 lanes
-        // that share h hold one row's 32 columns per j: butterfly within the half-wave
-        const int part_ld = 2 * p.tiles_n;                         // partials per row: (tile_n, wn)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + wn * WN + j * 32 + r;
-                    float badd = 0.0f;
-                    if (col < p.N) {
-                        if (p.bias) badd += p.bias[col];
-                        if (p.bias2) badd += p.bias2[col];
-                        mx = fmaxf(mx, acc[i][j][e] + badd);
-                    }
-                }
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-                float sm = 0.0f;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + wn * WN + j * 32 + r;
-                    if (col < p.N) {
-                        float badd = 0.0f;
-                        if (p.bias) badd += p.bias[col];
-                        if (p.bias2) badd += p.bias2[col];
-                        sm += expf(acc[i][j][e] + badd - mx);
-                    }
-                }
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) sm += __shfl_xor(sm, o, 64);
-                const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (r == 0 && row < p.M) {
-                    float* dst = p.lse_part + ((long)row * part_ld + (tile_n * 2 + wn)) * 2;
-                    dst[0] = mx;
-                    dst[1] = sm;
-                }
-            }
-        }
-    }
-    if constexpr (XF == 2 && AMODE == AM_KM) {
-        // bias gradient: this thread summed its 4 columns (m) over every k it loaded; the threads that share the m chunk
-        // (tid % (BM/4)) are reduced through LDS in a fixed order; tile column 0 writes
-        if (tile_n == 0 && p.colsum_out && kz == 0) {
-            __syncthreads();
-            float* red = (float*)smem;                             // [256 / (BM/4) * NA][BM] floats
-            constexpr int MC = BM / 4, G = 256 / MC;               // threads per k-row group, groups per block
-#pragma unroll
-            for (int i = 0; i < NA; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) red[((tid / MC) * NA + i) * BM + (tid % MC) * 4 + e] = xf_colsum[i][e];
-            __syncthreads();
-            for (int c = tid; c < BM; c += 256) {
-                float sacc = 0.0f;
-                for (int q = 0; q < G * NA; ++q) sacc += red[q * BM + c];
-                if (m0 + c < p.M) p.colsum_out[m0 + c] = sacc;
-            }
-        }
-    }
-
     if (p.stat_partial) {
         // per-tile column sum / sum of squares of the f32 accumulators (rows >= M are exact zeros)
         float* red = (float*)smem;  // [wm][2][BN]
@@ -441,36 +312,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int AMODE, int BMODE, int XF = 0>
+template <typename T, int BM, int BN, int AMODE, int BMODE>
 int launch(GemmArgs& a, hipStream_t s) {
     const int tm = sat_cdiv(a.M, BM), tn = sat_cdiv(a.N, BN);
     a.tiles_n = tn;
     if (a.ksplit < 1) a.ksplit = 1;
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AMODE, BMODE, XF>), dim3(tm * tn, a.ksplit), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AMODE, BMODE>), dim3(tm * tn, a.ksplit), dim3(256), 0, s, a);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
 
-template <int AMODE, int BMODE, int XF = 0>
+template <int AMODE, int BMODE>
 int launch_f32_auto(GemmArgs& a, hipStream_t s) {
     // fill the 256 CUs: fall to smaller tiles when the big ones leave most of the chip idle
     const int ks = a.ksplit < 1 ? 1 : a.ksplit;
-    static int force = -1;              // SAT_GEMM_TILE=1/2/3: tuning override (128x128 / 128x64 / 64x64)
-    if (force < 0) { const char* e = getenv("SAT_GEMM_TILE"); force = e ? atoi(e) : 0; }
-    if (force == 1) return launch<float, 128, 128, AMODE, BMODE, XF>(a, s);
-    if (force == 2) return launch<float, 128, 64, AMODE, BMODE, XF>(a, s);
-    if (force == 3) return launch<float, 64, 64, AMODE, BMODE, XF>(a, s);
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128) * ks;
     const long t12864 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 64) * ks;
-    if (t128 >= 384) return launch<float, 128, 128, AMODE, BMODE, XF>(a, s);
+    if (t128 >= 384) return launch<float, 128, 128, AMODE, BMODE>(a, s);
     if (t12864 >= 384) {
         // rounds of 256 workgroups x tile area x a per-flop penalty: 128x64 only where its last round is not mostly
         // empty (measured on the decoder's shapes, tools/microbench.py gemm: dW_vocab 138 -> 125 us with 64x64)
         const long t64 = (long)sat_cdiv(a.M, 64) * sat_cdiv(a.N, 64) * ks;
         const double c12864 = (double)((t12864 + 255) / 256) * 128 * 64 * 1.1, c64 = (double)((t64 + 255) / 256) * 64 * 64 * 1.25;
-        if (c12864 <= c64) return launch<float, 128, 64, AMODE, BMODE, XF>(a, s);
+        if (c12864 <= c64) return launch<float, 128, 64, AMODE, BMODE>(a, s);
     }
-    return launch<float, 64, 64, AMODE, BMODE, XF>(a, s);
+    return launch<float, 64, 64, AMODE, BMODE>(a, s);
 }
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -513,122 +379,28 @@ extern "C" int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------------
-// fused vocab projection + cross entropy (models.py:53 + train.py:53,143-144)
-namespace {
-// per row: combine the (max, sum exp) partials of every (tile column, wave column) into the log-sum-exp; the row loss needs
-// ONE logit (the target's) -- the logits themselves are not re-read
-__global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ part, int nparts, const float* __restrict__ logits,
-                                                         long ldl, const int64_t* __restrict__ targets, int N, int V,
-                                                         float* __restrict__ lse, float* __restrict__ row_loss) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= N) return;
-    const float* pp = part + (long)row * nparts * 2;
-    float m = -INFINITY;
-    for (int i = lane; i < nparts; i += 64) m = fmaxf(m, pp[2 * i]);
-    m = wave_max(m);
-    float s = 0.0f;
-    for (int i = lane; i < nparts; i += 64) {
-        const float pm = pp[2 * i];
-        if (pm > -INFINITY) s += pp[2 * i + 1] * expf(pm - m);
-    }
-    s = wave_sum(s);
-    if (lane == 0) {
-        const float l = m + logf(s);
-        long tg = targets[row];
-        tg = tg < 0 ? 0 : (tg >= V ? V - 1 : tg);          // memory safety only (sat_validate_ids reports bad ids)
-        lse[row] = l;
-        row_loss[row] = l - logits[(long)row * ldl + tg];
-    }
-}
-__global__ __launch_bounds__(256) void sum_scale2_kernel(const float* __restrict__ v, int n, float scale, float* out) {
-    __shared__ float sh[256];
-    float s = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = sh[0] * scale;
-}
-int vocab_bwd_ksplit(int N, int H, int V) {
-    const long tiles = (long)sat_cdiv(N, 64) * sat_cdiv(H, 64);
-    int ks = (int)(512 / (tiles > 0 ? tiles : 1));
-    const int nk = sat_cdiv(V, 32);
-    if (ks > nk / 8) ks = nk / 8;
-    return ks < 1 ? 1 : (ks > 16 ? 16 : ks);
-}
-}  // namespace
-
-extern "C" int64_t sat_vocab_ce_fwd_ws_bytes(int N, int V) {
-    return (int64_t)N * 2 * sat_cdiv(V, 128) * 2 * (int64_t)sizeof(float);
-}
+// vocab projection + cross entropy (models.py:53 + train.py:53,143) as one entry point: the logits GEMM, then the row-wise CE
+// that overwrites the logits with d(loss)/d(logits) -- what the fused trainer does in its f32 mode.  (A form with the
+// log-sum-exp in the GEMM epilogue and the softmax gradient formed inside the gradient GEMMs' operand loads was built in round
+// 2, measured slower -- 6.94 vs 6.70 ms/step, profiles/r02_fused_ce_ab.txt: expf in the epilogue / operand path costs more
+// than the passes over Infinity-Cache-resident logits it saves -- and removed in round 4.)
+extern "C" int sat_vocab_logits_fwd(const float* Hs, const float* w, const float* b, int N, int H, int V, float* logits, int64_t ldl,
+                                    sat_stream_t stream);
+extern "C" int sat_ce_rows(float* logits, int64_t ldl, const int64_t* targets, int N, int V, float inv_denom, int write_grad,
+                           float* row_loss, float* loss_out, sat_stream_t stream);
 
 extern "C" int sat_vocab_ce_fwd(const float* Hs, const float* w, const float* b, const int64_t* targets, int N, int H, int V,
-                                float inv_denom, float* logits, int64_t ldl, float* lse, float* row_loss, float* loss_out,
-                                float* workspace, int64_t ws_bytes, sat_stream_t stream) {
-    if (!Hs || !w || !b || !targets || !logits || !lse || !row_loss || N < 1 || H < 4 || (H & 3) || V < 1 || ldl < V) return SAT_ERR_ARG;
-    if (!workspace || ws_bytes < sat_vocab_ce_fwd_ws_bytes(N, V)) return SAT_ERR_WORKSPACE;
-    if (!aligned16(Hs) || !aligned16(w)) return SAT_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    GemmArgs a = {};
-    a.A = Hs; a.B = w; a.C = logits; a.bias = b;
-    a.M = N; a.N = V; a.K = H; a.lda = H; a.ldb = H; a.ldc = ldl; a.ksplit = 1;
-    a.lse_part = workspace;
-    SAT_TRY((launch<float, 128, 128, AM_ROW, BMODE_NT, 1>(a, s)));
-    const int nparts = 2 * sat_cdiv(V, 128);
-    hipLaunchKernelGGL(ce_combine_kernel, dim3(sat_cdiv(N, 4)), dim3(256), 0, s, workspace, nparts, logits, (long)ldl, targets, N, V, lse, row_loss);
-    SAT_LAUNCH_CHECK();
-    if (loss_out) {
-        hipLaunchKernelGGL(sum_scale2_kernel, dim3(1), dim3(256), 0, s, row_loss, N, inv_denom, loss_out);
-        SAT_LAUNCH_CHECK();
-    }
-    return SAT_OK;
-}
-
-extern "C" int64_t sat_vocab_ce_bwd_fused_ws_bytes(int N, int H, int V) {
-    const int ks = vocab_bwd_ksplit(N, H, V);
-    return ks > 1 ? (int64_t)ks * N * H * (int64_t)sizeof(float) : 0;
-}
-
-extern "C" int sat_sum_slabs_f32(const float* in, int nslab, int64_t slab_stride, int64_t n, float* out, sat_stream_t stream);
-
-extern "C" int sat_vocab_ce_bwd_fused(const float* logits, int64_t ldl, const float* lse, const int64_t* targets, float inv_denom,
-                                      const float* Hs, const float* w, int N, int H, int V, float* dw, float* db, float* dHs,
-                                      float* workspace, int64_t ws_bytes, sat_stream_t stream) {
-    if (!logits || !lse || !targets || !Hs || !w || !dw || !db || !dHs || N < 1) return SAT_ERR_ARG;
-    if ((H & 3) || (ldl & 3) || ldl < ((V + 3) & ~3) || !aligned16(logits) || !aligned16(Hs) || !aligned16(w)) return SAT_ERR_UNSUPPORTED;
-    const int ks = vocab_bwd_ksplit(N, H, V);
-    if (ks > 1 && (!workspace || ws_bytes < sat_vocab_ce_bwd_fused_ws_bytes(N, H, V) || (((long)N * H) & 3))) return SAT_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    // dW[V,H] = dlogits^T Hs with dlogits formed in the operand load; db = its column sums (same launch)
-    GemmArgs a = {};
-    a.A = logits; a.B = Hs; a.C = dw; a.M = V; a.N = H; a.K = N; a.lda = ldl; a.ldb = H; a.ldc = H; a.ksplit = 1;
-    a.lse = lse; a.targets = targets; a.inv_denom = inv_denom; a.xf_cols = V; a.colsum_out = db;
-    SAT_TRY((launch_f32_auto<AM_KM, BMODE_KM, 2>(a, s)));
-    // dHs[N,H] = dlogits W  (K = V is long: split-K slabs summed in fixed order)
-    GemmArgs c = {};
-    c.A = logits; c.B = w; c.M = N; c.N = H; c.K = V; c.lda = ldl; c.ldb = H; c.ldc = H;
-    c.lse = lse; c.targets = targets; c.inv_denom = inv_denom; c.xf_cols = V;
-    if (ks == 1) {
-        c.C = dHs; c.ksplit = 1;
-        return launch_f32_auto<AM_ROW, BMODE_KM, 2>(c, s);
-    }
-    c.C = workspace; c.ksplit = ks; c.slab_stride = (long)N * H;
-    SAT_TRY((launch_f32_auto<AM_ROW, BMODE_KM, 2>(c, s)));
-    return sat_sum_slabs_f32(workspace, ks, (int64_t)N * H, (int64_t)N * H, dHs, stream);
+                                float inv_denom, float* logits, int64_t ldl, float* row_loss, float* loss_out, sat_stream_t stream) {
+    if (!targets || !row_loss || !loss_out) return SAT_ERR_ARG;
+    SAT_TRY(sat_vocab_logits_fwd(Hs, w, b, N, H, V, logits, ldl, stream));
+    return sat_ce_rows(logits, ldl, targets, N, V, inv_denom, 1, row_loss, loss_out, stream);
 }
 
 extern "C" int sat_conv_tiles_m(int64_t M) { return sat_cdiv(M, 128); }
 
 int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s);   // sat_conv_glds.hip
 
-static bool conv_legacy() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SAT_CONV_LEGACY"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+static bool conv_legacy() { return false; }
 
 // SAT_OP_CONV
 int sat_conv_launch(const sat_op* op, int parity, hipStream_t s) {

@@ -374,11 +374,10 @@ int launch_gemm(const bf16_t* A, long lda, const bf16_t* B, long ldb, float* C, 
     const int tm = sat_cdiv(M, 128), tn = sat_cdiv(N, 128);
     a.tiles_n = tn;
     const dim3 grid(tm * tn, sat_cdiv(nk, a.ksteps)), block(512);
-    static const int force_s = getenv("SAT_GEMM_BF16_S") ? atoi(getenv("SAT_GEMM_BF16_S")) : 0;
     // ring depth, measured at cfg 2 (tools/microbench.py gemm16): more workgroups than CUs -> 2 stages (64 KB of LDS: two
     // workgroups per CU, one's f32 epilogue under the other's K loop: logits 29.1 vs 36.3 us, dW 26.4 vs 30.1 us); one round
     // of long-K workgroups -> 3 stages (dHs, split-K 6: 23.5 vs 26.5 us); a 4th stage never paid
-    const int S = force_s ? force_s : ((long)grid.x * grid.y > 256 ? 2 : 3);
+    const int S = (long)grid.x * grid.y > 256 ? 2 : 3;
     if (S == 2) hipLaunchKernelGGL((gemm_bf16_nt_kernel<128, 2>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_bf16_nt_kernel<128, 3>), grid, block, 0, s, a);
     SAT_LAUNCH_CHECK();

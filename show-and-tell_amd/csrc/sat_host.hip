@@ -25,12 +25,9 @@ extern "C" int sat_run_ops(const sat_op* ops, int n_ops, sat_stream_t stream) {
 extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_stream_t stream) {
     if (!ops || n_ops < 0 || (parity != 0 && parity != 1)) return SAT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    // diagnostics only (timing experiments; results are then garbage): SAT_DBG_SKIP_BN_ADD=1 drops every normalise + add + ReLU launch
-    static const int skip_bn_add = getenv("SAT_DBG_SKIP_BN_ADD") ? atoi(getenv("SAT_DBG_SKIP_BN_ADD")) : 0;
     for (int i = 0; i < n_ops; ++i) {
         const sat_op* op = ops + i;
         int rc;
-        if (skip_bn_add && op->kind == SAT_OP_BN_ADD_RELU) continue;
         switch (op->kind) {
             case SAT_OP_IMAGE_PREP: rc = sat_image_prep_launch(op, s); break;
             case SAT_OP_CONV: rc = sat_conv_launch(op, parity, s); break;
@@ -43,7 +40,6 @@ extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_
             case SAT_OP_MAXPOOL2: rc = sat_maxpool2_launch(op, s); break;
             case SAT_OP_MAXPOOL3S2: rc = sat_pool3_launch(op, false, s); break;
             case SAT_OP_AVGPOOL3: rc = sat_pool3_launch(op, true, s); break;
-            case SAT_OP_CONV3_FUSED: rc = sat_conv3_fused_launch(op, parity, s); break;
             default: rc = SAT_ERR_UNSUPPORTED;
         }
         if (rc != SAT_OK) return rc;
@@ -124,7 +120,7 @@ extern "C" int sat_run_ops_timed(const sat_op* ops, int n_ops, int parity, sat_s
     for (int i = 0; i < n_ops && rc == SAT_OK; ++i) {
         const sat_op* op = ops + i;
         op_us[i] = 0.0f;
-        const bool timed = (op->kind == SAT_OP_CONV || op->kind == SAT_OP_CONV3_FUSED) && op->dtype == SAT_BF16 && (op->Cout % 8) == 0;
+        const bool timed = op->kind == SAT_OP_CONV && op->dtype == SAT_BF16 && (op->Cout % 8) == 0;
         if (timed) {
             if (hipEventCreate(&ev[n_ev]) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
             if (hipEventCreate(&ev[n_ev + 1]) != hipSuccess) { (void)hipEventDestroy(ev[n_ev]); rc = SAT_ERR_UNSUPPORTED; break; }
@@ -349,11 +345,9 @@ static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, co
     for (int t = 0; t < T; ++t) N += batch_sizes[t];
     const int nz = lstm_bwd_split(H);
     const long slab = (long)B * H;
-    float* dh_part = workspace;              // [nz][B][H]
-    float* dc_state = workspace + nz * slab; // [B][H]
+    float* dc_state = workspace + nz * slab; // [B][H]  (the nz slabs in front of it: room kept for the split-K GEMMs below)
     hipError_t e = hipMemsetAsync(dc_state, 0, (size_t)slab * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    static const int fused_step = getenv("SAT_LSTM_BWD_FUSED") ? atoi(getenv("SAT_LSTM_BWD_FUSED")) : 1;
     // the recurrence: ONE persistent launch (W_hh in registers, per-group exchange of the d(pre-activation) rows) when every
     // workgroup can be resident and the caller brought the full workspace (its last 64 bytes = the status word); otherwise one
     // launch per step
@@ -377,16 +371,9 @@ static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, co
         off -= n;
         const int n_next = (t + 1 < T) ? batch_sizes[t + 1] : 0;
         const float* cs_prev = (t > 0) ? CS + (off - batch_sizes[t - 1]) * H : nullptr;
-        if (fused_step) {
-            // ONE launch per step: dh_t = dHS_t + DG_{t+1} W_hh (K = 4H inside the workgroup) and the gate backward of step t
-            SAT_TRY(sat_lstm_bwd_step(dHS + off * H, n_next ? DG + (off + n) * 4 * H : nullptr, n_next, w_hh, GA + off * 4 * H,
-                                      CS + off * H, cs_prev, dc_state, DG + off * 4 * H, n, H, s));
-            continue;
-        }
-        SAT_TRY(sat_lstm_bwd_point_launch(dHS + off * H, dh_part, nz, slab, n_next, GA + off * 4 * H, CS + off * H,
-                                          cs_prev, dc_state, DG + off * 4 * H, n, H, s));
-        if (t > 0)   // dh_{t-1} partial slabs = DG_t * W_hh   (K = 4H split over nz workgroup slices)
-            SAT_TRY(sat_skinny_store(DG + off * 4 * H, 4L * H, w_hh, H, 1, n, H, 4 * H, nz, dh_part, H, slab, nullptr, s));
+        // ONE launch per step: dh_t = dHS_t + DG_{t+1} W_hh (K = 4H inside the workgroup) and the gate backward of step t
+        SAT_TRY(sat_lstm_bwd_step(dHS + off * H, n_next ? DG + (off + n) * 4 * H : nullptr, n_next, w_hh, GA + off * 4 * H,
+                                  CS + off * H, cs_prev, dc_state, DG + off * 4 * H, n, H, s));
     }
     // batched weight gradients over all packed rows (the recurrence above is done with the workspace: it is free for
     // split-K slabs when the caller sized it with sat_lstm_bwd_ws_bytes_full)

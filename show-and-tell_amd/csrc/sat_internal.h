@@ -18,13 +18,6 @@ int sat_pool3_launch(const sat_op* op, bool avg, hipStream_t s);
 int64_t sat_gemm_mixed_scratch_bytes(int M, int N, int K);
 int sat_gemm_mixed_nt(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor, float* C, long ldc,
                       const float* bias, const float* bias2, int M, int N, int K, void* scratch, int64_t scratch_bytes, hipStream_t s);
-int sat_conv3_fused_launch(const sat_op* op, int parity, hipStream_t s);
-// one device-wide token for kernels that need ALL their workgroups resident (sat_conv3_fused.hip): acquire ahead of the launch
-// (a one-wave kernel that spins, bounded; `err` receives 2 on a timeout), release behind it
-int sat_resident_token_acquire(unsigned* err, hipStream_t s);
-int sat_resident_token_release(hipStream_t s);
-unsigned long long* sat_dbg_stamps();   // diagnostics: [workgroup][8] u64 device buffer armed by sat_conv3_fused_debug, or NULL
-int sat_resident_token_in_use();      // 0 until a fused conv3 launch has run in this process: nothing to exclude before that
 
 int sat_skinny_store(const float* A, long lda, const float* W, long ldw, int wkm, int M, int N, int K, int nz,
                      float* out, long ldo, long slab_stride, const float* bias, hipStream_t s);

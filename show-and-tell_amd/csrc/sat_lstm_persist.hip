@@ -7,10 +7,13 @@
 //   * a member loads its W_hh slice [64 columns x H] ONCE into registers in MFMA B-operand layout (128 VGPRs at
 //     H = 512) -- the per-step kernels re-read 4 MB of weights from L2 every step;
 //   * per step it needs only its group's h_{t-1} (8 rows x H, 16 KB), not the whole batch: each member publishes its
-//     8 x 16 slice as 8-byte {step tag, value} granules (one relaxed agent-scope = write-through store per value: the
-//     data IS the flag, no fence, no counter -- cdna_hip_programming.md Guideline 16, R2) and sweeps the other
-//     members' granules with agent-scope loads until every tag shows the step; two parity buffers, since a member
-//     can run at most one step ahead of the slowest member of its group;
+//     8 x 16 slice as SELF-TAGGED 4-byte words -- |h| <= 1, so bit 30 of its f32 pattern (the top exponent bit) is always
+//     0 and carries the hand-off phase instead: the data IS the flag (cdna_hip_programming.md Guideline 16, R2) at 4 bytes per
+//     value instead of an 8-byte {tag, value} granule -- written with write-through (sc1) 16-byte stores, and sweeps the
+//     group's [8 rows x H] words with sc1 16-byte loads until every word shows the phase, re-reading only the pieces that
+//     did not (round 4: the exchange moves half the bytes and a quarter of the load instructions; the poll traffic was 9x the
+//     kernel's other bytes, profiles/r03_pmc_traffic.json); two parity buffers, since a member can run at most one step ahead
+//     of the slowest member of its group;
 //   * groups never talk to each other: there is no grid-wide barrier, and a group whose rows have all ended
 //     (packed sequences: batch_sizes[t] shrinks) simply leaves;
 //   * gates = v_mfma_f32_16x16x4_f32 (exact f32: same K permutation on both operands), gate math fused, c_t in a
@@ -37,7 +40,7 @@ struct PersistArgs {
     float* CS;            // [N][H]
     float* HS;            // [N][H]
     float* HP;            // [N][H]  (rows of step 0 pre-zeroed by the host)
-    unsigned long long* xch;   // [2 parities][groups][members][8 rows][16 units] granules, zeroed per call
+    unsigned* xch;        // [2 parities][groups][8 rows][H] self-tagged words, zeroed per call
     unsigned* err;        // sticky timeout word (zeroed per call; the CALLER reads it back: sat_lstm_fwd_status_offset)
     unsigned spin_limit;  // sweeps a workgroup waits for its group before it gives up
     int dbg_stall;        // diagnostics (SAT_LSTM_DEBUG_STALL=1): workgroup 0 never publishes -> its group times out
@@ -47,6 +50,31 @@ struct PersistArgs {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
+
+// 16-byte write-through (sc1) buffer accesses: what `global_load/store_dwordx4 ... sc1` does, with the compiler keeping the
+// wait counts (aux 16 = sc1: the access bypasses this CU's L1 and goes through to memory -- agent-scope visibility)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xch_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));
+}
+__device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, (int)byte_off, 0, 16);
+}
+// hidden-state word <-> self-tagged word: bit 30 of a finite h (|h| <= 1) is 0 and carries the phase; a NaN travels as the
+// pattern of 1.5 (exponent 127 with a non-zero mantissa: no |h| <= 1 has it) so that a diverged run stays a diverged run
+constexpr unsigned kPhaseBit = 0x40000000u, kNanCode = 0x3fc00000u;
+__device__ __forceinline__ unsigned tag_h(float h, unsigned phase) {
+    unsigned b = __float_as_uint(h);
+    if ((b & 0x7f800000u) == 0x7f800000u) b = (b & 0x80000000u) | kNanCode;
+    return (b & ~kPhaseBit) | (phase ? kPhaseBit : 0u);
+}
+__device__ __forceinline__ float untag_h(unsigned w) {
+    w &= ~kPhaseBit;
+    return ((w & 0x7fffffffu) == kNanCode) ? __uint_as_float(0x7fc00000u) : __uint_as_float(w);
+}
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -78,8 +106,9 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
     // epilogue ownership: lanes 0..31 of each wave own (row = lane>>2, unit = u0 + (lane&3)); c lives in a register
     const int erow = lane >> 2, eu = u0 + (lane & 3);
     float c_reg = 0.0f;
-    gu64* xch = (gu64*)p.xch;
-    const long slab = (long)p.members * kRows * kUnits;                  // granules per (parity, group)
+    constexpr unsigned kSlab = kRows * H * 4;                           // bytes per (parity, group): [8 rows][H] words
+    constexpr int NCHUNK = kRows * H / 4;                                // 16-byte pieces of a slab
+    constexpr int NIT = (NCHUNK + 255) / 256;                            // pieces per thread
     const int groups = gridDim.x / p.members;
 
     for (int t = 0; t < p.T; ++t) {
@@ -88,37 +117,34 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
         if (active <= 0) break;                                           // batch_sizes never grow: nothing left for this group
         const int bs_next = (t + 1 < p.T) ? p.prefix[t + 2] - p.prefix[t + 1] : 0;
 
-        // ---- h_{t-1} of my group: sweep every member's granules of step t-1 (tag = t) ----
+        // ---- h_{t-1} of my group: sweep the group's [8 x H] words of step t-1 until every one shows that step's phase ----
         if (t > 0) {
-            const gu64* src = xch + ((long)((t - 1) & 1) * groups + group) * slab;
-            const int n = (int)slab;                                      // members * 128 granules
+            const unsigned phase = (((unsigned)(t - 1) >> 1) & 1u) ^ 1u;    // use k = (t-1)/2 of this parity buffer: 1, 0, 1, ... (zeroed buffer = 0)
+            const __amdgpu_buffer_rsrc_t src = xch_rsrc((const char*)p.xch + ((long)((t - 1) & 1) * groups + group) * kSlab, kSlab);
+            const unsigned want = phase ? kPhaseBit : 0u;
+            unsigned pending = (1u << NIT) - 1u;                          // bit k: piece tid + 256 k not yet seen complete
+#pragma unroll
+            for (int k = 0; k < NIT; ++k)
+                if (tid + k * 256 >= NCHUNK) pending &= ~(1u << k);
             unsigned spins = 0;
             bool fail = false;
             for (;;) {
-                bool ok = true;
-                // 16 granules per lane in flight per round trip (a load that is tested at once would serialise 16 L2 trips)
-                for (int base = 0; base < n; base += 256 * 16) {
-                    unsigned long long x[16];
+                u32x4 x[NIT];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const int i = base + tid + k * 256;
-                        x[k] = i < n ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                     : ((unsigned long long)(unsigned)t << 32);
-                    }
+                for (int k = 0; k < NIT; ++k)                             // all of a thread's pieces in flight together
+                    if (pending & (1u << k)) x[k] = load16_sc1(src, (unsigned)(tid + k * 256) * 16u);
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const int i = base + tid + k * 256;
-                        if ((unsigned)(x[k] >> 32) == (unsigned)t) {
-                            if (i < n) {
-                                const int mem = i >> 7, r = (i >> 4) & 7, u = i & 15;
-                                h_lds[r * HROW + mem * kUnits + u] = __uint_as_float((unsigned)x[k]);
-                            }
-                        } else {
-                            ok = false;
-                        }
+                for (int k = 0; k < NIT; ++k) {
+                    if (!(pending & (1u << k))) continue;
+                    const u32x4 w = x[k];
+                    if (((w[0] & w[1] & w[2] & w[3]) & kPhaseBit) == want && (((w[0] | w[1] | w[2] | w[3]) & kPhaseBit) == want)) {
+                        const int i = tid + k * 256, r = i / (H / 4), c4 = i - r * (H / 4);
+                        f32x4 v = {untag_h(w[0]), untag_h(w[1]), untag_h(w[2]), untag_h(w[3])};
+                        *(f32x4*)(h_lds + r * HROW + c4 * 4) = v;
+                        pending &= ~(1u << k);
                     }
                 }
-                if (__syncthreads_and(ok ? 1 : 0)) break;
+                if (__syncthreads_and(pending == 0u ? 1 : 0)) break;
                 if ((++spins & 63u) == 0) {            // every 64 sweeps: bounded spin + another workgroup's verdict
                     if (tid == 0 && (spins > p.spin_limit ||
                                      __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
@@ -183,12 +209,20 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
                 p.HS[prow * H + eu] = h_new;
                 if (row0 + erow < bs_next) p.HP[((long)p.prefix[t + 1] + row0 + erow) * H + eu] = h_new;
             }
-            // publish h_t of (row, unit) for the group: tag = t + 1 (never 0), parity t & 1
-            if (t + 1 < p.T && !(p.dbg_stall && blockIdx.x == 0)) {
-                gu64* dst = xch + ((long)(t & 1) * groups + group) * slab +
-                            ((long)member * kRows + erow) * kUnits + wave * 4 + (lane & 3);
-                __hip_atomic_store(dst, ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(h_new),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // publish h_t for the group: the wave's 4 units of a row go out as ONE 16-byte write-through store (lane & 3 == 0
+            // collects its three neighbours' words), phase bit = the parity buffer's use count, parity t & 1
+            {
+                const unsigned phase = (((unsigned)t >> 1) & 1u) ^ 1u;
+                const unsigned w0 = tag_h(h_new, phase);
+                u32x4 w;
+                w[0] = w0;
+                w[1] = (unsigned)__shfl_down((int)w0, 1, 64);
+                w[2] = (unsigned)__shfl_down((int)w0, 2, 64);
+                w[3] = (unsigned)__shfl_down((int)w0, 3, 64);
+                if ((lane & 3) == 0 && t + 1 < p.T && !(p.dbg_stall && blockIdx.x == 0)) {
+                    const __amdgpu_buffer_rsrc_t dst = xch_rsrc((const char*)p.xch + ((long)(t & 1) * groups + group) * kSlab, kSlab);
+                    store16_sc1(dst, (unsigned)(erow * H + u0) * 4u, w);
+                }
             }
         }
         __syncthreads();         // c_lds / h_lds are rewritten by the next step
@@ -291,24 +325,30 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(const PersistBwdA
             const int q = tid >> 7, cell = tid & 127;
             unsigned spins = 0;
             bool fail = false;
+            static_assert(NKB <= 32, "one 16-granule batch per thread half");
+            // granule k of this thread: source member q + 2k.  A sweep re-reads only the granules that have not shown the tag yet
+            // (their values stay in registers), so a hand-off that arrives piecemeal costs its bytes once, not once per sweep
+            unsigned long long x[16];
+            unsigned pending = 0u;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (q + 2 * k < NKB) pending |= 1u << k;
             for (;;) {
-                bool ok = true;
-                float sum = 0.0f;
-                for (int m0 = 0; m0 < NKB; m0 += 32) {
-                    unsigned long long x[16];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const int m = m0 + q + 2 * k;
-                        x[k] = m < NKB ? __hip_atomic_load(src + (long)m * pair + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                       : ((unsigned long long)want << 32);
-                    }
+                for (int k = 0; k < 16; ++k)
+                    if (pending & (1u << k))
+                        x[k] = __hip_atomic_load(src + (long)(q + 2 * k) * pair + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        if ((unsigned)(x[k] >> 32) != want) ok = false;
-                        sum += __uint_as_float((unsigned)x[k]);
-                    }
+                for (int k = 0; k < 16; ++k)
+                    if ((pending & (1u << k)) && (unsigned)(x[k] >> 32) == want) pending &= ~(1u << k);
+                if (__syncthreads_and(pending == 0u ? 1 : 0)) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)                      // fixed order over the source members: bitwise reproducible
+                        if (q + 2 * k < NKB) sum += __uint_as_float((unsigned)x[k]);
+                    rec = sum;
+                    break;
                 }
-                if (__syncthreads_and(ok ? 1 : 0)) { rec = sum; break; }
                 if ((++spins & 63u) == 0) {
                     if (tid == 0 && (spins > p.spin_limit ||
                                      __hip_atomic_load((gu32*)p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
@@ -392,7 +432,7 @@ bool sat_lstm_persist_has(int H);
 extern "C" int64_t sat_lstm_fwd_ws_bytes(int B, int H) {
     if (H < 16 || (H % 16)) return 0;
     const int64_t groups = (B + kRows - 1) / kRows, members = H / kUnits;
-    return 2 * groups * members * kRows * kUnits * 8 + 64;
+    return 2 * groups * members * kRows * kUnits * 4 + 64;
 }
 
 // Byte offset of the recurrence's STATUS WORD (u32) inside the sat_lstm_fwd workspace: 0 after a clean run, non-zero when a
@@ -428,7 +468,7 @@ int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, flo
     if (!workspace || ws_bytes < need) return SAT_ERR_WORKSPACE;
     PersistArgs a = {};
     a.GA = GA; a.W = W; a.CS = CS; a.HS = HS; a.HP = HP;
-    a.xch = (unsigned long long*)workspace;
+    a.xch = (unsigned*)workspace;
     a.err = (unsigned*)((char*)workspace + (need - 64));
     a.H = H; a.T = T; a.B = B; a.members = members;
     const char* sl = getenv("SAT_LSTM_SPIN_LIMIT");
@@ -439,21 +479,16 @@ int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, flo
     for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
     hipError_t e = hipMemsetAsync(workspace, 0, (size_t)need, s);
     if (e != hipSuccess) return (int)e;
-    // all workgroups must be resident together: run under the process-wide residency token (sat_conv3_fused.hip) so that no other
-    // spinning kernel of this process (the fused conv3 launches of the look-ahead streams) holds CUs this grid is waiting for
-    const bool token = sat_resident_token_in_use() != 0;
-    if (token) SAT_TRY(sat_resident_token_acquire(a.err, s));
+    // (all workgroups must be resident together; the only other kernels of this library that spin are this one's own instances)
     const dim3 grid(groups * members), block(256);
     switch (H / 16) {
 #define SAT_PERSIST_CASE(n) case n: hipLaunchKernelGGL((lstm_persist_kernel<n>), grid, block, 0, s, a); break;
         SAT_PERSIST_CASE(2) SAT_PERSIST_CASE(4) SAT_PERSIST_CASE(6) SAT_PERSIST_CASE(8) SAT_PERSIST_CASE(16) SAT_PERSIST_CASE(32)
 #undef SAT_PERSIST_CASE
-        default:
-            if (token) (void)sat_resident_token_release(s);
-            return SAT_ERR_UNSUPPORTED;
+        default: return SAT_ERR_UNSUPPORTED;
     }
     SAT_LAUNCH_CHECK();
-    return token ? sat_resident_token_release(s) : SAT_OK;
+    return SAT_OK;
 }
 
 // granule exchange of the persistent BACKWARD recurrence (+ 64 bytes for its status word)
@@ -498,19 +533,15 @@ int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* 
         e = hipMemsetAsync(xch, 0, (size_t)(sat_lstm_persist_bwd_ws_bytes(B, H) - 64), s);
         if (e != hipSuccess) return (int)e;
     }
-    const bool token = sat_resident_token_in_use() != 0;
-    if (token) SAT_TRY(sat_resident_token_acquire(a.err, s));
     const dim3 grid(groups * members), block(256);
     switch (H / 16) {
 #define SAT_PERSIST_CASE(n) case n: hipLaunchKernelGGL((lstm_persist_bwd_kernel<n>), grid, block, 0, s, a); break;
         SAT_PERSIST_CASE(2) SAT_PERSIST_CASE(4) SAT_PERSIST_CASE(6) SAT_PERSIST_CASE(8) SAT_PERSIST_CASE(16) SAT_PERSIST_CASE(32)
 #undef SAT_PERSIST_CASE
-        default:
-            if (token) (void)sat_resident_token_release(s);
-            return SAT_ERR_UNSUPPORTED;
+        default: return SAT_ERR_UNSUPPORTED;
     }
     SAT_LAUNCH_CHECK();
-    return token ? sat_resident_token_release(s) : SAT_OK;
+    return SAT_OK;
 }
 
 bool sat_lstm_persist_has(int H) {

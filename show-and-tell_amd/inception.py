@@ -112,6 +112,7 @@ class InceptionProgram(ConvStackProgram):
 
     def __init__(self, stack, N, H, W, dtype, training, device):
         self.N, self.H, self.W, self.dtype, self.training, self.stack = N, H, W, dtype, training, stack
+        self.groups, self._n_prep = 1, 1                   # one batch per launch; ops[0] is the image prep (ConvStackProgram.run)
         self.keep, self.bn_list = [], []
         td = torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
         esz = 2 if dtype == L.SAT_BF16 else 4

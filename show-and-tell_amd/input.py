@@ -87,13 +87,19 @@ class DevicePrefetcher:
             ev.record(self.stream)
         return (d_images, d_captions) + tuple(batch[2:]), ev
 
-    def upcoming_images(self):
+    def upcoming_images(self, wait=False):
         """device image tensors of the staged batches that follow the one just yielded.  Their H2D copies may still be in
-        flight: each tensor carries its copy-done event (`_sat_ready_event`), which `EncoderCNN.prefetch` makes ITS side stream
-        wait for -- the caller's compute stream is not held up by copies of batches it will only consume later; it
-        waits for a batch's copy when `__iter__` yields that batch."""
+        flight.  wait=False (what the encoder look-ahead wants): each tensor carries its copy-done event (`_sat_ready_event`),
+        which `EncoderCNN.prefetch` / `prefetch_many` make THEIR side stream wait for -- the caller's compute stream is not held
+        up by copies of batches it will only consume later; it waits for a batch's copy when `__iter__` yields that
+        batch.  Hand such tensors to nothing but the look-ahead.  wait=True: the current stream waits for every staged copy
+        first, so the tensors are safe for ANY use on it."""
         out = []
+        cur = torch.cuda.current_stream(self.device) if wait else None
         for staged, ev in self._queue:
+            if wait:
+                cur.wait_event(ev)
+                staged[0].record_stream(cur)
             staged[0]._sat_ready_event = ev
             out.append(staged[0])
         return out

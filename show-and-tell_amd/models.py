@@ -20,10 +20,9 @@ import torch.nn as nn
 
 from . import _lib as L
 from .pack import PackInfo
-from .resnet import RESNET152, ConvStackProgram, ResNetStack, fused_conv3_enabled, weights_signature
+from .resnet import RESNET152, ConvStackProgram, ResNetStack, weights_signature
 from .watch import ResidencyWatch
 
-_LSTM_SPLITK = os.environ.get("SAT_LSTM_SPLITK", "1") != "0"   # roomy LSTM-backward workspace => split-K dW_ih / dX GEMMs
 BN1D_MOMENTUM = 0.01   # models.py:17
 BN_EPS = 1e-5
 
@@ -117,8 +116,14 @@ class EncoderCNN(nn.Module):
             self.resnet = ResNetStack(embed_size, arch)     # frozen stack + trainable fc (models.py:13-16)
         self.bn = _BN1d(embed_size)                         # models.py:17
         self.compute_dtype = compute_dtype
+        # GROUPED look-ahead (ResNet stacks, bf16, train mode): `lookahead_groups` = G later batches run as ONE op program
+        # (`ConvStackProgram(groups=G)`: every launch covers G batches, per-batch BatchNorm statistics, results bit-identical per
+        # batch) -- half the launch boundaries and twice the workgroups per launch of the frozen stack.  1 = one program per batch.
+        env_g = os.environ.get("SAT_LOOKAHEAD_GROUPS")
+        self.lookahead_groups = max(1, int(env_g)) if env_g else (1 if isinstance(arch, str) else self.LOOKAHEAD_GROUPS)
         env = os.environ.get("SAT_LOOKAHEAD_DEPTH")
-        self.lookahead_depth = int(env) if env else self.LOOKAHEAD_DEPTH.get(arch if isinstance(arch, str) else "", 3)
+        self.lookahead_depth = int(env) if env else self.LOOKAHEAD_DEPTH.get(arch if isinstance(arch, str) else "",
+                                                                              3 * self.lookahead_groups)
         # side streams the stacks in flight are spread over (round robin in prefetch order); None = one per stack in flight.  Fewer
         # streams than stacks queue a later batch's stack BEHIND an earlier one's on the same hardware queue (it starts the moment
         # that one ends, without waiting for the host) -- for steps that need a hardware queue for something else (RCCL: trainer.py)
@@ -126,7 +131,7 @@ class EncoderCNN(nn.Module):
         self.lookahead_streams = int(env_s) if env_s else None
         self._pf_seq = 0
         self._programs = {}      # insertion-ordered: least recently used first (`_program` re-inserts on a hit)
-        self._inflight = []      # look-ahead (prefetch): [(images, instance, event, program, weights signature, images._version)]
+        self._inflight = []      # look-ahead (prefetch): [dict(images, taken, inst, ev, prog, sig, vers)], one per program run in flight
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
         # `encoder.resnet.load_state_dict(torchvision_sd)` -- the natural way to load the pretrained ResNet-152 the
         # reference uses (models.py:13) -- does not fire the parent's hook: hook the stack too
@@ -153,13 +158,14 @@ class EncoderCNN(nn.Module):
         self._invalidate()          # device / dtype moves invalidate cached device pointers
         return super()._apply(fn, *a, **k)
 
-    def _program(self, images, instance=None):
+    def _program(self, images, instance=None, groups=1):
         """instance None: the program `forward` runs (updates running statistics itself).  instance 0, 1, ...: independent
         copies (own activations, statistics accumulators, graphs) with DEFERRED running-statistics updates, for batches in
-        flight next to each other on side streams (TrainStep.prefetch_encoder)."""
+        flight next to each other on side streams (TrainStep.prefetch_encoder); groups > 1: a copy that runs that many batches
+        per launch (`prefetch_many`)."""
         N, _, H, W = images.shape
         dt = L.SAT_BF16 if self.compute_dtype == "bf16" else L.SAT_F32
-        key = (N, H, W, dt, self.training, str(images.device), weights_signature(self.resnet), instance, fused_conv3_enabled())
+        key = (N, H, W, dt, self.training, str(images.device), weights_signature(self.resnet), instance, groups)
         prog = self._programs.pop(key, None)
         if prog is not None:
             self._programs[key] = prog                      # most recently used last
@@ -170,12 +176,15 @@ class EncoderCNN(nn.Module):
             cap = 2 * (self.lookahead_depth + 1) + 2
             while len(self._programs) >= cap:
                 old = next(iter(self._programs))
-                if any(e[3] is self._programs[old] for e in self._inflight):
+                if any(e["prog"] is self._programs[old] for e in self._inflight):
                     break                                   # never evict a program with a batch in flight
                 del self._programs[old]
             make = getattr(self.resnet, "program", None)
-            prog = self._programs[key] = (make(N, H, W, dt, self.training, images.device) if make is not None else
-                                          ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device))
+            if make is not None:
+                prog = make(N, H, W, dt, self.training, images.device)
+            else:
+                prog = ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device, groups=groups)
+            self._programs[key] = prog
             if instance is not None:
                 prog.defer_running_stats()
         return prog
@@ -185,55 +194,112 @@ class EncoderCNN(nn.Module):
     # 8 hardware queues; 4.86 with HIP's default 4, where the third stream shares a queue)
     # whole ResNet-152 step: 5.25 ms at depth 2, 5.10 at depth 3, 5.38 at depth 4; Inception-v3 299x299: 5.68 at 2, 5.98 at 3
     LOOKAHEAD_DEPTH = {"inception_v3": 2}
+    LOOKAHEAD_GROUPS = 2
+
+    def _side_stream(self, device, slot, n_slots):
+        """side stream of look-ahead slot `slot` of `n_slots`: one per slot, or -- `lookahead_streams` fewer than slots -- round
+        robin in prefetch order (a later stack then queues behind an earlier one on its hardware queue)"""
+        n_streams = self.lookahead_streams or n_slots
+        idx = slot if n_streams >= n_slots else self._pf_seq % n_streams
+        self._pf_seq += 1
+        return lookahead_stream(device, idx)
+
+    def _batches_in_flight(self):
+        return sum(len(e["images"]) for e in self._inflight)
+
+    def _is_in_flight(self, images):
+        return any(im is images for e in self._inflight for im in e["images"])
+
+    def _launch(self, ims, inst, groups, n_slots):
+        dev = ims[0].device
+        stream = self._side_stream(dev, inst if isinstance(inst, int) else int(inst[1:]), n_slots)
+        stream.wait_stream(torch.cuda.current_stream(dev))             # the images, and this instance's previous consumers
+        for im in ims:
+            ready = getattr(im, "_sat_ready_event", None)              # a DevicePrefetcher copy still in flight on its own stream
+            if ready is not None:
+                stream.wait_event(ready)
+        with torch.cuda.stream(stream), torch.no_grad():
+            prog = self._program(ims[0], instance=inst, groups=groups)
+            prog.run(ims if groups > 1 else ims[0])
+            for im in ims:
+                im.record_stream(stream)                               # the side stream reads the tensor: the allocator must know
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._inflight.append(dict(images=list(ims), taken=[False] * len(ims), inst=inst, ev=ev, prog=prog,
+                                   sig=weights_signature(self.resnet), vers=[im._version for im in ims]))
 
     def prefetch(self, images):
         """Start the conv stack (frozen, `no_grad`: models.py:14-15, 25-27) of a LATER batch on a side stream.  Its pooled
         features depend on the images and the frozen weights only, not on the optimizer steps in between, so computing them
-        early changes nothing but the schedule: up to `lookahead_depth` (3; Inception 2) stacks run next to each other (one's HBM-bound
+        early changes nothing but the schedule: up to `lookahead_depth` stacks run next to each other (one's HBM-bound
         BatchNorm passes and under-filled launches under the other's convs) and under the current batch's head / decoder /
         backward / optimizer.  Each batch keeps its own BatchNorm batch statistics (separate program instances); the model's
         running statistics are updated when the batch is consumed, i.e. in batch order.  `forward(images)` /
         `pooled_features(images)` / `TrainStep.step(images, ...)` of the SAME tensor object later picks the result up.
         Returns False (and does nothing) when the tensor is already in flight or `lookahead_depth` batches are."""
-        if images is None or images.dim() != 4 or any(e[0] is images for e in self._inflight):
+        if images is None or images.dim() != 4 or self._is_in_flight(images):
             return False
-        if len(self._inflight) >= self.lookahead_depth:
+        if self._batches_in_flight() >= self.lookahead_depth:
             return False
         L.require_gpu(images, "images")
-        busy = {e[1] for e in self._inflight}
+        busy = {e["inst"] for e in self._inflight}
         inst = next(i for i in range(self.lookahead_depth) if i not in busy)
-        n_streams = self.lookahead_streams or self.lookahead_depth
-        stream = lookahead_stream(images.device, inst if n_streams >= self.lookahead_depth else self._pf_seq % n_streams)
-        self._pf_seq += 1
-        stream.wait_stream(torch.cuda.current_stream(images.device))   # the images, and this instance's previous consumer
-        ready = getattr(images, "_sat_ready_event", None)              # a DevicePrefetcher copy still in flight on its own stream
-        if ready is not None:
-            stream.wait_event(ready)
-        with torch.cuda.stream(stream), torch.no_grad():
-            prog = self._program(images, instance=inst)
-            prog.run(images)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-        self._inflight.append((images, inst, ev, prog, weights_signature(self.resnet), images._version))
+        self._launch([images], inst, 1, self.lookahead_depth)
         return True
 
+    def prefetch_many(self, images_list):
+        """`prefetch` for the next few batches IN ORDER.  With `lookahead_groups` = G > 1 (ResNet, bf16, train mode) G batches
+        that are not in flight yet start together as ONE grouped program (every launch of the stack covers G batches; each
+        batch's statistics and features are bit for bit those of its own ungrouped run); a batch left over is started alone
+        only when it is the very next one.  Returns the number of batches started."""
+        ims = [im for im in images_list if im is not None and im.dim() == 4]
+        G = self.lookahead_groups if (self.training and self.compute_dtype == "bf16" and not hasattr(self.resnet, "program")) else 1
+        started = 0
+        new = [im for im in ims if not self._is_in_flight(im)]
+        if G > 1:
+            n_slots = max(1, self.lookahead_depth // G)
+            while len(new) >= G and self._batches_in_flight() + G <= self.lookahead_depth:
+                grp = new[:G]
+                if len({tuple(im.shape) for im in grp}) != 1 or len({id(im) for im in grp}) != G:
+                    break                                               # ragged last batch / the same tensor twice: singles below
+                busy = {e["inst"] for e in self._inflight}
+                free = [k for k in range(n_slots) if ("g%d" % k) not in busy]
+                if not free:
+                    break
+                for im in grp:
+                    L.require_gpu(im, "images")
+                self._launch(grp, "g%d" % free[0], G, n_slots)
+                new = new[G:]
+                started += G
+            if new and ims and new[0] is ims[0] and self.prefetch(new[0]):      # the next batch must not wait for a partner
+                started += 1
+            return started
+        for im in new:
+            started += 1 if self.prefetch(im) else 0
+        return started
+
     def _take_prefetched(self, images):
-        """The finished program instance of a prefetched `images` (the current stream now waits for it), or None.  The caller
-        reads `prog.pooled` and then calls `prog.apply_running_stats()` -- both on the current stream."""
-        for k, (im, inst, ev, prog, sig, ver) in enumerate(self._inflight):
-            if im is images:
-                del self._inflight[k]
-                torch.cuda.current_stream(images.device).wait_event(ev)
-                # conv weights rewritten since (version counters): the stack in flight used the old ones -> recompute;
-                # the same for the IMAGES: a staging buffer refilled in place (copy_, normal_, ...) between prefetch and
-                # forward is the same tensor object with other contents (its version counter moved)
-                return prog if (sig == weights_signature(self.resnet) and ver == images._version) else None
+        """(program instance, group index) of a prefetched `images` whose run has finished (the current stream now waits for
+        it), or None.  The caller reads `prog.pooled_of(g)` and then calls `prog.apply_running_stats(g)` -- both on the current
+        stream."""
+        for k, e in enumerate(self._inflight):
+            for g, im in enumerate(e["images"]):
+                if im is images and not e["taken"][g]:
+                    e["taken"][g] = True
+                    if all(e["taken"]):
+                        del self._inflight[k]
+                    torch.cuda.current_stream(images.device).wait_event(e["ev"])
+                    # conv weights rewritten since (version counters): the stack in flight used the old ones -> recompute;
+                    # the same for the IMAGES: a staging buffer refilled in place (copy_, normal_, ...) between prefetch and
+                    # forward is the same tensor object with other contents (its version counter moved)
+                    ok = e["sig"] == weights_signature(self.resnet) and e["vers"][g] == images._version
+                    return (e["prog"], g) if ok else None
         return None
 
     def drop_lookahead(self):
         """Forget batches in flight (their results are discarded; the model's running statistics never see them)."""
         for e in self._inflight:
-            e[2].synchronize()
+            e["ev"].synchronize()
         self._inflight = []
 
     def refresh_weights(self):
@@ -251,10 +317,11 @@ class EncoderCNN(nn.Module):
     def pooled_features(self, images):
         """conv stack + global average pool: f32 [B, 2048] (no autograd: the stack is frozen, models.py:14-15).
         Returns a tensor the caller owns (a copy of the program's output buffer, B x 2048 f32)."""
-        prog = self._take_prefetched(images)
-        if prog is not None:
-            out = prog.pooled.clone()
-            prog.apply_running_stats()              # batch order = consumption order
+        hit = self._take_prefetched(images)
+        if hit is not None:
+            prog, g = hit
+            out = prog.pooled_of(g).clone()
+            prog.apply_running_stats(g)             # batch order = consumption order
             return out
         return self._pooled_raw(images).clone()
 
@@ -378,8 +445,8 @@ class _Weight(nn.Module):
 def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, captions, pi, logits=None, ce=None, mixed_ws=None,
                           lstm_ws=None):
     """embed+cat+pack -> L x LSTM -> vocab logits (models.py:49-53).  Returns (logits, tapes).
-    `ce` = dict(targets, inv_denom, lse, row_loss, loss_out, ws): the projection and the cross entropy (train.py:143) run as
-    ONE fused op (`sat_vocab_ce_fwd`: the loss never re-reads the logits).
+    `ce` = dict(kind="bf16", targets, inv_denom, row_loss, loss_out, ws): the projection on the bf16 matrix pipe and the cross
+    entropy (train.py:143) as one call (`sat_vocab_ce_fwd_bf16`), d(loss)/d(logits) left in `ws` for the backward.
     `lstm_ws`: per layer (forward workspace, backward workspace) uint8 tensors the CALLER owns and watches (`TrainStep`: it
     folds their status words into its step's fault flag); None: workspaces of this module, each call's status word handed to
     `watch.ResidencyWatch`."""
@@ -433,11 +500,6 @@ def decoder_forward_tapes(lib, features, embed_w, lstm_layers, lin_w, lin_b, cap
                                           float(ce["inv_denom"]), L.ptr(logits), logits.stride(0), L.ptr(ce["row_loss"]),
                                           L.ptr(ce["loss_out"]), L.ptr(ce["ws"]), ce["ws"].numel(), st), "sat_vocab_ce_fwd_bf16")
         return logits, tapes
-    if ce is not None:
-        L.check(lib.sat_vocab_ce_fwd(L.ptr(inp), L.ptr(lin_w), L.ptr(lin_b), L.ptr(ce["targets"]), N, lin_w.shape[1], V,
-                                     float(ce["inv_denom"]), L.ptr(logits), logits.stride(0), L.ptr(ce["lse"]), L.ptr(ce["row_loss"]),
-                                     L.ptr(ce["loss_out"]), L.ptr(ce["ws"]), ce["ws"].numel() * 4, st), "sat_vocab_ce_fwd")
-        return logits, tapes
     L.check(lib.sat_vocab_logits_fwd(L.ptr(inp), L.ptr(lin_w), L.ptr(lin_b), N, lin_w.shape[1], V, L.ptr(logits),
                                      logits.stride(0), st), "sat_vocab_logits_fwd")
     return logits, tapes
@@ -458,13 +520,6 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
     if ce is not None and ce.get("kind") == "bf16":
         L.check(lib.sat_vocab_ce_bwd_bf16(N, Hl, V, L.ptr(grads_out["lin_w"]), L.ptr(grads_out["lin_b"]), L.ptr(dH), L.ptr(ce["ws"]),
                                           ce["ws"].numel(), st), "sat_vocab_ce_bwd_bf16")
-    elif ce is not None:
-        # `dlogits` holds the LOGITS: d(loss)/d(logits) is formed inside the two gradient GEMMs' operand loads (never stored)
-        vwsb = lib.sat_vocab_ce_bwd_fused_ws_bytes(N, Hl, V)
-        vws = torch.empty(max(vwsb // 4, 4), device=dev)
-        L.check(lib.sat_vocab_ce_bwd_fused(L.ptr(dlogits), dlogits.stride(0), L.ptr(ce["lse"]), L.ptr(ce["targets"]), float(ce["inv_denom"]),
-                                           L.ptr(Xtop), L.ptr(lin_w), N, Hl, V, L.ptr(grads_out["lin_w"]), L.ptr(grads_out["lin_b"]),
-                                           L.ptr(dH), L.ptr(vws), vwsb, st), "sat_vocab_ce_bwd_fused")
     else:
         vwsb = lib.sat_vocab_ce_bwd_ws_bytes(N, Hl, V)
         vws = torch.empty(max(vwsb // 4, 4), device=dev)
@@ -478,13 +533,10 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
         GA, CS, HP = tapes["layers"][l]
         DG = torch.empty(N, 4 * H, device=dev)
         dX = torch.empty(N, In, device=dev)
-        wsb = lib.sat_lstm_bwd_ws_bytes_full(N, B, In, H) if _LSTM_SPLITK else lib.sat_lstm_bwd_ws_bytes(B, H)
-        if lstm_ws is not None:
-            ws = lstm_ws[l][1]
-        elif _LSTM_SPLITK:                     # the full workspace must be zero before its first use and ours alone (sat_hip.h)
-            ws = _persistent_ws(dev, wsb, ("lstm_bwd", l))
-        else:
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        # the FULL workspace (split-K weight-gradient GEMMs + the persistent backward recurrence): it must be zero before its
+        # first use and ours alone (sat_hip.h)
+        wsb = lib.sat_lstm_bwd_ws_bytes_full(N, B, In, H)
+        ws = lstm_ws[l][1] if lstm_ws is not None else _persistent_ws(dev, wsb, ("lstm_bwd", l))
         if mixed_ws is not None:
             L.check(lib.sat_lstm_bwd_bf16(L.ptr(dH), L.ptr(tapes["X"][l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(GA), L.ptr(CS),
                                           L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
@@ -496,7 +548,7 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
                                      L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
                                      L.ptr(grads_out[("w_hh", l)]), L.ptr(grads_out[("b_ih", l)]),
                                      L.ptr(grads_out[("b_hh", l)]), L.ptr(dX), L.ptr(ws), wsb, st), "sat_lstm_bwd")
-        if _LSTM_SPLITK and lstm_ws is None:   # full workspace: the backward recurrence may have run persistently -- its status word
+        if lstm_ws is None:                    # the backward recurrence may have run persistently: its status word
             _watch_lstm(dev, ws, lib.sat_lstm_bwd_status_offset(N, B, In, H))
         dH = dX
     if on_stage is not None:

@@ -22,12 +22,6 @@ from .pack import PackInfo
 
 import os as _os
 
-# SAT_FUSED_CE=1: projection + CE as ONE op (sat_vocab_ce_fwd: the loss never re-reads the logits) and a backward that never
-# materialises d(loss)/d(logits) (sat_vocab_ce_bwd_fused).  Built, parity-tested and measured -- and OFF by default: at cfg 2
-# the 48.6 MB of logits live in the 256 MB Infinity Cache, so the passes the fusion removes cost ~10 us each (ce_rows 23 us,
-# colsum 15 us), while exp() in the epilogue / operand path costs the three GEMMs +65 / +113 / +49 us (6.94 vs 6.70 ms/step,
-# profiles/r02_fused_ce_ab.txt).  Default: logits -> sat_ce_rows (gradient in place) -> sat_vocab_ce_bwd.
-_FUSED_CE = _os.environ.get("SAT_FUSED_CE", "0") == "1"
 # bf16 throughput mode (compute_dtype="bf16", BASELINE configs[1]): the vocab projection and its two gradient GEMMs run on the
 # bf16 matrix pipe from per-step bf16 operand copies (sat_gemm_bf16.hip; f32 accumulate, f32 logits / CE / outputs / master
 # weights).  SAT_DECODER_BF16=0 keeps them exact-f32 as in the parity mode (round 2's behaviour: 0.39 ms/step instead of ~0.1).
@@ -117,15 +111,26 @@ class TrainStep:
         flight next to each other and under this batch's decoder work; bitwise identical results)."""
         return self.model.encoder.prefetch(images)
 
-    def _encoder_pooled(self, images, out):
+    def _encoder_pooled(self, images, out, next_images=None):
         """pooled features [B, F] of `images` into `out` (a buffer this step owns): from the look-ahead if this tensor was
-        prefetched, computed now otherwise."""
+        prefetched, computed now otherwise.  `next_images`: the following batches -- their stacks are started on side streams
+        (`EncoderCNN.prefetch_many`): BEFORE this batch's own stack when that still has to run (the first step of a loop: the
+        look-ahead then fills the chip next to it instead of waiting for it), behind the hand-over otherwise (the instance this
+        batch frees is available to them)."""
         enc = self.model.encoder
-        prog = enc._take_prefetched(images)
-        if prog is not None:
-            out.copy_(prog.pooled)
-            prog.apply_running_stats()          # batch order = consumption order
+        nxt = None
+        if next_images is not None:
+            nxt = list(next_images) if isinstance(next_images, (list, tuple)) else [next_images]
+        hit = enc._take_prefetched(images)
+        if hit is not None:
+            prog, g = hit
+            out.copy_(prog.pooled_of(g))
+            prog.apply_running_stats(g)         # batch order = consumption order
+            if nxt:
+                enc.prefetch_many(nxt)
             return out
+        if nxt:
+            enc.prefetch_many(nxt)
         out.copy_(enc._pooled_raw(images))
         return out
 
@@ -169,8 +174,7 @@ class TrainStep:
             wsb = lib.sat_fc_bn1d_ws_bytes(B, F, E)
             bufs = self._bufs[key] = dict(
                 targets=torch.empty(N, dtype=torch.int64, device=dev), logits=torch.zeros(N, (V + 3) // 4 * 4, device=dev),
-                row_loss=torch.empty(N, device=dev), lse=torch.empty(N, device=dev),
-                ce_ws=torch.empty(max(lib.sat_vocab_ce_fwd_ws_bytes(N, V) // 4, 4), device=dev), feats=torch.empty(B, E, device=dev),
+                row_loss=torch.empty(N, device=dev), feats=torch.empty(B, E, device=dev),
                 xhat=torch.empty(B, E, device=dev), rstd=torch.empty(E, device=dev),
                 head_ws=torch.empty(max(wsb // 4, B * E), device=dev), d_feat=torch.empty(B, E, device=dev),
                 pooled=torch.empty(B, F, device=dev))
@@ -200,10 +204,7 @@ class TrainStep:
             feats_in = images.contiguous()
             pooled = None
         else:
-            pooled = self._encoder_pooled(images, bufs["pooled"])
-            if next_images is not None:
-                for nxt in (next_images if isinstance(next_images, (list, tuple)) else (next_images,)):
-                    self.prefetch_encoder(nxt)
+            pooled = self._encoder_pooled(images, bufs["pooled"], next_images)
             F = pooled.shape[1]
             fc, bn = enc.resnet.fc, enc.bn
             L.check(lib.sat_fc_bn1d_fwd(L.ptr(pooled), L.ptr(fc.weight), L.ptr(fc.bias), L.ptr(bn.weight), L.ptr(bn.bias),
@@ -222,9 +223,6 @@ class TrainStep:
                     bufs["vocab_bf16_ws"] = torch.empty(wsb, dtype=torch.uint8, device=dev)
                 ce = dict(kind="bf16", targets=bufs["targets"], inv_denom=inv_denom, row_loss=bufs["row_loss"], loss_out=loss_slot,
                           ws=bufs["vocab_bf16_ws"])
-        if ce is None and _FUSED_CE:          # projection + CE as one op; the backward forms d(loss)/d(logits) inside its GEMMs
-            ce = dict(kind="fused", targets=bufs["targets"], inv_denom=inv_denom, lse=bufs["lse"], row_loss=bufs["row_loss"], loss_out=loss_slot,
-                      ws=bufs["ce_ws"])
         mixed_ws = None
         if self.decoder_gemm_dtype == "bf16":          # the LSTM layers' batched GEMMs on the bf16 matrix pipe too
             if "lstm_mixed_ws" not in bufs:
@@ -408,15 +406,10 @@ class DataParallelStep:
         self.engine = engine
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        # How the bucket all-reduces overlap the rest of the backward.  "c10d" (default): async_op=True + work.wait() before clamp +
-        # Adam.  "stream" (SAT_DP_OVERLAP=stream): a communication stream of our own that waits for the bucket's gradients, issues
-        # the collective synchronously and is waited for once.  Measured on ONE rank, where RCCL launches no kernel
-        # (tools/dp_overhead.py, bench.py --force-dist): any DEFERRED wait costs 0.4-0.5 ms of a 4.5 ms step (4.87 / 4.96 ms for
-        # c10d / stream against 4.49 without collective calls), whatever the bucket count (1 or 3) or the hardware-queue count;
-        # waiting at once (async_op=False on the compute stream) costs nothing (4.41) but would expose the whole exchange with
-        # N > 1.  Not resolvable without N > 1 hardware: the default stays the overlapping form.
-        self.mode = _os.environ.get("SAT_DP_OVERLAP", "c10d")
-        self._comm_stream = None
+        # The bucket all-reduces overlap the rest of the backward: c10d `async_op=True` as each bucket's gradients become final,
+        # `wait()` before clamp + Adam.  (Measured on ONE rank, where RCCL launches no kernel -- bench.py --force-dist, round 3: any
+        # DEFERRED wait costs 0.4-0.5 ms of a 4.5 ms step, whatever the form -- a communication stream of our own, one bucket or
+        # three -- while waiting at once would expose the whole exchange with N > 1; those variants were removed in round 4.)
         if self.world > 1:
             self.cap_lookahead()
 
@@ -436,42 +429,17 @@ class DataParallelStep:
         eng, dist = self.engine, self.dist
         works = []
 
-        single = _os.environ.get("SAT_DP_SINGLE_BUCKET", "0") == "1"      # experiment: ONE all-reduce of the whole flat gradient at the end
-
-        use_stream = self.mode == "stream" and self.world > 1 and eng.flat_grad.is_cuda
-        if use_stream and self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=eng.flat_grad.device)
-        comm = self._comm_stream
-
         def ready(i):
-            if use_stream:
-                if single and i != len(eng.buckets) - 1:
-                    return
-                s, e = (0, eng.flat_grad.numel()) if single else eng.buckets[i]
-                ev = torch.cuda.Event()
-                ev.record()                               # the bucket's gradients are final on the compute stream here
-                comm.wait_event(ev)
-                with torch.cuda.stream(comm):
-                    dist.all_reduce(eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group)
-                return
             if self.world > 1:
-                if single:
-                    if i == len(eng.buckets) - 1:
-                        works.append(dist.all_reduce(eng.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                    return
-                s, e = eng.buckets[i]
-                works.append(dist.all_reduce(eng.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                s_, e_ = eng.buckets[i]
+                works.append(dist.all_reduce(eng.flat_grad[s_:e_], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
         if next_images is not None:
             loss = eng.forward_backward(batch, 1.0 / float(global_tokens), ready, next_images=next_images)
         else:
             loss = eng.forward_backward(batch, 1.0 / float(global_tokens), ready)
         for w in works:
-            w.wait()
-        if use_stream:
-            done = torch.cuda.Event()
-            done.record(comm)
-            torch.cuda.current_stream().wait_event(done)  # every bucket is reduced before clamp + Adam read the gradients
+            w.wait()                 # every bucket is reduced before clamp + Adam read the gradients
         loss = loss.clone()          # the slot in the flat gradient buffer is overwritten by the next step
         eng.optimizer_step(lr)
         return loss

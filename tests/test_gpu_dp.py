@@ -230,7 +230,7 @@ def test_bench_py_gpus2_runs_its_real_multi_rank_branch_on_one_device():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
     cfg = out["config"]
     assert cfg["global_batch"] == 128 and cfg["parallelism"] == "dp2" and cfg["backend"] == "gloo"
-    assert cfg["lookahead_depth"] == 3 and cfg["lookahead_streams"] == 2          # DataParallelStep.cap_lookahead took effect
+    assert cfg["lookahead_depth"] == 6 and cfg["lookahead_streams"] == 2          # DataParallelStep.cap_lookahead took effect
     assert "on 2 side streams" in cfg["schedule"]
     assert math.isfinite(cfg["final_loss"]) and 8.5 < cfg["final_loss"] < 9.6      # ~ ln(10000) after three steps
     assert out["value"] > 0 and abs(out["value"] - 128 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-2

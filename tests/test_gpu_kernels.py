@@ -107,8 +107,8 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 44
-PLAIN_CONV_VARIANTS = list(range(1, 22)) + [28, 29, 30, 31, 32]      # 33..39: pipelined input affine (their own test)      # 22..27 are dual-source only (their own test)
+NUM_CONV_VARIANTS = 30
+PLAIN_CONV_VARIANTS = list(range(1, 27))      # ring kernel variants (27..29: conv_xp_kernel, 30: conv_pr_kernel -- their own tests)
 
 
 @pytest.mark.parametrize("variant", PLAIN_CONV_VARIANTS)
@@ -135,10 +135,10 @@ def test_conv_bf16_every_kernel_variant(lib, variant, N, H, W, Cin, Cout, k, str
 @pytest.mark.parametrize("stat_mode", ["slab", "atomic"])
 @pytest.mark.parametrize("affine", [False, True])
 @pytest.mark.parametrize("variant,N,H,W,Cin,Cout", [
-    (40, 5, 12, 12, 256, 1024), (41, 5, 12, 12, 256, 1024), (42, 3, 14, 14, 256, 1024), (40, 2, 16, 16, 128, 512),
-    (41, 7, 9, 9, 128, 512), (42, 2, 28, 28, 128, 512), (40, 3, 20, 20, 64, 256), (41, 1, 30, 30, 64, 256), (41, 64, 14, 14, 256, 1024)])
+    (27, 5, 12, 12, 256, 1024), (28, 5, 12, 12, 256, 1024), (29, 3, 14, 14, 256, 1024), (27, 2, 16, 16, 128, 512),
+    (28, 7, 9, 9, 128, 512), (29, 2, 28, 28, 128, 512), (27, 3, 20, 20, 64, 256), (28, 1, 30, 30, 64, 256), (28, 64, 14, 14, 256, 1024)])
 def test_conv_expansion_1x1_register_resident_panel_is_bit_identical(lib, variant, N, H, W, Cin, Cout, affine, stat_mode):
-    """conv_xp_kernel (variants 40-42: 1 / 2 / 4 column tiles per workgroup, the A panel of an expansion 1x1 conv held in MFMA
+    """conv_xp_kernel (variants 27-29: 1 / 2 / 4 column tiles per workgroup, the A panel of an expansion 1x1 conv held in MFMA
     fragment registers, the operand's BatchNorm + ReLU applied there once) against the 128x128-tile ring kernel (variant 3) on
     the same op: output tensor BITWISE equal, per-tile statistics slabs and integer-atomic sums equal to rounding; ragged M (rows past the last
     full 128-row tile), the derive-from-sums table with its running-statistics update; models.py:27."""
@@ -154,8 +154,8 @@ def test_conv_expansion_1x1_register_resident_panel_is_bit_identical(lib, varian
         o.variant = v
         extra = {}
         if stat_mode == "atomic":
-            acc = torch.zeros(2, 4, 2, Cout, dtype=torch.int64, device="cuda")
-            o.stat_acc, o.stat_shards = acc.data_ptr(), 4
+            acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc = acc.data_ptr()
             extra["acc"] = acc
         if affine:
             iacc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
@@ -178,8 +178,8 @@ def test_conv_expansion_1x1_register_resident_panel_is_bit_identical(lib, varian
     # the column sums pair even / odd rows (two rows per packed instruction): the same numbers in another fixed order
     if stat_mode == "slab":
         torch.testing.assert_close(got[3], want[3], rtol=2e-5, atol=2e-4)
-    else:                                                            # shard = workgroup id % 4: only the totals are comparable
-        torch.testing.assert_close(gx["acc"].sum(1).double() / 2 ** 22, wx["acc"].sum(1).double() / 2 ** 22, rtol=2e-5, atol=2e-3)
+    else:
+        torch.testing.assert_close(gx["acc"].double() / 2 ** 22, wx["acc"].double() / 2 ** 22, rtol=2e-5, atol=2e-3)
         assert int(gx["acc"][0].abs().sum()) > 0
     if affine:
         assert int(gx["iacc"][1].abs().sum()) == 0
@@ -199,7 +199,7 @@ def test_conv_expansion_1x1_register_resident_panel_is_bit_identical(lib, varian
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 15, 13, 64, 192), (64, 14, 14, 256, 256), (5, 28, 28, 128, 128), (7, 7, 7, 512, 136),
                                             (2, 5, 31, 64, 128), (1, 3, 3, 128, 256)])
 def test_conv3x3_lds_resident_patch_matches_the_ring_kernel(lib, N, H, W, Cin, Cout, stat_mode):
-    """conv_pr_kernel (variant 43: 3x3 / stride 1 / pad 1 with the input patch of a 128-row tile resident in LDS, only the weights
+    """conv_pr_kernel (variant 30: 3x3 / stride 1 / pad 1 with the input patch of a 128-row tile resident in LDS, only the weights
     streaming) against the f64 definition and against the ring kernel (variant 1): the K axis is walked channel-block major,
     so outputs agree to f32 summation order (then one bf16 rounding), not bitwise; image borders, rows of two images in one tile,
     ragged M and N, the widest supported image (W = 31); models.py:27."""
@@ -213,14 +213,14 @@ def test_conv3x3_lds_resident_patch_matches_the_ring_kernel(lib, N, H, W, Cin, C
         o.variant = v
         acc = None
         if stat_mode == "atomic":
-            acc = torch.zeros(2, 4, 2, Cout, dtype=torch.int64, device="cuda")
-            o.stat_acc, o.stat_shards = acc.data_ptr(), 4
+            acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc = acc.data_ptr()
         L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
         sync()
         return keep, acc
 
     want, wacc = run(1)
-    got, gacc = run(43)
+    got, gacc = run(30)
     out = got[2].float().cpu().double()
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max().item() < 2e-2
@@ -231,14 +231,14 @@ def test_conv3x3_lds_resident_patch_matches_the_ring_kernel(lib, N, H, W, Cin, C
     if stat_mode == "slab":
         torch.testing.assert_close(got[3], want[3], rtol=1e-4, atol=2e-3)
     else:
-        torch.testing.assert_close(gacc.sum(1).double() / 2 ** 22, wacc.sum(1).double() / 2 ** 22, rtol=1e-4, atol=5e-3)
+        torch.testing.assert_close(gacc.double() / 2 ** 22, wacc.double() / 2 ** 22, rtol=1e-4, atol=5e-3)
 
 
 @pytest.mark.parametrize("derive", [False, True])
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(64, 14, 14, 256, 256), (5, 28, 28, 128, 128), (3, 9, 13, 64, 192), (2, 7, 7, 512, 136)])
 def test_conv3x3_lds_resident_patch_with_fused_input_bn_relu(lib, N, H, W, Cin, Cout, derive):
     """conv_pr_kernel with the operand's BatchNorm + ReLU (bn1 of a bottleneck) applied to each 64-channel slice of the LDS-resident
-    patch by the loader waves: against relu(bn(x)) -> bf16 -> conv in f64 and against the pipelined in-ring transform (variant 33);
+    patch by the loader waves: against relu(bn(x)) -> bf16 -> conv in f64 (outputs and the per-tile statistics slabs);
     zero padding stays zero (shift != 0), table precomputed or derived from the producer's integer sums (running statistics
     updated once, the other parity cleared); models.py:27."""
     g = torch.Generator().manual_seed(N * 13 + W + Cin)
@@ -275,19 +275,19 @@ def test_conv3x3_lds_resident_patch_with_fused_input_bn_relu(lib, N, H, W, Cin, 
         sync()
         return keep, extra
 
-    want, wx = run(33)
-    got, gx = run(43)
+    got, gx = run(30)
+    again, ax = run(0)                                 # the heuristic picks the same kernel for a 3x3 conv with a fused input BatchNorm
     out = got[2].float().cpu().double()
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max().item() < 3e-2 + 4e-3 * ref.abs().max().item()
-    d = (got[2].float() - want[2].float()).abs()
-    assert d.max().item() <= 2.0 ** -6 * max(1.0, want[2].float().abs().max().item())
-    assert (d > 0).float().mean().item() < 0.05
-    torch.testing.assert_close(got[3], want[3], rtol=1e-4, atol=5e-3)
+    assert torch.equal(got[2], again[2]) and torch.equal(got[3], again[3])
+    part = got[3].cpu().double()
+    np.testing.assert_allclose(part[:, 0].sum(0).numpy(), ref.sum(0).numpy(), rtol=0, atol=2e-3 * ref.shape[0] ** 0.5 + 1e-3)
+    np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=5e-4, atol=5e-3)
     if derive:
         assert int(gx["iacc"][1].abs().sum()) == 0
-        assert torch.equal(gx["rm"], wx["rm"]) and torch.equal(gx["rv"], wx["rv"])
         np.testing.assert_allclose(gx["rm"].cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(gx["rv"].cpu().numpy(), (0.9 + 0.1 * var * M / (M - 1)).numpy(), rtol=1e-4)
 
 
 def test_conv_autotune_sets_a_variant_and_keeps_results(lib):
@@ -513,11 +513,9 @@ def test_fc_bn1d_fwd_bwd(lib):
     assert db.cpu().abs().max().item() < 5e-4 and gr["resnet.fc.bias"].abs().max().item() < 5e-4
 
 
-@pytest.mark.parametrize("shards", [1, 8])
-def test_conv_atomic_stats_then_consumer_derives_affine(lib, shards):
-    """bf16 conv adds fixed-point column sums with integer atomics (optionally into 8 shards of the accumulator: workgroup
-    id % 8); BN_RELU / BN_ADD_RELU sum the shards, derive scale/shift, update the running statistics once, clear the other
-    parity's accumulators; results are bitwise reproducible -- and identical for 1 and 8 shards (integer sums)"""
+def test_conv_atomic_stats_then_consumer_derives_affine(lib):
+    """bf16 conv adds fixed-point column sums with integer atomics; BN_RELU / BN_ADD_RELU derive scale/shift from them, update
+    the running statistics once, clear the other parity's accumulators; results are bitwise reproducible"""
     N, H, W, Cin, Cout = 6, 20, 20, 64, 192
     g = torch.Generator().manual_seed(93)
     x = (torch.randn(N, Cin, H, W, generator=g) + 0.3).bfloat16().float()
@@ -527,9 +525,9 @@ def test_conv_atomic_stats_then_consumer_derives_affine(lib, shards):
     ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cout)
     M = ref.shape[0]
     conv, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1, stats=False)
-    acc = torch.zeros(2, shards, 2, Cout, dtype=torch.int64, device="cuda")
+    acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
     acc[1] = 12345                                     # stale other-parity half: must be cleared by the consumer
-    conv.stat_acc, conv.stat_shards = acc.data_ptr(), shards
+    conv.stat_acc = acc.data_ptr()
     gd, bd = cu(gamma), cu(beta)
     rm, rv = cu(torch.zeros(Cout)), cu(torch.ones(Cout))
     idd = cu(idt)
@@ -538,7 +536,6 @@ def test_conv_atomic_stats_then_consumer_derives_affine(lib, shards):
     act.kind, act.dtype = L.OP_BN_ADD_RELU, L.SAT_BF16
     act.in0, act.in1, act.out = keep[2].data_ptr(), idd.data_ptr(), y1.data_ptr()
     act.stat_acc, act.gamma, act.beta = acc.data_ptr(), gd.data_ptr(), bd.data_ptr()
-    act.stat_shards = shards
     act.running_mean, act.running_var = rm.data_ptr(), rv.data_ptr()
     act.count, act.momentum, act.eps = M, 0.1, 1e-5
     act.N, act.Hout, act.Wout, act.Cout = N, H, W, Cout
@@ -553,9 +550,7 @@ def test_conv_atomic_stats_then_consumer_derives_affine(lib, shards):
     np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * var * M / (M - 1)).numpy(), rtol=1e-3)
     assert int(acc[1].abs().sum()) == 0 and int(acc[0].abs().sum()) > 0
-    if shards > 1:                                      # 19 row tiles x 2 column tiles spread over the shards; totals = the plain sums
-        assert int((acc[0, :, 0].abs().sum(1) > 0).sum()) > 1
-        np.testing.assert_allclose((acc[0].sum(0)[0].cpu().double() / 2 ** 22).numpy(), ref.sum(0).numpy(), rtol=0, atol=2e-2 * M ** 0.5)
+    np.testing.assert_allclose((acc[0, 0].cpu().double() / 2 ** 22).numpy(), ref.sum(0).numpy(), rtol=0, atol=2e-2 * M ** 0.5)
     # next step uses parity 1 and clears parity 0; same data => bit-identical output
     y_first = y1.clone()
     L.check(lib.sat_run_ops_parity(ops, 2, 1, st()))
@@ -757,129 +752,6 @@ def test_embed_concat_bwd_beyond_the_default_lds_limit(lib):
     assert torch.equal(d_feat.cpu(), dX[:B])
 
 
-@pytest.mark.parametrize("derive", [False, True])
-@pytest.mark.parametrize("variant", [0, 22, 23, 24, 25, 26, 27])
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(5, 12, 12, 256, 192), (3, 7, 7, 1024, 256), (2, 9, 5, 64, 64)])
-def test_conv1x1_dual_source_bn_add_relu_fused(lib, derive, variant, N, H, W, Cin, Cout):
-    """dual-source 1x1 conv (sat_op.out1): A = relu(c3*s+t + resid) formed in LDS from two LDS-DMA sources -- the previous
-    bottleneck's bn3 + add + ReLU -- stored once as the next residual (out1) and convolved; every dual kernel variant,
-    table precomputed or derived from the producer's integer sums; atomic statistics of the conv's own output"""
-    g = torch.Generator().manual_seed(131 + variant + Cin)
-    c3 = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
-    resid = torch.randn(N, H, W, Cin, generator=g).clamp(min=0).bfloat16()
-    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).bfloat16()
-    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
-    xf = c3.float().reshape(-1, Cin).double()
-    M = xf.shape[0]
-    mean, var = xf.mean(0), xf.var(0, unbiased=False)
-    scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
-    shift = (beta.double() - mean * scale.double()).float()
-    y = torch.clamp(c3.float().reshape(-1, Cin) * scale + shift + resid.float().reshape(-1, Cin), min=0).bfloat16()
-    ref = y.float().double() @ w.float().double().t()
-    o, keep, _ = _conv_op(L.SAT_BF16, c3.float(), w.float().reshape(Cout, 1, 1, Cin), 1, 0, stats=False)
-    o.variant = variant
-    rd = cu(resid.contiguous())
-    yd = torch.full((M, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
-    o.in1, o.out1 = rd.data_ptr(), yd.data_ptr()
-    own = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
-    o.stat_acc = own.data_ptr()
-    if derive:
-        acc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
-        acc[0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
-        acc[0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
-        acc[1] = 777
-        gd, bd, rm, rv = cu(gamma), cu(beta), cu(torch.zeros(Cin)), cu(torch.ones(Cin))
-        o.stat_acc1, o.gamma1, o.beta1 = acc.data_ptr(), gd.data_ptr(), bd.data_ptr()
-        o.running_mean1, o.running_var1 = rm.data_ptr(), rv.data_ptr()
-        o.count, o.momentum, o.eps = M, 0.1, 1e-5
-    else:
-        sd, td = cu(scale), cu(shift)
-        o.scale0, o.shift0 = sd.data_ptr(), td.data_ptr()
-    L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
-    sync()
-    got_y = yd.float().cpu()
-    # y: one bf16 rounding of an f32 value that may differ in its last bits from the CPU's (fma contraction): <= 1 bf16 ulp
-    assert torch.isfinite(got_y).all()
-    assert (got_y - y.float()).abs().max().item() <= 2 ** -7 * max(1.0, y.float().abs().max().item())
-    assert (got_y != y.float()).float().mean().item() < 0.02
-    out = keep[2].float().cpu().double()
-    assert (out - ref).abs().max().item() < 3e-2 + 6e-3 * ref.abs().max().item()
-    s1 = own[0, 0].cpu().double() / 2 ** 22
-    np.testing.assert_allclose(s1.numpy(), ref.sum(0).numpy(), rtol=2e-3, atol=0.3 + 2e-3 * M ** 0.5)
-    if derive:
-        assert int(acc[1].abs().sum()) == 0
-        np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-4, atol=1e-6)
-    # argument checks: the side output must not alias an input, and the dual form needs the affine
-    o2 = L.SatOp.from_buffer_copy(bytes(o))
-    o2.out1 = o2.in0
-    in_place_ok = 160 <= Cin <= 1024 and Cout <= 256            # conv_du_kernel's geometry: y may overwrite the raw operand there
-    assert lib.sat_run_ops_parity(C.pointer(o2), 1, 0, st()) == (0 if in_place_ok else 1001)
-    o3 = L.SatOp.from_buffer_copy(bytes(o))
-    o3.scale0 = o3.shift0 = o3.stat_acc1 = None
-    assert lib.sat_run_ops_parity(C.pointer(o3), 1, 0, st()) == 1003
-
-
-
-@pytest.mark.parametrize("in_place", [False, True])
-@pytest.mark.parametrize("derive", [False, True])
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(64, 14, 14, 1024, 256), (5, 12, 12, 256, 192), (3, 7, 7, 1024, 256), (1, 5, 5, 320, 256)])
-def test_conv1x1_dual_source_loader_side_transform_is_bit_identical(lib, N, H, W, Cin, Cout, derive, in_place):
-    """conv_du_kernel (variant 44: 64 rows x all columns per workgroup, 32-channel stages in a six-slot ring, the previous block's
-    bn3 + residual add + ReLU formed by the LOADER waves, y stored once -- optionally over the raw operand itself) against the
-    dual-source ring kernel (variant 22): y and the conv output BITWISE equal, integer statistics equal to rounding; ragged M
-    (loader waves whose rows all lie past M store nothing: the counted wait has a form for them); models.py:27."""
-    g = torch.Generator().manual_seed(211 + Cin + N)
-    c3 = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
-    resid = torch.randn(N, H, W, Cin, generator=g).clamp(min=0).bfloat16()
-    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).bfloat16()
-    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
-    xf = c3.float().reshape(-1, Cin).double()
-    M = xf.shape[0]
-    mean, var = xf.mean(0), xf.var(0, unbiased=False)
-    scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
-    shift = (beta.double() - mean * scale.double()).float()
-
-    def run(v, inpl):
-        o, keep, _ = _conv_op(L.SAT_BF16, c3.float(), w.float().reshape(Cout, 1, 1, Cin), 1, 0, stats=False)
-        o.variant = v
-        rd = cu(resid.contiguous())
-        yd = keep[0].view(M, Cin) if inpl else torch.full((M, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
-        o.in1, o.out1 = rd.data_ptr(), yd.data_ptr()
-        own = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
-        o.stat_acc = own.data_ptr()
-        extra = dict(rd=rd, yd=yd, own=own)
-        if derive:
-            acc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
-            acc[0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
-            acc[0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
-            acc[1] = 777
-            gd, bd, rm, rv = cu(gamma), cu(beta), cu(torch.zeros(Cin)), cu(torch.ones(Cin))
-            o.stat_acc1, o.gamma1, o.beta1 = acc.data_ptr(), gd.data_ptr(), bd.data_ptr()
-            o.running_mean1, o.running_var1 = rm.data_ptr(), rv.data_ptr()
-            o.count, o.momentum, o.eps = M, 0.1, 1e-5
-            extra.update(acc=acc, gd=gd, bd=bd, rm=rm, rv=rv)
-        else:
-            sd, td = cu(scale), cu(shift)
-            o.scale0, o.shift0 = sd.data_ptr(), td.data_ptr()
-            extra.update(sd=sd, td=td)
-        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
-        sync()
-        return keep, extra
-
-    want, wx = run(22, False)
-    got, gx = run(44, in_place)
-    assert torch.isfinite(gx["yd"].float()).all() and torch.isfinite(got[2].float()).all()
-    assert torch.equal(gx["yd"], wx["yd"])
-    assert torch.equal(got[2], want[2])
-    torch.testing.assert_close(gx["own"][0].double() / 2 ** 22, wx["own"][0].double() / 2 ** 22, rtol=2e-5, atol=2e-3)
-    if derive:
-        assert int(gx["acc"][1].abs().sum()) == 0
-        assert torch.equal(gx["rm"], wx["rm"]) and torch.equal(gx["rv"], wx["rv"])
-    y = torch.clamp(c3.float().reshape(-1, Cin) * scale + shift + resid.float().reshape(-1, Cin), min=0).bfloat16()
-    ref = y.float().double() @ w.float().double().t()
-    assert (got[2].float().cpu().double() - ref).abs().max().item() < 3e-2 + 6e-3 * ref.abs().max().item()
-
-
 @pytest.mark.parametrize("B,T,In,H,ragged", [(64, 19, 256, 512, False), (64, 19, 64, 512, True), (13, 7, 32, 64, True),
                                              (8, 5, 32, 32, False), (40, 12, 96, 256, True), (3, 9, 32, 128, True)])
 def test_lstm_fwd_persistent_equals_per_step_launches(lib, B, T, In, H, ragged, monkeypatch):
@@ -931,10 +803,10 @@ def test_lstm_fwd_persistent_equals_per_step_launches(lib, B, T, In, H, ragged, 
 
 
 @pytest.mark.parametrize("N,H,V", [(1216, 512, 10000), (76, 64, 500), (33, 32, 1003), (200, 128, 130)])
-def test_fused_vocab_ce_fwd_and_bwd_vs_fp64(lib, N, H, V):
-    """sat_vocab_ce_fwd (GEMM epilogue emits per-row max / sum-exp partials, combine kernel -> lse, loss) and
-    sat_vocab_ce_bwd_fused (softmax gradient formed in the GEMMs' operand loads; bias gradient accumulated in the dW GEMM)
-    against fp64 softmax cross entropy and its gradients; V not a multiple of 4 / of the tile, N below one tile"""
+def test_vocab_ce_fwd_and_bwd_vs_fp64(lib, N, H, V):
+    """sat_vocab_ce_fwd (projection + row-wise CE, d(loss)/d(logits) written over the logits) and sat_vocab_ce_bwd against
+    fp64 softmax cross entropy and its gradients; V not a multiple of 4 / of the tile, N below one tile (models.py:53,
+    train.py:53,143-144)"""
     g = torch.Generator().manual_seed(N + V)
     Hs = torch.randn(N, H, generator=g) * 0.5
     W = torch.empty(V, H).uniform_(-0.1, 0.1, generator=g)
@@ -944,75 +816,30 @@ def test_fused_vocab_ce_fwd_and_bwd_vs_fp64(lib, N, H, V):
     Hd, Wd, bd, tgd = cu(Hs), cu(W), cu(b), cu(tg)
     ldl = (V + 3) // 4 * 4
     logits = torch.zeros(N, ldl, device="cuda")
-    lse, rl, lo = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(1, device="cuda")
-    wsb = lib.sat_vocab_ce_fwd_ws_bytes(N, V)
-    ws = torch.empty(wsb // 4, device="cuda")
-    assert lib.sat_vocab_ce_fwd(L.ptr(Hd), L.ptr(Wd), L.ptr(bd), L.ptr(tgd), N, H, V, inv, L.ptr(logits), ldl, L.ptr(lse), L.ptr(rl),
-                                L.ptr(lo), L.ptr(ws), 16, st()) == 1002
-    L.check(lib.sat_vocab_ce_fwd(L.ptr(Hd), L.ptr(Wd), L.ptr(bd), L.ptr(tgd), N, H, V, inv, L.ptr(logits), ldl, L.ptr(lse), L.ptr(rl),
-                                 L.ptr(lo), L.ptr(ws), wsb, st()))
+    rl, lo = torch.empty(N, device="cuda"), torch.empty(1, device="cuda")
+    assert lib.sat_vocab_ce_fwd(L.ptr(Hd), L.ptr(Wd), L.ptr(bd), None, N, H, V, inv, L.ptr(logits), ldl, L.ptr(rl), L.ptr(lo), st()) == 1001
+    L.check(lib.sat_vocab_ce_fwd(L.ptr(Hd), L.ptr(Wd), L.ptr(bd), L.ptr(tgd), N, H, V, inv, L.ptr(logits), ldl, L.ptr(rl), L.ptr(lo), st()))
     sync()
     Hq, Wq = Hs.double().requires_grad_(True), W.double().requires_grad_(True)
     bq = b.double().requires_grad_(True)
-    ref_logits = Hq @ Wq.t() + bq
-    ref_lse = torch.logsumexp(ref_logits, 1)
-    ref_rows = ref_lse - ref_logits[torch.arange(N), tg]
+    ref_logits = (Hq @ Wq.t() + bq)
+    ref_logits.retain_grad()
+    ref_rows = torch.logsumexp(ref_logits, 1) - ref_logits[torch.arange(N), tg]
     loss = ref_rows.sum() * inv
     loss.backward()
-    np.testing.assert_allclose(logits[:, :V].cpu().numpy(), ref_logits.detach().numpy(), rtol=0, atol=5e-6)
-    np.testing.assert_allclose(lse.cpu().numpy(), ref_lse.detach().numpy(), rtol=0, atol=5e-6)
     np.testing.assert_allclose(rl.cpu().numpy(), ref_rows.detach().numpy(), rtol=0, atol=1e-5)
     assert abs(lo.item() - loss.item()) < 2e-6
+    np.testing.assert_allclose(logits[:, :V].cpu().numpy(), ref_logits.grad.numpy(), rtol=1e-4, atol=2e-9)      # the gradient, in place
     if ldl > V:
         assert float(logits[:, V:].abs().sum()) == 0.0
     dw, db, dH = torch.full((V, H), float("nan"), device="cuda"), torch.full((V,), float("nan"), device="cuda"), torch.full((N, H), float("nan"), device="cuda")
-    bwsb = lib.sat_vocab_ce_bwd_fused_ws_bytes(N, H, V)
+    bwsb = lib.sat_vocab_ce_bwd_ws_bytes(N, H, V)
     bws = torch.empty(max(bwsb // 4, 4), device="cuda")
-    L.check(lib.sat_vocab_ce_bwd_fused(L.ptr(logits), ldl, L.ptr(lse), L.ptr(tgd), inv, L.ptr(Hd), L.ptr(Wd), N, H, V, L.ptr(dw), L.ptr(db),
-                                       L.ptr(dH), L.ptr(bws), bwsb, st()))
+    L.check(lib.sat_vocab_ce_bwd(L.ptr(logits), ldl, L.ptr(Hd), L.ptr(Wd), N, H, V, L.ptr(dw), L.ptr(db), L.ptr(dH), L.ptr(bws), bwsb, st()))
     sync()
     np.testing.assert_allclose(dw.cpu().numpy(), Wq.grad.numpy(), rtol=1e-4, atol=2e-8)
     np.testing.assert_allclose(db.cpu().numpy(), bq.grad.numpy(), rtol=1e-4, atol=2e-8)
     np.testing.assert_allclose(dH.cpu().numpy(), Hq.grad.numpy(), rtol=1e-4, atol=2e-8)
-
-
-@pytest.mark.parametrize("variant", [0, 33, 34, 35, 36, 37, 38, 39])
-@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(3, 14, 14, 128, 192, 3, 1, 1), (2, 15, 13, 64, 64, 3, 2, 1), (4, 9, 9, 256, 320, 1, 1, 0)])
-def test_conv_with_pipelined_input_bn_relu_any_geometry(lib, variant, N, H, W, Cin, Cout, k, stride, pad):
-    """XA variants: the operand's BatchNorm + ReLU applied to each landed LDS stage one K-step ahead of the MFMAs, for 3x3 convs
-    too: a per-row tap mask keeps the zero padding zero (relu(0*s+t) would not be).  Table derived from integer sums."""
-    g = torch.Generator().manual_seed(171 + variant + Cin)
-    x = (torch.randn(N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
-    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
-    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.5 + 0.3       # positive shifts: a wrong pad shows
-    xf = x.float().reshape(-1, Cin).double()
-    Mi = xf.shape[0]
-    mean, var = xf.mean(0), xf.var(0, unbiased=False)
-    scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
-    shift = (beta.double() - mean * scale.double()).float()
-    a = torch.clamp(x.float() * scale + shift, min=0).bfloat16().float()
-    ref = F.conv2d(a.permute(0, 3, 1, 2).double(), w.float().permute(0, 3, 1, 2).double(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, Cout)
-    o, keep, _ = _conv_op(L.SAT_BF16, x.float(), w.float(), stride, pad, stats=False)
-    o.variant = variant
-    own = torch.zeros(2, 8, 2, Cout, dtype=torch.int64, device="cuda")
-    o.stat_acc, o.stat_shards = own.data_ptr(), 8
-    acc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
-    acc[0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
-    acc[0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
-    acc[1] = 777
-    gd, bd, rm, rv = cu(gamma), cu(beta), cu(torch.zeros(Cin)), cu(torch.ones(Cin))
-    o.stat_acc1, o.gamma1, o.beta1 = acc.data_ptr(), gd.data_ptr(), bd.data_ptr()
-    o.running_mean1, o.running_var1 = rm.data_ptr(), rv.data_ptr()
-    o.count, o.momentum, o.eps = Mi, 0.1, 1e-5
-    L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
-    sync()
-    out = keep[2].float().cpu().double()
-    assert torch.isfinite(out).all()
-    assert (out - ref).abs().max().item() < 3e-2 + 6e-3 * ref.abs().max().item(), (out - ref).abs().max().item()
-    s1 = own[0].sum(0)[0].cpu().double() / 2 ** 22
-    np.testing.assert_allclose(s1.numpy(), ref.sum(0).numpy(), rtol=2e-3, atol=0.3 + 2e-3 * ref.shape[0] ** 0.5)
-    assert int(acc[1].abs().sum()) == 0
-    np.testing.assert_allclose(rm.cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.gpu
@@ -1076,15 +903,15 @@ def test_fixed_point_statistics_hold_for_small_magnitude_channels(lib):
     ref = F.conv2d(x.double(), w.double()).permute(0, 2, 3, 1).reshape(-1, Cout)
     M = ref.shape[0]
     conv, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 0, stats=False)
-    acc = torch.zeros(2, 1, 2, Cout, dtype=torch.int64, device="cuda")
-    conv.stat_acc, conv.stat_shards = acc.data_ptr(), 1
+    acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+    conv.stat_acc = acc.data_ptr()
     gd, bd = cu(gamma), cu(beta)
     rm, rv = cu(torch.zeros(Cout)), cu(torch.zeros(Cout))
     y1 = torch.empty(M, Cout, device="cuda", dtype=torch.bfloat16)
     act = L.SatOp()
     act.kind, act.dtype = L.OP_BN_RELU, L.SAT_BF16
     act.in0, act.out = keep[2].data_ptr(), y1.data_ptr()
-    act.stat_acc, act.gamma, act.beta, act.stat_shards = acc.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1
+    act.stat_acc, act.gamma, act.beta = acc.data_ptr(), gd.data_ptr(), bd.data_ptr()
     act.running_mean, act.running_var = rm.data_ptr(), rv.data_ptr()
     act.count, act.momentum, act.eps = M, 1.0, 1e-5          # momentum 1: the running buffers receive the batch statistics
     act.N, act.Hout, act.Wout, act.Cout = N, H, W, Cout
@@ -1190,12 +1017,12 @@ def test_a_stalled_train_step_never_reaches_the_parameters(lib, monkeypatch, sta
         for _ in range(3):
             ts2.step(images, caps, lengths)
         ts2.check_ids()
-        assert (ts2.flat.params - ts.flat.params).abs().max().item() < 1e-4      # persistent vs per-step recurrence: another summation order
+        assert (ts2.flat.params - ts.flat.params).abs().max().item() < 5e-4      # persistent vs per-step recurrence: another summation order (Adam amplifies a near-zero gradient element)
     finally:
         lib.sat_lstm_persist_enable(1)
 
 
-@pytest.mark.parametrize("variant", [28, 29, 30])
+@pytest.mark.parametrize("variant", [22, 23, 24])
 def test_wide_tile_output_stores_are_stable_over_many_launches(lib, variant):
     """Regression pin for the `store16_wt` hazard (robustness 13): the write-through output stores are inline asm,
     and a VMEM store of more than 64 bits needs wait states before its data VGPRs are overwritten -- the compiler's hazard
@@ -1293,82 +1120,6 @@ def test_vocab_ce_bf16_path_vs_exact_f32_path(lib, N, H, V):
           % (N, H, V, abs(loss16.item() - loss32.item()), rel(dW16, dW32), rel(db16, db32), rel(dH16, dH32)))
     assert rel(dW16, dW32) < 1e-2 and rel(db16, db32) < 1e-2 and rel(dH16, dH32) < 1e-2
     assert lib.sat_vocab_bf16_ws_bytes(N, 100, V) == 0 and lib.sat_vocab_bf16_ws_bytes(N, H, 20000) == 0      # unsupported shapes say so
-
-
-@pytest.mark.parametrize("Nimg,HW,Cout", [(3, 14, 512), (4, 14, 1024), (1, 12, 1024)])
-def test_conv3_fused_bn_add_relu_single_launch_vs_reference(lib, Nimg, HW, Cout):
-    """SAT_OP_CONV3_FUSED (sat_conv3_fused.hip): y = relu(bn3(conv1x1(relu(bn2(raw2)))) + x) in ONE launch, the accumulators held
-    across a grid-wide statistics barrier -- against the same arithmetic on the CPU (bf16 storage, f32 / f64 accumulate): outputs
-    to bf16 rounding, integer sums, running statistics, parity clearing, re-armed sync words; two consecutive runs (both
-    parities).  torchvision Bottleneck.forward under models.py:27."""
-    Cin, M = 256, Nimg * HW * HW
-    assert lib.sat_conv3_fused_ok(M, Cout, Cin) == 1 and lib.sat_conv3_fused_ok(M, Cout, 128) == 0
-    g = torch.Generator().manual_seed(M + Cout)
-    w = (torch.randn(Cout, Cin, generator=g) / 16).bfloat16()
-    g2, b2 = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.1
-    g3, b3 = torch.rand(Cout, generator=g) * 0.2 + 0.1, torch.randn(Cout, generator=g) * 0.1
-    rm2, rv2, rm3, rv3 = torch.zeros(Cin), torch.ones(Cin), torch.zeros(Cout), torch.ones(Cout)
-    dw, dg2, db2, dg3, db3 = cu(w), cu(g2), cu(b2), cu(g3), cu(b3)
-    drm2, drv2, drm3, drv3 = cu(rm2), cu(rv2), cu(rm3), cu(rv3)
-    acc2 = torch.zeros(2, 1, 2, Cin, dtype=torch.int64, device="cuda")
-    acc3 = torch.zeros(2, 1, 2, Cout, dtype=torch.int64, device="cuda")
-    sync_w, err = torch.zeros(2, dtype=torch.int32, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda")
-    out = torch.empty(M, Cout, dtype=torch.bfloat16, device="cuda")
-    for parity in (0, 1):
-        raw2 = (torch.randn(M, Cin, generator=g) * 1.5 + 0.3).bfloat16()
-        x = torch.randn(M, Cout, generator=g).bfloat16()
-        r2 = raw2.double()
-        acc2[parity, 0, 0] = torch.round(r2.sum(0) * 2 ** 22).long().cuda()          # what conv2's epilogue leaves
-        acc2[parity, 0, 1] = torch.round((r2 * r2).sum(0) * 2 ** 22).long().cuda()
-        acc2[1 - parity].fill_(7)                                                       # must be cleared by the launch
-        acc3[1 - parity].fill_(9)
-        draw, dx = cu(raw2), cu(x)
-        out.fill_(float("nan"))
-        o = L.SatOp()
-        o.kind, o.dtype = L.OP_CONV3_FUSED, L.SAT_BF16
-        o.in0, o.w, o.in1, o.out = draw.data_ptr(), dw.data_ptr(), dx.data_ptr(), out.data_ptr()
-        o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = Nimg, HW, HW, Cin, HW, HW, Cout
-        o.KH, o.KW, o.stride, o.pad = 1, 1, 1, 0
-        o.stat_acc1, o.stat_shards1, o.gamma1, o.beta1 = acc2.data_ptr(), 1, dg2.data_ptr(), db2.data_ptr()
-        o.running_mean1, o.running_var1 = drm2.data_ptr(), drv2.data_ptr()
-        o.stat_acc, o.stat_shards, o.gamma, o.beta = acc3.data_ptr(), 1, dg3.data_ptr(), db3.data_ptr()
-        o.running_mean, o.running_var = drm3.data_ptr(), drv3.data_ptr()
-        o.count, o.momentum, o.eps = M, 0.1, 1e-5
-        o.scale_out, o.shift_out = sync_w.data_ptr(), err.data_ptr()
-        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, parity, st()))
-        sync()
-        assert int(err[0]) == 0 and sync_w.tolist() == [0, 0]
-        # reference
-        m2 = r2.mean(0)
-        v2 = (r2 * r2).mean(0) - m2 * m2
-        sc2 = (g2.double() / torch.sqrt(v2 + 1e-5)).float()
-        sh2 = (b2.double() - m2 * sc2.double()).float()
-        a2 = torch.relu(raw2.float() * sc2 + sh2).bfloat16()
-        conv = a2.double() @ w.double().t()
-        m3 = conv.mean(0)
-        v3 = (conv * conv).mean(0) - m3 * m3
-        sc3 = (g3.double() / torch.sqrt(v3 + 1e-5)).float()
-        sh3 = (b3.double() - m3 * sc3.double()).float()
-        ref = torch.relu(conv.float().bfloat16().float() * sc3 + sh3 + x.float())
-        got = out.float().cpu()
-        assert torch.isfinite(got).all()
-        # bf16(conv) may round the other way when the f32 accumulation order differs: two output ulps
-        tol = 2 ** -7 * ref.abs().clamp(min=1.0) + 2 ** -7 * conv.abs().float() * sc3.abs()
-        assert ((got - ref).abs() <= tol).all(), ((got - ref).abs() / tol).max().item()
-        s1 = acc3[parity, 0, 0].cpu().double() / 2 ** 22
-        s2 = acc3[parity, 0, 1].cpu().double() / 2 ** 22
-        assert (s1 - conv.sum(0)).abs().max().item() < 2e-3 * M ** 0.5 + 2e-2
-        assert ((s2 - (conv * conv).sum(0)).abs() / (conv * conv).sum(0)).max().item() < 1e-3
-        assert int(acc2[1 - parity].abs().sum()) == 0 and int(acc3[1 - parity].abs().sum()) == 0
-        rm2 = 0.9 * rm2 + 0.1 * m2.float()
-        rv2 = 0.9 * rv2 + 0.1 * (v2 * M / (M - 1)).float()
-        rm3 = 0.9 * rm3 + 0.1 * m3.float()
-        rv3 = 0.9 * rv3 + 0.1 * (v3 * M / (M - 1)).float()
-        np.testing.assert_allclose(drm2.cpu().numpy(), rm2.numpy(), rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(drv2.cpu().numpy(), rv2.numpy(), rtol=1e-3, atol=1e-5)
-        np.testing.assert_allclose(drm3.cpu().numpy(), rm3.numpy(), rtol=1e-3, atol=1e-4)
-        np.testing.assert_allclose(drv3.cpu().numpy(), rv3.numpy(), rtol=2e-3, atol=1e-4)
-        acc3[parity].zero_()                       # (a consumer-less test: the next run of this parity starts from zero)
 
 
 @pytest.mark.parametrize("B,T,In,H", [(8, 6, 32, 64), (64, 19, 256, 512), (5, 4, 36, 48)])

@@ -298,27 +298,22 @@ def test_encoder_bf16_close_to_oracle():
     assert d2.abs().max().item() < 0.03 * ref_bf.abs().max().item() + 0.01
 
 
-def test_encoder_bf16_eval_fused_epilogues_vs_unfused_and_oracle(monkeypatch):
-    """eval mode (eval.py:65): BatchNorm + add + ReLU ride in the conv epilogues (SAT_FUSE_EVAL_BN=1, default) -- against
-    the unfused op sequence (same kernels + separate normalise launches) and against the f32 oracle in eval mode"""
+def test_encoder_bf16_eval_fused_epilogues_vs_oracle():
+    """eval mode (eval.py:65): BatchNorm + add + ReLU ride in the conv epilogues -- 3-4 launches per bottleneck, no normalise
+    launch at all -- against the f32 oracle in eval mode and the bf16 train-mode program's launch count"""
     arch, E, B = SMALL, 32, 8
     x = torch.randn(B, 3, 96, 96, generator=torch.Generator().manual_seed(26))
-    monkeypatch.setenv("SAT_FUSE_EVAL_BN", "0")
-    plain, params, buffers = _encoder_pair(arch, E, 25, "bf16")
-    ref_plain = plain.eval().pooled_features(x.cuda()).clone()
-    n_plain = next(iter(plain._programs.values())).n_ops
-    monkeypatch.setenv("SAT_FUSE_EVAL_BN", "1")
-    fused, _, _ = _encoder_pair(arch, E, 25, "bf16")
+    fused, params, buffers = _encoder_pair(arch, E, 25, "bf16")
     out = fused.eval().pooled_features(x.cuda()).clone()
-    n_fused = next(iter(fused._programs.values())).n_ops
-    assert n_plain - n_fused >= 2 * sum(arch["layers"])  # per bottleneck at least the bn1+ReLU and bn3+add+ReLU launches are gone
-    d = (out - ref_plain).float()
-    assert (d.norm() / ref_plain.float().norm()).item() < 0.01          # one bf16 rounding fewer per BatchNorm
+    prog = next(iter(fused._programs.values()))
+    kinds = [prog.ops[i].kind for i in range(prog.n_ops)]
+    L = sat._lib
+    assert L.OP_BN_RELU not in kinds and L.OP_BN_ADD_RELU not in kinds and L.OP_BN_FINALIZE not in kinds
+    assert kinds.count(L.OP_CONV) == 1 + 3 * sum(arch["layers"]) + len(arch["layers"])      # stem + 3 per bottleneck + 4 projections
     bufs = {k: v.clone() for k, v in buffers.items()}
     pooled_ref, _ = OE.resnet_forward(params, bufs, x, arch, training=False)
     rel = ((out.cpu() - pooled_ref).norm() / pooled_ref.norm()).item()
-    rel_plain = ((ref_plain.cpu() - pooled_ref).norm() / pooled_ref.norm()).item()
-    assert rel < 0.05 and rel <= rel_plain * 1.25 + 1e-3, (rel, rel_plain)
+    assert rel < 0.05, rel
     for k in ("resnet.bn1.running_mean", "resnet.layer2.0.bn3.running_var"):      # eval never touches the statistics
         assert torch.equal(fused.state_dict()[k].cpu(), buffers[k])
 
@@ -544,32 +539,43 @@ def test_cfg2_greedy_and_dropin_forward():
 
 
 def test_cfg2_decode_full_size_vs_oracle_and_eval_determinism():
-    """BASELINE configs[4] shape on one GPU: batch 64, V=10000, beam 5 and greedy.  The decoder half is compared with
-    the CPU oracle on the SAME encoder features (ids bit-exact); the eval-mode encoder (running-statistics BatchNorm,
-    one batched table launch, hipGraph replay from the 3rd call on) must be bit-reproducible call after call."""
-    model, images, caps, lengths = _cfg2(B=64)
+    """BASELINE configs[4] shape on one GPU: batch 64, V=10000, beam 5 and greedy, decoded from the REAL eval-mode encoder
+    output: a well-conditioned stack (`conditioning="trained_like"`) whose running statistics were brought to the data by
+    train-mode passes, as a trained model's are (eval.py:65 `model.eval()`), and a vocabulary projection with trained-like logit
+    spread.  The decoder half is compared with the CPU oracle on the SAME encoder features: greedy ids bit-exact, beam-5 best
+    hypothesis equal on >= 95 % of the images (a candidate pair closer than the f32 summation-order noise may swap); the eval-mode
+    encoder (running-statistics BatchNorm in the conv epilogues, hipGraph replay from the 3rd call on) must be bit-reproducible
+    call after call."""
+    gen = torch.Generator().manual_seed(321)
+    ep, eb = OE.init_encoder_params(256, OE.RESNET152, generator=gen, conditioning="trained_like")
+    dp = OD.init_decoder_params(256, 512, 10000, 1, generator=gen)
+    dp["linear.weight"] = dp["linear.weight"] * 6.0          # a trained projection separates its logits: no 1e-6 ties among 10000 words
+    model = sat.ShowAndTell(256, 512, 10000, 1, compute_dtype="bf16")
+    model.encoder.load_state_dict({**ep, **eb})
+    model.decoder.load_state_dict(dp)
+    model.cuda().train()
+    images = torch.randn(64, 3, 224, 224, generator=gen).cuda()
+    with torch.no_grad():
+        for _ in range(40):                                   # momentum 0.1: the running statistics converge to this data's
+            model.encoder(images)
     model.eval()
     with torch.no_grad():
         feats = [model.encoder(images).clone() for _ in range(4)]      # eager, eager, graph capture, graph replay
     for f in feats[1:]:
         assert torch.equal(feats[0].view(torch.int32), f.view(torch.int32))       # bit patterns (NaN-proof)
+    f0 = feats[0]
+    assert bool(torch.isfinite(f0).all()) and 0.05 < float(f0.std()) < 20.0, (float(f0.abs().max()), float(f0.std()))
+    assert float((f0[0] - f0[1]).norm() / f0[0].norm()) > 0.05            # the features really depend on the image
     params = {k: v.detach().cpu() for k, v in model.decoder.state_dict().items()}
-    # a randomly initialised 152-layer stack without batch statistics may overflow bf16: decode from its features only
-    # if they are usable, else from unit-normal ones (what the trained BatchNorm1d head emits)
-    f0 = feats[0] if bool(torch.isfinite(feats[0]).all()) and float(feats[0].abs().max()) < 1e3 else torch.randn_like(feats[0])
     f_cpu = f0.cpu()
     greedy = model.decoder.sample(f0)
     assert torch.equal(greedy.cpu(), OD.greedy_sample(params, f_cpu, 1))
     ids, scores = model.decoder.sample_beam(f0, 5, end_id=2, return_all=True)
     ref_ids, ref_scores = OD.beam_search(params, f_cpu, 5, 1, end_id=2)
-    # 64 x 5 hypotheses x 20 steps of top-5-of-50000: a candidate pair closer than the f32 summation-order noise
-    # (~1e-6) may swap, after which that hypothesis' ids diverge -- scores stay equal, and most images agree exactly
-    # (an untrained model is the worst case: all 50000 continuations are within 1e-2 of each other)
-    # and beam search is chaotic in such swaps: a prefix dropped at the 5th/6th boundary can cost 1e-2 at the end)
     np.testing.assert_allclose(scores.cpu().numpy(), ref_scores.numpy(), rtol=0, atol=5e-2)
     assert (scores[:, :-1] >= scores[:, 1:]).all()
     same = (ids[:, 0].cpu() == ref_ids[:, 0]).all(dim=1).float().mean().item()
-    assert same >= 0.8, same
+    assert same >= 0.95, same
     # ids and scores are consistent: teacher-forcing the returned best sequence reproduces its score
     for b in (0, 17, 63):
         seq = ids[b, 0].cpu()
@@ -580,13 +586,12 @@ def test_cfg2_decode_full_size_vs_oracle_and_eval_determinism():
             if not done:
                 total += lp[t, seq[t]].item()
             done = done or int(seq[t]) == 2
-        assert abs(total - scores[b, 0].item()) < 1e-3, (b, total, scores[b, 0].item())
-    if f0 is feats[0]:
-        assert torch.equal(model.sample_beam(images, 5, end_id=2), ids[:, 0])
+        assert abs(total - scores[b, 0].item()) < 2e-3, (b, total, scores[b, 0].item())
+    assert torch.equal(model.sample_beam(images, 5, end_id=2), ids[:, 0])
     # beam-1 vs greedy at full size: bit-equal on the goldens; here the two paths' logits differ in summation order
-    # (skinny arg-max kernel vs GEMM + sat_beam_step), so a near-tie may flip in a few of the 64 images
+    # (skinny arg-max kernel vs GEMM + sat_beam_step), so a near-tie may flip in one or two of the 64 images
     b1 = model.decoder.sample_beam(f0, 1)
-    assert (b1 == greedy).all(dim=1).float().mean().item() >= 0.8
+    assert (b1 == greedy).all(dim=1).float().mean().item() >= 0.95
 
 
 @pytest.mark.timeout(900)
@@ -635,7 +640,8 @@ def test_decoder_odd_shapes_ragged_vs_oracle(B, T, E, H, V, Lh):
     for k, p in dec.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref_grads[k].numpy(), rtol=2e-3, atol=2e-7, err_msg=k)
     ids = dec.eval().sample(feats.cuda(), None)
-    assert np.array_equal(ids.cpu().numpy(), OD.greedy_sample(params, feats, Lh).numpy())
+    assert tuple(ids.shape) == ((B, 20) if B > 1 else (20,))                 # models.py:67 `sampled_ids.squeeze()`
+    assert np.array_equal(ids.cpu().numpy().reshape(B, 20), OD.greedy_sample(params, feats, Lh).numpy())
 
 
 def test_decoder_rejects_bad_inputs():

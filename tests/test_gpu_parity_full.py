@@ -137,7 +137,10 @@ def test_cfg2_whole_train_steps_f32_and_bf16_vs_oracle():
         print("cfg2 params after 3 steps %-22s max|d| %.2e, fraction beyond 1e-5: %.2e" % (k, d.max().item(), frac))
         # the encoder output (2e-3 conv-stack difference, amplified by the batch-of-64 BatchNorm1d) is the LSTM's step-0
         # input, so the recurrent chain's small gradient elements change sign in both W_ih and W_hh (~10 %); the vocabulary
-        # side (embed, linear) sees it only through h: a fraction of a percent
+        # side (embed, linear) sees it only through h: a fraction of a percent.
+        # STRESS CHECK, NOT THE PARITY CLAIM: on this He-init stack the bound below cannot catch a wiring error on
+        # the encoder side -- the parameter parity claim (<= 1e-3 of the elements beyond 1e-5, LSTM and fc included) is
+        # test_cfg2_trained_like_whole_train_steps... below, on the well-conditioned stack; here only "nothing exploded"
         assert frac < (0.2 if ("lstm" in k or k == "resnet.fc.weight") else 5e-3), (k, frac)
     # head output of the two HIP modes on the SAME (now trained-for-3-steps-apart) weights is not comparable; compare
     # encoder features on the f32 model's weights instead
@@ -146,14 +149,17 @@ def test_cfg2_whole_train_steps_f32_and_bf16_vs_oracle():
     p32 = model32.encoder.pooled_features(di)
     p16 = model16.encoder.pooled_features(di)
     print("cfg2 pooled bf16 vs f32 HIP: rel-L2 %.4f cos %.5f" % (_rel(p16.cpu(), p32.cpu()), _cos(p16, p32)))
+    # (stress check on the chaotic He-init stack: garbage gives cos ~ 0; the tight bf16 bounds live in the trained-like tests)
     assert _rel(p16.cpu(), p32.cpu()) < 0.30 and _cos(p16, p32) > 0.95     # the chaos floor at full depth (module docstring)
 
 
 @pytest.mark.timeout(900)
 def test_cfg2_bf16_vs_f32_hip_train_two_steps_and_eval():
-    """Full size, autotuned variants, atomic statistics, slab-to-acc, hipGraph replay: bf16 pooled features and head
-    output against this library's f32 mode (itself oracle-checked at cfg1/cfg2 above) on the same weights -- train
-    mode (3 passes: both parities + the captured graph) and eval mode (fused epilogues)."""
+    """STRESS CASE (He-init weights: the 152-layer map is chaotic at bf16 resolution, so these bounds only say "finite, and
+    pointing the same way" -- the parity bounds are the trained-like tests at the end of this file).  Full size, autotuned
+    variants, atomic statistics, slab-to-acc, hipGraph replay: bf16 pooled features and head output against this library's f32
+    mode (itself oracle-checked at cfg1/cfg2 above) on the same weights -- train mode (3 passes: both parities + the captured
+    graph) and eval mode (fused epilogues)."""
     model32, ep, eb, dp, images, caps, lengths = _cfg2_models("f32", seed=7)
     model16, _, _, _, _, _, _ = _cfg2_models("bf16", seed=7)
     di = images.cuda()
@@ -318,66 +324,8 @@ def test_resnet152_conv_geometries_batch64_autotuned_vs_cpu(geom):
     assert ((s2 - rq).abs() / rq).max().item() < 1e-3
 
 
-def test_residual_fusion_into_next_conv1_matches_separate_bn_add(monkeypatch):
-    """bf16 training: bn3 + add + ReLU of an identity-residual bottleneck folded into the next bottleneck's conv1
-    (SAT_FUSE_RESIDUAL=1, opt-in) against the same stack with the separate normalise+add launches, three training
-    passes (both statistics parities + hipGraph replay), running statistics included"""
-    arch, E, B = dict(layers=(2, 3, 2, 2), width=16), 32, 8
-    gen = torch.Generator().manual_seed(61)
-    params, buffers = OE.init_encoder_params(E, arch, generator=gen, randomize_bn=True)
-    xs = [torch.randn(B, 3, 96, 96, generator=gen).cuda() for _ in range(3)]
-    monkeypatch.setenv("SAT_FUSE_RESIDUAL", "0")
-    plain = _encoder(arch, E, params, buffers, "bf16").train()
-    ref = [plain.pooled_features(x) for x in xs]
-    n_plain = next(iter(plain._programs.values())).n_ops
-    monkeypatch.setenv("SAT_FUSE_RESIDUAL", "1")
-    fused = _encoder(arch, E, params, buffers, "bf16").train()
-    out = [fused.pooled_features(x) for x in xs]
-    n_fused = next(iter(fused._programs.values())).n_ops
-    assert n_plain - n_fused == sum(arch["layers"]) - 4 - 1 + 1 - 1 or n_plain - n_fused >= 3, (n_plain, n_fused)
-    for a, b in zip(out, ref):
-        r = _rel(a.cpu(), b.cpu())
-        print("fused-residual vs separate bn_add: rel-L2 %.5f" % r)
-        assert r < 0.01, r                     # same arithmetic; an occasional 1-ulp bf16 flip from fma contraction
-    sa, sb = plain.state_dict(), fused.state_dict()
-    for k in sa:
-        if "running" in k:
-            assert torch.allclose(sa[k], sb[k], rtol=2e-2, atol=2e-3), k
-    bufs = {k: v.clone() for k, v in buffers.items()}
-    ref_bf = OE.resnet_forward_bf16_storage(params, xs[0].cpu(), arch)
-    assert _rel(out[0].cpu(), ref_bf) < 0.02
-
-
-def test_residual_fusion_in_place_by_conv_du_kernel_matches_separate_bn_add(monkeypatch):
-    """SAT_FUSE_RESIDUAL=2 (opt-in): inside layer 3 the previous block's bn3 + add + ReLU is formed by conv_du_kernel in the next
-    conv1, y written over the raw conv3 tensor in place; the other layers keep their in-place normalise+add launches.  Same pooled
-    features as the default program to bf16 noise (the conv1 statistics are summed over 64-row tiles there), same launch
-    bookkeeping: 35 normalise+add launches gone; models.py:27."""
-    arch, E = OE.RESNET152, 64
-    gen = torch.Generator().manual_seed(7)
-    params, buffers = OE.init_encoder_params(E, arch, generator=gen, conditioning="trained_like")     # (the He-init stack is chaotic)
-    imgs = torch.randn(8, 3, 224, 224, generator=gen).cuda()
-    monkeypatch.setenv("SAT_FUSE_RESIDUAL", "0")
-    enc0 = _encoder(arch, E, params, buffers, "bf16").train()
-    with torch.no_grad():
-        ref = enc0.pooled_features(imgs).clone()
-    n_plain = next(iter(enc0._programs.values())).n_ops
-    monkeypatch.setenv("SAT_FUSE_RESIDUAL", "2")
-    enc1 = _encoder(arch, E, params, buffers, "bf16").train()
-    with torch.no_grad():
-        got = enc1.pooled_features(imgs)
-    prog = next(iter(enc1._programs.values()))
-    assert n_plain - prog.n_ops == 35                       # the transitions inside layer 3
-    n_dual = sum(1 for i in range(prog.n_ops) if prog.ops[i].kind == L.OP_CONV and prog.ops[i].out1)
-    assert n_dual == 35
-    assert all(prog.ops[i].out1 == prog.ops[i].in0 for i in range(prog.n_ops) if prog.ops[i].kind == L.OP_CONV and prog.ops[i].out1)
-    rel = _rel(got.cpu(), ref.cpu())
-    print("conv_du_kernel program vs default program, pooled features: rel-L2 %.5f" % rel)
-    assert rel < 0.01, rel
-
-
 def test_default_program_fuses_bn1_where_the_patch_kernel_runs():
-    """The default bf16 training program of ResNet-152 (SAT_FUSE_BN1=2): conv2 of every stride-1 bottleneck with 128..512 planes and
+    """The default bf16 training program of ResNet-152: conv2 of every stride-1 bottleneck with 128..512 planes and
     rows of <= 31 pixels carries bn1 + ReLU itself (conv_pr_kernel's LDS-resident patch) -- 44 of the 50 normalise+ReLU launches are
     gone (7 + 35 + 2 in layers 2, 3, 4), six remain (layer 1: 64 planes; the stride-2 first blocks of layers 2-4)."""
     torch.manual_seed(3)
@@ -393,24 +341,25 @@ def test_default_program_fuses_bn1_where_the_patch_kernel_runs():
 
 
 def test_lookahead_is_bitwise_identical_at_the_benchmarked_configuration():
-    """BASELINE configs[1] itself (batch 64, 224x224, E=256 / H=512 / V=10000, bf16 stack, autotuned variants, hipGraph replay): five
-    steps with the next three batches' conv stacks running ahead on side streams give the same losses, parameters and BatchNorm
-    running statistics, bit for bit, as five strictly sequential steps."""
+    """BASELINE configs[1] itself (batch 64, 224x224, E=256 / H=512 / V=10000, bf16 stack, autotuned variants, hipGraph replay): seven
+    steps with the next six batches' conv stacks running ahead on side streams as GROUPED programs (two batches per launch) give
+    the same losses, parameters and BatchNorm running statistics, bit for bit, as seven strictly sequential steps."""
     def run(lookahead):
         torch.manual_seed(123)
         model = sat.ShowAndTell(256, 512, 10000, 1, compute_dtype="bf16").cuda().train()
         ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
         g = torch.Generator().manual_seed(77)
-        batches = [torch.randn(64, 3, 224, 224, generator=g).cuda() for _ in range(4)]
+        nb = model.encoder.lookahead_depth + 1
+        batches = [torch.randn(64, 3, 224, 224, generator=g).cuda() for _ in range(nb)]
         caps = torch.randint(4, 10000, (64, 20), generator=g)
         caps[:, 0], caps[:, -1] = 1, 2
         caps = caps.cuda()
         lengths = [20] * 64
         losses = []
-        n = 5
+        n = 7
         for i in range(n):
-            nxt = [batches[j % 4] for j in range(i + 1, i + 1 + model.encoder.lookahead_depth) if j < n] if lookahead else None
-            losses.append(ts.step(batches[i % 4], caps, lengths, next_images=nxt or None))
+            nxt = [batches[j % nb] for j in range(i + 1, i + 1 + model.encoder.lookahead_depth) if j < n] if lookahead else None
+            losses.append(ts.step(batches[i % nb], caps, lengths, next_images=nxt or None))
         torch.cuda.synchronize()
         rs = torch.cat([torch.cat([bn.running_mean, bn.running_var]) for bn in model.encoder.resnet.bns()])
         return torch.cat(losses).cpu(), ts.flat.params.clone().cpu(), rs.cpu()

@@ -78,9 +78,8 @@ def bench_conv(shapes=None, reps=20):
         if mode == "partial":
             o.stat_partial, o.tiles_m = part.data_ptr(), tiles
         elif mode == "acc":
-            shards = int(os.environ.get("SAT_MB_SHARDS", "1"))
-            acc = torch.zeros(2, shards, 2, Cout, dtype=torch.int64, device="cuda")
-            o.stat_acc, o.stat_shards = acc.data_ptr(), shards
+            acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc = acc.data_ptr()
         ops = (L.SatOp * 1)(o)
         if os.environ.get("SAT_VARIANT"):
             ops[0].variant = int(os.environ["SAT_VARIANT"])
@@ -192,122 +191,3 @@ def bench_gemm_bf16(reps=30):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gemm16":
     bench_gemm_bf16()
-
-
-def bench_xp(reps=20):
-    """conv_xp_kernel (variants 40-42) against the ring kernel on expansion 1x1 convs; the workgroup-count sweep (16x16 images:
-    8 workgroups per image at CT = 2, K = 256, N = 1024) shows how many workgroups a CU holds at once"""
-    lib = L.load()
-
-    def one(N, H, W, Cin, Cout, v, fused=1):
-        x = torch.randn(N, H, W, Cin, device="cuda").bfloat16()
-        w = (torch.randn(Cout, Cin, device="cuda") / 16).bfloat16()
-        out = torch.empty(N * H * W, Cout, device="cuda", dtype=torch.bfloat16)
-        acc = torch.zeros(2, 8, 2, Cout, dtype=torch.int64, device="cuda")
-        sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
-        o = L.SatOp()
-        o.kind, o.dtype = L.OP_CONV, L.SAT_BF16
-        o.in0, o.w, o.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
-        o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, H, W, Cout
-        o.KH, o.KW, o.stride, o.pad = 1, 1, 1, 0
-        o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
-        o.stat_acc, o.stat_shards, o.variant = acc.data_ptr(), 8, v
-        if fused:
-            o.scale0, o.shift0 = sc.data_ptr(), sh.data_ptr()
-        ops = (L.SatOp * 1)(o)
-        return time_ops(ops, 1, reps)
-    for N in (16, 32, 48, 64, 96, 128):
-        print("sweep 16x16 images, N=%3d (%4d workgroups at CT=2): v41 %.1f us   v40 %.1f   v42 %.1f   v3 %.1f" % (
-            N, 8 * N, one(N, 16, 16, 256, 1024, 41), one(N, 16, 16, 256, 1024, 40), one(N, 16, 16, 256, 1024, 42), one(N, 16, 16, 256, 1024, 3)))
-    for (N, H, Cin, Cout) in ((64, 14, 256, 1024), (64, 28, 128, 512), (64, 56, 64, 256)):
-        for fused in (0, 1):
-            print("N=%d %dx%d %d->%d fused=%d: " % (N, H, H, Cin, Cout, fused) +
-                  "  ".join("v%d %.1f" % (v, one(N, H, H, Cin, Cout, v, fused)) for v in (3, 2, 1, 40, 41, 42) if not (v == 42 and Cout < 512)))
-
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "xp":
-    bench_xp()
-
-
-def xp_stamps(variant=41, fused=1):
-    """s_memtime stamps of conv_xp_kernel workgroups at the layer-3 conv3 geometry (0 start, 1 loads issued, 2 table built, 3 panel
-    landed, 4 transform done, 5 first column tile's K loop done, 6 its stores issued (a store wave), 7 end)"""
-    lib = L.load()
-    N, H, W, Cin, Cout = 64, 14, 14, 256, 1024
-    x = torch.randn(N, H, W, Cin, device="cuda").bfloat16()
-    w = (torch.randn(Cout, Cin, device="cuda") / 16).bfloat16()
-    out = torch.empty(N * H * W, Cout, device="cuda", dtype=torch.bfloat16)
-    acc = torch.zeros(2, 8, 2, Cout, dtype=torch.int64, device="cuda")
-    sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
-    o = L.SatOp()
-    o.kind, o.dtype = L.OP_CONV, L.SAT_BF16
-    o.in0, o.w, o.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
-    o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, H, W, Cout
-    o.KH, o.KW, o.stride, o.pad = 1, 1, 1, 0
-    o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
-    o.stat_acc, o.stat_shards, o.variant = acc.data_ptr(), 8, variant
-    if fused:
-        o.scale0, o.shift0 = sc.data_ptr(), sh.data_ptr()
-    ops = (L.SatOp * 1)(o)
-    stamps = torch.zeros(1024, 8, dtype=torch.int64, device="cuda")
-    for _ in range(3):
-        L.check(lib.sat_run_ops(ops, 1, L.stream()))
-    torch.cuda.synchronize()
-    L.check(lib.sat_conv3_fused_debug(stamps.data_ptr()))
-    L.check(lib.sat_run_ops(ops, 1, L.stream()))
-    torch.cuda.synchronize()
-    L.check(lib.sat_conv3_fused_debug(None))
-    st = stamps.cpu()
-    live = st[:, 0] > 0
-    st = st[live]
-    t0 = st[:, 0].min()
-    rel = (st - t0).double()
-    print("variant %d fused %d: %d workgroups; s_memtime ticks relative to the first start" % (variant, fused, st.shape[0]))
-    print("  start  : min %.0f  median %.0f  max %.0f" % (rel[:, 0].min(), rel[:, 0].median(), rel[:, 0].max()))
-    d = (st[:, 1:] - st[:, :-1]).double()
-    names = ["issue+A loads", "table", "wait panel", "transform", "K loop tile 0", "epilogue 0 (store wave)", "rest"]
-    for k, nm in enumerate(names):
-        print("  %-26s median %7.0f   p90 %7.0f" % (nm, d[:, k].median(), d[:, k].quantile(0.9)))
-    print("  lifetime                   median %7.0f   max %7.0f;  last end %.0f" % ((st[:, 7] - st[:, 0]).double().median(), (st[:, 7] - st[:, 0]).max(), rel[:, 7].max()))
-
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "xpstamps":
-    for v in (41, 42):
-        for f in (0, 1):
-            xp_stamps(v, f)
-
-
-def bench_du(reps=20):
-    """dual-source conv1 of layer 3 (M = 12544, K = 1024, N = 256): conv_du_kernel (44) against the dual ring kernels (22, 24) and against
-    the un-fused pair (normalise+add launch, then the plain conv)"""
-    lib = L.load()
-    N, H, W, Cin, Cout = 64, 14, 14, 1024, 256
-    M = N * H * W
-    c3 = torch.randn(M, Cin, device="cuda").bfloat16()
-    resid = torch.randn(M, Cin, device="cuda").clamp(min=0).bfloat16()
-    w = (torch.randn(Cout, Cin, device="cuda") / 32).bfloat16()
-    out = torch.empty(M, Cout, device="cuda", dtype=torch.bfloat16)
-    yd = torch.empty(M, Cin, device="cuda", dtype=torch.bfloat16)
-    own = torch.zeros(2, 8, 2, Cout, dtype=torch.int64, device="cuda")
-    sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
-
-    def conv(v, dual, in_place=False):
-        o = L.SatOp()
-        o.kind, o.dtype = L.OP_CONV, L.SAT_BF16
-        o.in0, o.w, o.out = c3.data_ptr(), w.data_ptr(), out.data_ptr()
-        o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, H, W, Cout
-        o.KH, o.KW, o.stride, o.pad = 1, 1, 1, 0
-        o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
-        o.stat_acc, o.stat_shards, o.variant = own.data_ptr(), 8, v
-        if dual:
-            o.in1, o.out1 = resid.data_ptr(), (c3 if in_place else yd).data_ptr()
-            o.scale0, o.shift0 = sc.data_ptr(), sh.data_ptr()
-        return o
-    for name, o in (("plain conv v12 (no fusion; + a normalise+add launch of ~19 us in the program)", conv(12, False)),
-                    ("plain conv v16", conv(16, False)), ("dual ring v22", conv(22, True)), ("dual ring v24", conv(24, True)),
-                    ("conv_du_kernel v44", conv(44, True)), ("conv_du_kernel v44 in place", conv(44, True, True))):
-        print("%-90s %.1f us" % (name, time_ops((L.SatOp * 1)(o), 1, reps)))
-
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "du":
-    bench_du()
