@@ -543,9 +543,11 @@ def main():
     images, caps, lengths = synth_batch(torch, wl["batch"], wl["vocab"], wl["cap_len"], wl["image"], dev, 123 + rank)
     global_tokens = world * sum(l - 1 for l in lengths)
     if use_dist and world > 1:
-        # build (and autotune) the conv-stack program on rank 0 first, then everywhere from rank 0's table
+        # build (and autotune) the conv-stack programs on rank 0 first, then everywhere from rank 0's table
         if rank == 0:
             model.encoder._program(images)
+            if args.lookahead:
+                model.encoder.build_lookahead(images)
             torch.cuda.synchronize()
         dist.barrier()
 
@@ -567,9 +569,8 @@ def main():
             out = dp.step((batches[i % nb], caps, lengths), global_tokens, next_images=nxt or None)
         return out
 
-    prio_env = os.environ.get("SAT_MAIN_STREAM_PRIO")          # experiment: run the step's own stream at another priority
-    if prio_env is not None:
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(prio_env)))
+    if args.lookahead:
+        model.encoder.build_lookahead(images)          # op programs of the look-ahead instances: autotune + graph capture, before any step
     if args.warmup:
         loss = run_steps(args.warmup)
     # The timed region: EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks.  K = 20 steps are 0.1 s of

@@ -278,6 +278,23 @@ class EncoderCNN(nn.Module):
             started += 1 if self.prefetch(im) else 0
         return started
 
+    def build_lookahead(self, images):
+        """Build (autotune, capture the hipGraphs of) every op program the look-ahead of batches shaped like `images` will use,
+        now instead of inside the first steps: each look-ahead instance runs four times on `images` (both statistics parities,
+        eager then captured).  Touches no model state: look-ahead instances keep their running-statistics updates deferred, and
+        nothing here applies them."""
+        L.require_gpu(images, "images")
+        G = self.lookahead_groups if (self.training and self.compute_dtype == "bf16" and not hasattr(self.resnet, "program")) else 1
+        progs = []
+        with torch.no_grad():
+            if G > 1:
+                progs += [(self._program(images, instance="g%d" % k, groups=G), [images] * G) for k in range(max(1, self.lookahead_depth // G))]
+            progs += [(self._program(images, instance=0), images)]          # the single a left-over batch runs on
+            for prog, arg in progs:
+                for _ in range(4):
+                    prog.run(arg)
+        torch.cuda.current_stream(images.device).synchronize()
+
     def _take_prefetched(self, images):
         """(program instance, group index) of a prefetched `images` whose run has finished (the current stream now waits for
         it), or None.  The caller reads `prog.pooled_of(g)` and then calls `prog.apply_running_stats(g)` -- both on the current

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-kernel-class counter sums of ONE training step (the last full one) of a `rocprofv3 --pmc` run of bench.py.
-    python tools/pmc_summary.py <rocprof output dir>   -> JSON on stdout"""
+"""Per-kernel-class counter sums of one segment of tools/pmc_workload.py under `rocprofv3 --pmc`: "program" = one in-order pass of
+the grouped look-ahead program (default), "step" = one whole sequential training step.
+    python tools/pmc_summary.py <rocprof output dir> [program|step]   -> JSON on stdout"""
 import csv
 import glob
 import json
@@ -22,12 +23,11 @@ def main():
                                                "end": int(r["End_Timestamp"]), "c": {}})
         e["c"][r["Counter_Name"]] = e["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     rows = sorted(disp.values(), key=lambda e: e["start"])
-    ip = [i for i, e in enumerate(rows) if "image_prep" in e["name"]]
-    adam = [i for i, e in enumerate(rows) if "clamp_adam" in e["name"]]
-    last = adam[-1]            # last FULL training step (the roofline passes after it run the encoder without an optimizer step)
-    s = [i for i in ip if i < last][-1]
-    en = [last]
-    step = rows[s:en[0] + 1]
+    # tools/pmc_workload.py: marker | one pass of the grouped look-ahead program | marker | one sequential training step | marker
+    marks = [i for i, e in enumerate(rows) if "kept_tokens" in e["name"]][-3:]
+    seg = sys.argv[2] if len(sys.argv) > 2 else "program"
+    a, b = (marks[0], marks[1]) if seg == "program" else (marks[1], marks[2])
+    step = [e for e in rows[a + 1:b] if "kept_tokens" not in e["name"]]
     agg = defaultdict(lambda: defaultdict(float))
     for e in step:
         k = short(e["name"])
@@ -36,7 +36,7 @@ def main():
         agg[k]["duration_us"] += (e["end"] - e["start"]) / 1e3
         for n, v in e["c"].items():
             agg[k][n] += v
-    out = {"_note": "one training step of bench.py (cfg2) under rocprofv3 --pmc; SQ_VALU_MFMA_BUSY_CYCLES sums the matrix "
+    out = {"_segment": seg, "_note": "tools/pmc_workload.py (cfg2) under rocprofv3 --pmc; SQ_VALU_MFMA_BUSY_CYCLES sums the matrix "
                     "pipes' busy cycles over the chip's 1024 SIMDs (32 per v_mfma_f32_32x32x16_bf16, 64 per "
                     "v_mfma_f32_32x32x2_f32); mfma_busy_frac prices every SIMD for the kernels' whole duration at the "
                     "2.4 GHz peak clock (the chip holds 1.5-2.1 GHz under MFMA load, so true occupancy is higher)"}
