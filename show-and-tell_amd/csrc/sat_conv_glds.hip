@@ -609,7 +609,7 @@ int launch_glds(ConvArgs& a, int groups, hipStream_t s) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows).
 // LDS = S * (BM/8 + BN/8) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, xp, pr; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel
+struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128}, {128, 3, 8, 0, 0, 128}, {128, 2, 8, 0, 0, 128}, {64, 4, 8, 0, 0, 128}, {64, 3, 8, 0, 0, 128},
     {64, 2, 8, 0, 0, 128}, {128, 4, 4, 0, 0, 128}, {128, 2, 4, 0, 0, 128}, {64, 3, 4, 0, 0, 128}, {64, 2, 4, 0, 0, 128},
@@ -620,12 +620,14 @@ constexpr Variant kVariants[] = {
     {128, 3, 8, 0, 0, 64}, {128, 2, 8, 0, 0, 64},                                                                        // 64-row tiles: 2 workgroups per CU on the N = 256 layers
     {128, 5, 4, 0, 0, 128, 1}, {128, 5, 4, 0, 0, 128, 2}, {128, 5, 4, 0, 0, 128, 4},                                     // register-resident A panel (expansion 1x1 convs, sat_conv_xp.inc)
     {128, 6, 8, 1, 0, 128, 0, 1},                                                                                        // LDS-resident input patch (3x3 / stride 1, sat_conv_pr.inc)
+    {64, 1, 4, 0, 0, 128, 0, 0, 1},                                                                                      // persistent stem kernel: weights in registers, input row segments in LDS (sat_conv_stem.inc)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
 
 #include "sat_conv_xp.inc"
 #include "sat_conv_pr.inc"
+#include "sat_conv_stem.inc"
 
 int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
     switch (v) {
@@ -659,6 +661,7 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 27: return launch_xp(a, 2, groups, s);
         case 28: return launch_xp(a, 4, groups, s);
         case 29: return launch_pr(a, groups, s);
+        case 30: return launch_stem(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -669,6 +672,7 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
 // grouped launch may pick any variant of its ungrouped twin's signature and stay bit-identical to it per batch.
 int stat_signature(int v) {
     const Variant& k = kVariants[v];
+    if (k.stem) return 3000;
     if (k.pr) return 2000;
     if (k.xp) return 1000;
     const int cw = k.spec ? k.nw / 2 : k.nw;
@@ -716,6 +720,7 @@ int op_groups(const sat_op* op) { return op->groups > 1 ? op->groups : 1; }
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
+    if (k.stem) return stem_ok(a);
     if (k.pr) return pr_ok(a);
     if (k.xp) return xp_ok(a, k.xp);
     if (k.bn >= 128 && a.N <= 64) return false;
@@ -730,6 +735,7 @@ int heuristic_variant(const ConvArgs& a) {
     // 128x128 with a deep ring when it still leaves >= 2 tiles per CU and K is long enough to use the ring;
     // otherwise 128x64 with a shallower ring (more workgroups per CU to overlap prologue/epilogue phases)
     if (a.in_affine && !a.linear) return kVariantPr;      // 3x3 with a fused input BatchNorm: the LDS-resident patch (the builder fuses bn1 only where it can run)
+    if (stem_ok(a)) return 30;                            // the op program's stem layout: the persistent stem kernel
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const int nk = sat_cdiv(a.K, 64);
     if (a.N > 64 && t128 >= 512) return nk <= 4 ? 2 : 0;

@@ -107,7 +107,7 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 30
+NUM_CONV_VARIANTS = 31
 PLAIN_CONV_VARIANTS = list(range(1, 27))      # ring kernel variants (27..29: conv_xp_kernel, 30: conv_pr_kernel -- their own tests)
 
 
@@ -288,6 +288,129 @@ def test_conv3x3_lds_resident_patch_with_fused_input_bn_relu(lib, N, H, W, Cin, 
         assert int(gx["iacc"][1].abs().sum()) == 0
         np.testing.assert_allclose(gx["rm"].cpu().numpy(), (0.1 * mean).numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(gx["rv"].cpu().numpy(), (0.9 + 0.1 * var * M / (M - 1)).numpy(), rtol=1e-4)
+
+
+def _stem_op(x_pad, w, Ho, Wo, groups=1):
+    """the op program's stem conv (resnet.ConvStackProgram): a 7 x 1 kernel over rows of 8 pixels x 4 channels of a zero-bordered
+    NHWC4 image, stride 2; x_pad bf16 [G*N][Hp][Wp][4] on the device, w bf16 [64][224]"""
+    GN, Hp, Wp, _ = x_pad.shape
+    N = GN // groups
+    out = torch.full((GN * Ho * Wo, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+    tiles = L.load().sat_conv_tiles_m(N * Ho * Wo)
+    part = torch.full((groups, tiles, 2, 64), float("nan"), device="cuda")
+    o = L.SatOp()
+    o.kind, o.dtype, o.groups = L.OP_CONV, L.SAT_BF16, groups
+    o.in0, o.w, o.out = x_pad.data_ptr(), w.data_ptr(), out.data_ptr()
+    o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, Hp, Wp, 32, Ho, Wo, 64
+    o.KH, o.KW, o.stride, o.pad = 7, 1, 2, 0
+    o.sN, o.sH, o.sW = Hp * Wp * 4, Wp * 4, 4
+    o.stat_partial, o.tiles_m = part.data_ptr(), tiles
+    return o, out, part
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 224, 224), (2, 160, 192), (1, 130, 128), (5, 224, 224)])
+def test_conv_stem_kernel_is_bit_identical_to_the_ring_kernel(lib, N, H, W):
+    """conv_stem_kernel (variant 31: persistent workgroups, weights in registers, input row segments in LDS) on the op program's
+    stem layout against the ring kernel (variant 10) and the f64 definition: output BITWISE equal (same MFMA, same K order),
+    per-tile statistics slabs equal to rounding; tiles that span two and three (image, output row) pairs, a ragged last tile"""
+    g = torch.Generator().manual_seed(N * 7 + W)
+    Hp, Wp = H + 6, (W + 8 + 1) // 2 * 2
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    x = torch.zeros(N, Hp, Wp, 4)
+    x[:, 3:3 + H, 3:3 + W, :3] = torch.randn(N, H, W, 3, generator=g)
+    w = torch.zeros(64, 7, 8, 4)
+    w[:, :, :7, :3] = torch.randn(64, 7, 7, 3, generator=g) / 12.0
+    xd, wd = x.bfloat16().cuda(), w.reshape(64, 224).bfloat16().cuda()
+    res = {}
+    for v in (10, 31, 0):                               # 0: the heuristic must pick the stem kernel for this layout
+        o, out, part = _stem_op(xd, wd, Ho, Wo)
+        o.variant = v
+        L.check(lib.sat_run_ops(C.pointer(o), 1, st()))
+        sync()
+        res[v] = (out.clone(), part.clone())
+    assert torch.isfinite(res[31][0].float()).all()
+    assert torch.equal(res[31][0], res[10][0]) and torch.equal(res[0][0], res[31][0])
+    torch.testing.assert_close(res[31][1], res[10][1], rtol=2e-5, atol=2e-4)
+    assert torch.equal(res[0][1], res[31][1])
+    # f64 definition on the same bf16 operands: windows of 8 pixels x 4 channels per kernel row
+    xf, wf = xd.float().cpu().double(), wd.float().cpu().double().reshape(64, 7, 32)
+    rows = torch.stack([xf[:, kh:kh + 2 * Ho:2].reshape(N, Ho, Wp * 4) for kh in range(7)], 2)      # [N, Ho, 7, Wp*4]
+    win = torch.stack([rows[..., 8 * wo:8 * wo + 32] for wo in range(Wo)], 2)                        # [N, Ho, Wo, 7, 32]
+    ref = torch.einsum("nhwkc,okc->nhwo", win, wf).reshape(-1, 64)
+    assert (res[31][0].float().cpu().double() - ref).abs().max().item() < 2e-2
+    np.testing.assert_allclose(res[31][1][0, :, 0].cpu().double().sum(0).numpy(), ref.sum(0).numpy(), rtol=0, atol=2e-3 * ref.shape[0] ** 0.5 + 1e-3)
+
+
+@pytest.mark.parametrize("kind", ["ring", "ring_wide", "xp", "pr", "stem"])
+def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
+    """sat_op.groups = 3: three batches in ONE launch (grid.y = group; activations, statistics slabs / integer accumulators and the
+    operand-BatchNorm accumulators + running-statistics log moved by their group strides, weights shared) against three launches,
+    one per batch, of the same variant: outputs, slabs, integer sums and the running-statistics log BITWISE equal per batch --
+    every kernel family of the conv stack (models.py:27 under the look-ahead of DESIGN 3.1d)"""
+    G = 3
+    g = torch.Generator().manual_seed(len(kind) * 13)
+    if kind == "stem":
+        N, H, W = 2, 224, 224
+        Hp, Wp, Ho, Wo = H + 6, 232, 112, 112
+        x = torch.zeros(G * N, Hp, Wp, 4)
+        x[:, 3:3 + H, 3:3 + W, :3] = torch.randn(G * N, H, W, 3, generator=g)
+        w = torch.zeros(64, 7, 8, 4)
+        w[:, :, :7, :3] = torch.randn(64, 7, 7, 3, generator=g) / 12.0
+        xd, wd = x.bfloat16().cuda(), w.reshape(64, 224).bfloat16().cuda()
+        og, outg, partg = _stem_op(xd, wd, Ho, Wo, groups=G)
+        og.variant = 31
+        L.check(lib.sat_run_ops(C.pointer(og), 1, st()))
+        sync()
+        M = N * Ho * Wo
+        for k in range(G):
+            o1, out1, part1 = _stem_op(xd[k * N:(k + 1) * N].contiguous(), wd, Ho, Wo)
+            o1.variant = 31
+            L.check(lib.sat_run_ops(C.pointer(o1), 1, st()))
+            sync()
+            assert torch.equal(outg[k * M:(k + 1) * M], out1) and torch.equal(partg[k], part1[0])
+        return
+    geo = {"ring": (4, 13, 11, 128, 192, 1, 2), "ring_wide": (4, 14, 14, 256, 512, 1, 22), "xp": (5, 12, 12, 256, 1024, 1, 28),
+           "pr": (5, 14, 14, 128, 256, 3, 30)}[kind]
+    N, H, W, Cin, Cout, k, variant = geo
+    pad = 1 if k == 3 else 0
+    x = (torch.randn(G * N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    M = N * H * W
+    with_in_bn = kind in ("xp", "pr")
+
+    def run(xs, groups):
+        o, keep, _ = _conv_op(L.SAT_BF16, xs.float(), w.float(), 1, pad, stats=False)
+        o.N, o.groups, o.variant = N, groups, variant
+        acc = torch.zeros(groups, 2, 2, Cout, dtype=torch.int64, device="cuda")
+        o.stat_acc = acc.data_ptr()
+        extra = {"acc": acc}
+        if with_in_bn:
+            iacc = torch.zeros(groups, 2, 2, Cin, dtype=torch.int64, device="cuda")
+            for q in range(groups):
+                xf = xs[q * N:(q + 1) * N].float().reshape(-1, Cin).double()
+                iacc[q, 0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
+                iacc[q, 0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
+            iacc[:, 1] = 777
+            gd, bd, log = cu(gamma), cu(beta), torch.zeros(groups, 2, Cin, device="cuda")
+            o.stat_acc1, o.gamma1, o.beta1 = iacc.data_ptr(), gd.data_ptr(), bd.data_ptr()
+            o.running_mean1, o.running_var1 = log[0, 0].data_ptr(), log[0, 1].data_ptr()
+            o.count, o.momentum, o.eps = M, 1.0, 1e-5
+            extra.update(iacc=iacc, gd=gd, bd=bd, log=log)
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+        sync()
+        return keep[2], extra
+
+    outg, xg = run(x, G)
+    assert torch.isfinite(outg.float()).all()
+    for q in range(G):
+        out1, x1 = run(x[q * N:(q + 1) * N].contiguous(), 1)
+        assert torch.equal(outg[q * M:(q + 1) * M], out1[:M]), q
+        assert torch.equal(xg["acc"][q], x1["acc"][0]), q
+        if with_in_bn:
+            assert torch.equal(xg["log"][q], x1["log"][0]) and int(xg["iacc"][q, 1].abs().sum()) == 0
+    if with_in_bn:                                      # the batches differ, so do their operand statistics
+        assert not torch.equal(xg["log"][0], xg["log"][1])
 
 
 def test_conv_autotune_sets_a_variant_and_keeps_results(lib):
