@@ -537,7 +537,7 @@ def main():
     model = sat.ShowAndTell(wl["embed"], wl["hidden"], wl["vocab"], wl["layers"], compute_dtype="bf16", **kw).to(dev).train()
     ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
     dp = sat.DataParallelStep(ts)
-    if args.force_dist and os.environ.get("SAT_FORCE_DIST_INIT_ONLY", "0") != "1":
+    if args.force_dist:
         dp.world = 2          # take the multi-rank code path (async bucket all-reduces) on the single rank
         dp.cap_lookahead()    # ... with the look-ahead depth that path runs at
     images, caps, lengths = synth_batch(torch, wl["batch"], wl["vocab"], wl["cap_len"], wl["image"], dev, 123 + rank)

@@ -173,7 +173,7 @@ class EncoderCNN(nn.Module):
             # room for BOTH modes of one shape with every look-ahead instance (the reference alternates train and eval,
             # train.py:157-159: None + depth instances each), plus a partial last batch; evict the least recently used one
             # program at a time -- a program is ~0.9 GB of activations and its captured graphs at cfg 2
-            cap = 2 * (self.lookahead_depth + 1) + 2
+            cap = 2 * (2 * self._n_slots() + 2) + 2
             while len(self._programs) >= cap:
                 old = next(iter(self._programs))
                 if any(e["prog"] is self._programs[old] for e in self._inflight):
@@ -196,23 +196,35 @@ class EncoderCNN(nn.Module):
     LOOKAHEAD_DEPTH = {"inception_v3": 2}
     LOOKAHEAD_GROUPS = 2
 
-    def _side_stream(self, device, slot, n_slots):
-        """side stream of look-ahead slot `slot` of `n_slots`: one per slot, or -- `lookahead_streams` fewer than slots -- round
-        robin in prefetch order (a later stack then queues behind an earlier one on its hardware queue)"""
+    # Look-ahead RUN SLOTS: at most `lookahead_depth // lookahead_groups` op-program runs are in flight (3 by default: more than
+    # three side streams beside the main one cost a hardware queue), each on its slot's side stream; a slot holds a
+    # grouped run (instance "g<k>", `lookahead_groups` batches) or a single one (instance k)
+    def _n_slots(self):
+        return max(1, self.lookahead_depth // max(1, self.lookahead_groups))
+
+    def _slot_stream(self, device, slot):
+        """side stream of run slot `slot`: one per slot, or -- `lookahead_streams` fewer than slots -- round robin in prefetch
+        order (a later run then queues behind an earlier one on its hardware queue)"""
+        n_slots = self._n_slots()
         n_streams = self.lookahead_streams or n_slots
-        idx = slot if n_streams >= n_slots else self._pf_seq % n_streams
+        idx = slot if (n_streams >= n_slots and slot < n_slots) else self._pf_seq % n_streams
         self._pf_seq += 1
         return lookahead_stream(device, idx)
 
-    def _batches_in_flight(self):
-        return sum(len(e["images"]) for e in self._inflight)
+    def _free_slot(self, extra=False):
+        busy = {e["slot"] for e in self._inflight}
+        for k in range(self._n_slots() + (1 if extra else 0)):
+            if k not in busy:
+                return k
+        return None
 
     def _is_in_flight(self, images):
         return any(im is images for e in self._inflight for im in e["images"])
 
-    def _launch(self, ims, inst, groups, n_slots):
+    def _launch(self, ims, slot, groups):
         dev = ims[0].device
-        stream = self._side_stream(dev, inst if isinstance(inst, int) else int(inst[1:]), n_slots)
+        inst = ("g%d" % slot) if groups > 1 else slot
+        stream = self._slot_stream(dev, slot)
         stream.wait_stream(torch.cuda.current_stream(dev))             # the images, and this instance's previous consumers
         for im in ims:
             ready = getattr(im, "_sat_ready_event", None)              # a DevicePrefetcher copy still in flight on its own stream
@@ -225,54 +237,59 @@ class EncoderCNN(nn.Module):
                 im.record_stream(stream)                               # the side stream reads the tensor: the allocator must know
             ev = torch.cuda.Event()
             ev.record(stream)
-        self._inflight.append(dict(images=list(ims), taken=[False] * len(ims), inst=inst, ev=ev, prog=prog,
+        self._inflight.append(dict(images=list(ims), taken=[False] * len(ims), slot=slot, ev=ev, prog=prog,
                                    sig=weights_signature(self.resnet), vers=[im._version for im in ims]))
 
-    def prefetch(self, images):
+    def prefetch(self, images, _extra=False):
         """Start the conv stack (frozen, `no_grad`: models.py:14-15, 25-27) of a LATER batch on a side stream.  Its pooled
         features depend on the images and the frozen weights only, not on the optimizer steps in between, so computing them
-        early changes nothing but the schedule: up to `lookahead_depth` stacks run next to each other (one's HBM-bound
+        early changes nothing but the schedule: up to three stacks run next to each other (one's HBM-bound
         BatchNorm passes and under-filled launches under the other's convs) and under the current batch's head / decoder /
         backward / optimizer.  Each batch keeps its own BatchNorm batch statistics (separate program instances); the model's
         running statistics are updated when the batch is consumed, i.e. in batch order.  `forward(images)` /
         `pooled_features(images)` / `TrainStep.step(images, ...)` of the SAME tensor object later picks the result up.
-        Returns False (and does nothing) when the tensor is already in flight or `lookahead_depth` batches are."""
+        Returns False (and does nothing) when the tensor is already in flight or every run slot is taken."""
         if images is None or images.dim() != 4 or self._is_in_flight(images):
             return False
-        if self._batches_in_flight() >= self.lookahead_depth:
+        slot = self._free_slot(extra=_extra)
+        if slot is None:
             return False
         L.require_gpu(images, "images")
-        busy = {e["inst"] for e in self._inflight}
-        inst = next(i for i in range(self.lookahead_depth) if i not in busy)
-        self._launch([images], inst, 1, self.lookahead_depth)
+        self._launch([images], slot, 1)
         return True
 
     def prefetch_many(self, images_list):
         """`prefetch` for the next few batches IN ORDER.  With `lookahead_groups` = G > 1 (ResNet, bf16, train mode) G batches
         that are not in flight yet start together as ONE grouped program (every launch of the stack covers G batches; each
         batch's statistics and features are bit for bit those of its own ungrouped run); a batch left over is started alone
-        only when it is the very next one.  Returns the number of batches started."""
+        when it is the very next one or the list is shorter than the look-ahead window (the end of the data).  Returns the
+        number of batches started."""
         ims = [im for im in images_list if im is not None and im.dim() == 4]
         G = self.lookahead_groups if (self.training and self.compute_dtype == "bf16" and not hasattr(self.resnet, "program")) else 1
         started = 0
         new = [im for im in ims if not self._is_in_flight(im)]
         if G > 1:
-            n_slots = max(1, self.lookahead_depth // G)
-            while len(new) >= G and self._batches_in_flight() + G <= self.lookahead_depth:
+            while len(new) >= G:
                 grp = new[:G]
                 if len({tuple(im.shape) for im in grp}) != 1 or len({id(im) for im in grp}) != G:
                     break                                               # ragged last batch / the same tensor twice: singles below
-                busy = {e["inst"] for e in self._inflight}
-                free = [k for k in range(n_slots) if ("g%d" % k) not in busy]
-                if not free:
+                slot = self._free_slot()
+                if slot is None:
                     break
                 for im in grp:
                     L.require_gpu(im, "images")
-                self._launch(grp, "g%d" % free[0], G, n_slots)
+                self._launch(grp, slot, G)
                 new = new[G:]
                 started += G
-            if new and ims and new[0] is ims[0] and self.prefetch(new[0]):      # the next batch must not wait for a partner
-                started += 1
+            # a batch left without a partner starts alone when it is the very next one (it must not wait: one slot beyond the
+            # regular ones is its), or when the caller's list is shorter than the look-ahead window -- the end of the data: no
+            # partner will come, and started now its stack runs beside the last groups instead of alone behind them
+            tail = len(ims) < self.lookahead_depth
+            for im in new:
+                if im is ims[0]:
+                    started += 1 if self.prefetch(im, _extra=True) else 0
+                elif tail:
+                    started += 1 if self.prefetch(im) else 0
             return started
         for im in new:
             started += 1 if self.prefetch(im) else 0
@@ -288,8 +305,10 @@ class EncoderCNN(nn.Module):
         progs = []
         with torch.no_grad():
             if G > 1:
-                progs += [(self._program(images, instance="g%d" % k, groups=G), [images] * G) for k in range(max(1, self.lookahead_depth // G))]
-            progs += [(self._program(images, instance=0), images)]          # the single a left-over batch runs on
+                progs += [(self._program(images, instance="g%d" % k, groups=G), [images] * G) for k in range(self._n_slots())]
+                progs += [(self._program(images, instance=0), images)]      # the single a left-over batch runs on
+            else:
+                progs += [(self._program(images, instance=k), images) for k in range(self._n_slots())]
             for prog, arg in progs:
                 for _ in range(4):
                     prog.run(arg)

@@ -181,13 +181,13 @@ def test_collate_batch_keeps_the_reference_invariant():
         sat.DevicePrefetcher([], "cpu")
 
 
-def test_inception_mac_constant_of_the_bench_tool_matches_the_oracle():
-    """tools/bench_configs.py prices its TFLOP/s with a constant (tools may not import the oracle): keep it equal to the oracle's count"""
+def test_inception_mac_constant_of_bench_py_matches_the_oracle():
+    """bench.py --workload inception prices its roofline with a constant (the timed path may not import the oracle): keep it equal
+    to the oracle's count"""
     import re
     from oracle import inception as OI
-    for rel in (("tools", "bench_configs.py"), ("bench.py",)):            # bench.py --workload inception prices its roofline with it too
-        src = open(os.path.join(ROOT, *rel)).read()
-        assert int(re.search(r"INCEPTION_V3_CONV_MACS = (\d+)", src).group(1)) == OI.conv_macs()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert int(re.search(r"INCEPTION_V3_CONV_MACS = (\d+)", src).group(1)) == OI.conv_macs()
 
 
 def test_packinfo_prev_rows_index_the_h_prev_table():
