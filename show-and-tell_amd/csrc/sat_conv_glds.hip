@@ -85,7 +85,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 9 || N == 10 || N == 12 ||
+    static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 7 || N == 8 || N == 9 || N == 10 || N == 12 ||
                       N == 15 || N == 16 || N == 18 || N == 19 || N == 20 || N == 21 || N == 22 || N == 24,
                   "add the vmcnt literal");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -101,6 +101,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
