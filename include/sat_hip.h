@@ -236,7 +236,8 @@ int sat_lstm_fwd(const float* X /*[N,In]*/, const float* w_ih /*[4H,In]*/, const
                  const float* b_ih, const float* b_hh, const int32_t* batch_sizes /*[T] host*/, int T,
                  int In, int H, float* GA, float* CS, float* HS, float* HP, float* c_state,
                  void* workspace, int64_t ws_bytes, sat_stream_t stream);
-/* workspace of the persistent recurrence (hidden-state exchange granules + an error word).  With it (and H in
+/* workspace of the persistent recurrence (hidden-state exchange: [2 parities][groups of 8 rows][8][H] self-tagged 4-byte words --
+ * bit 30 of |h| <= 1 carries the hand-off phase -- + an error word; the call zeroes it itself).  With it (and H in
  * {32,64,96,128,256,512}, T <= 64, ceil(B/8) * H/16 <= CUs) all T steps run in ONE launch with W_hh register-resident;
  * workspace NULL / too small, or a shape outside that envelope, falls back to one launch per step (same results). */
 int64_t sat_lstm_fwd_ws_bytes(int B, int H);

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def cls(n):
-    if 'conv_glds_kernel' in n or 'conv_xp_kernel' in n or 'conv_pr_kernel' in n:
+    if 'conv_glds_kernel' in n or 'conv_xp_kernel' in n or 'conv_pr_kernel' in n or 'conv_stem_kernel' in n:
         return 'conv'
     if 'bn_act_kernel' in n or 'bn_relu' in n or 'bn_strided' in n:
         return 'bn apply'
@@ -46,7 +46,7 @@ def main():
           % (nsteps, wall, tot / nsteps, tot / nsteps / wall))
     for k in sorted(busy, key=lambda k: -busy[k]):
         print("  %-28s %5d launches/step  %7.3f ms/step of spans" % (k, cnt[k] // nsteps, busy[k] / nsteps))
-    is_conv = lambda r: any(k in r['Kernel_Name'] for k in ('conv_glds_kernel', 'conv_xp_kernel', 'conv_pr_kernel'))
+    is_conv = lambda r: any(k in r['Kernel_Name'] for k in ('conv_glds_kernel', 'conv_xp_kernel', 'conv_pr_kernel', 'conv_stem_kernel'))
     conv_win = [r for r in win if is_conv(r)]
     # bench.py's roofline leg: the conv launches after the last optimizer step run in sequence, alone
     tail = [r for r in rows if r['s'] > adam[-1]['e'] and is_conv(r)]
@@ -56,8 +56,15 @@ def main():
     if conv_win:
         print("conv launches: mean span %.1f us in the training steps of the look-ahead run (the profiler serialises the streams)"
               % (sum(r['e'] - r['s'] for r in conv_win) / len(conv_win) / 1e3))
+    # bench.py's roofline leg proper: the in-order passes of the GROUPED program (grid.y = batches per launch) behind the last step
+    grouped = [r for r in rows if r['s'] > adam[-1]['e'] and is_conv(r) and int(r.get('Grid_Size_Y', 1) or 1) > 1]
+    if grouped:
+        per_pass = 155
+        print("conv launches of the grouped program, in sequence (bench.py's `roofline`): %d launches (%d passes), mean %.2f us, %.3f ms per pass"
+              % (len(grouped), len(grouped) // per_pass, sum(r['e'] - r['s'] for r in grouped) / len(grouped) / 1e3,
+                 sum(r['e'] - r['s'] for r in grouped) / max(1, len(grouped) // per_pass) / 1e6))
     if tail:
-        print("conv launches: %d in the last in-sequence pass, mean %.1f us, sum %.3f ms (what bench.py's roofline.achieved is computed from)"
+        print("conv launches: %d in the last in-sequence pass, mean %.1f us, sum %.3f ms (bench.py's `roofline.one_batch_per_launch` pass: the ungrouped program)"
               % (len(tail), sum(r['e'] - r['s'] for r in tail) / len(tail) / 1e3, sum(r['e'] - r['s'] for r in tail) / 1e6))
 
 
