@@ -686,8 +686,12 @@ def run_decode(args, torch, dist, sat, wl, dev, rank, world, use_dist, backend):
     if use_dist and world > 1:
         if rank == 0:
             model.encoder._program(batches[0])
+            if args.lookahead:
+                model.encoder.build_lookahead(batches[0])
             torch.cuda.synchronize()
         dist.barrier()
+    if args.lookahead:
+        model.encoder.build_lookahead(batches[0])
 
     def decode(f):
         return model.decoder.sample_beam(f, beam, end_id=2) if beam > 1 else model.decoder.sample(f)
@@ -696,10 +700,8 @@ def run_decode(args, torch, dist, sat, wl, dev, rank, world, use_dist, backend):
         ids = None
         with torch.no_grad():
             for i in range(n):
-                if args.lookahead:
-                    for j in range(i + 1, i + 1 + depth):
-                        if j < n:
-                            model.prefetch(batches[j % nb])
+                if args.lookahead:             # the next batches' stacks run ahead, two batches per program run (eval mode: concatenated)
+                    model.encoder.prefetch_many([batches[j % nb] for j in range(i + 1, i + 1 + depth) if j < n])
                 ids = decode(model.encoder(batches[i % nb]))
         return ids
 
@@ -719,11 +721,11 @@ def run_decode(args, torch, dist, sat, wl, dev, rank, world, use_dist, backend):
                "config": {"workload": wl["name"], "global_batch": world * B, "parallelism": "dp%d (sharded by image, no collective in the decode)" % world,
                           "beam_size": beam, "end_id": 2 if beam > 1 else None, "steps_per_caption": 20,
                           "precision": "conv stack bf16 MFMA / f32 accumulate (eval mode: BatchNorm + add + ReLU in the conv epilogues); head, LSTM step, vocab projection, log-softmax / top-k exact f32",
-                          "schedule": ("encoder look-ahead depth %d: the conv stacks of batches i+1..i+%d run on side streams under batch i's decode loop" % (depth, depth))
+                          "schedule": ("encoder look-ahead depth %d: the conv stacks of batches i+1..i+%d run on side streams under batch i's decode loop, %d batches per program run (eval mode: the batches of a run concatenate)" % (depth, depth, model.encoder.lookahead_groups))
                                       if args.lookahead else "strictly sequential batches",
                           "backend": (backend if backend != "nccl" else "nccl (RCCL)") if use_dist else None,
                           "features_finite": finite, "ids_shape": list(ids.shape)},
-               "roofline": conv_roofline(torch, sat, model, batches[0], wl, "batch")}
+               "roofline": conv_roofline(torch, sat, model, batches[0], wl, "batch", model.encoder.lookahead_groups if args.lookahead else 1)}
         out["roofline"]["traffic_note"] = "null: the PMC traffic passes of this round were taken on the headline workload (profiles/r04_pmc_traffic.json)"
         if world == 1 and not args.no_f32_mode:
             feats = model.encoder(batches[0]).clone()

@@ -265,7 +265,7 @@ class EncoderCNN(nn.Module):
         when it is the very next one or the list is shorter than the look-ahead window (the end of the data).  Returns the
         number of batches started."""
         ims = [im for im in images_list if im is not None and im.dim() == 4]
-        G = self.lookahead_groups if (self.training and self.compute_dtype == "bf16" and not hasattr(self.resnet, "program")) else 1
+        G = self.lookahead_groups if (self.compute_dtype == "bf16" and not hasattr(self.resnet, "program")) else 1
         started = 0
         new = [im for im in ims if not self._is_in_flight(im)]
         if G > 1:
@@ -301,7 +301,7 @@ class EncoderCNN(nn.Module):
         eager then captured).  Touches no model state: look-ahead instances keep their running-statistics updates deferred, and
         nothing here applies them."""
         L.require_gpu(images, "images")
-        G = self.lookahead_groups if (self.training and self.compute_dtype == "bf16" and not hasattr(self.resnet, "program")) else 1
+        G = self.lookahead_groups if (self.compute_dtype == "bf16" and not hasattr(self.resnet, "program")) else 1
         progs = []
         with torch.no_grad():
             if G > 1:
@@ -827,6 +827,10 @@ class ShowAndTell(nn.Module):
     def prefetch(self, images):
         """Start the frozen conv stack of a LATER batch on a side stream (`EncoderCNN.prefetch`)."""
         return self.encoder.prefetch(images)
+
+    def prefetch_many(self, images_list):
+        """... of the next few batches, in order (`EncoderCNN.prefetch_many`: two batches per program run)."""
+        return self.encoder.prefetch_many(images_list)
 
     def forward(self, images, captions, lengths):
         return self.decoder(self.encoder(images), captions, lengths)

@@ -144,9 +144,15 @@ class ConvStackProgram:
 
     def __init__(self, stack, N, H, W, dtype, training, device, groups=1):
         self.N, self.H, self.W, self.dtype, self.training, self.groups = N, H, W, dtype, training, int(groups)
-        G = self.groups
-        if G > 1 and not (training and dtype == L.SAT_BF16):
-            raise ValueError("grouped programs are for the bf16 train-mode stack (eval-mode batches simply concatenate)")
+        if self.groups > 1 and dtype != L.SAT_BF16:
+            raise ValueError("grouped programs are for the bf16 stack")
+        # eval mode: BatchNorm is a fixed affine, so the batches of a group simply CONCATENATE -- one program over groups * N images
+        # (no per-group statistics, no sat_op.groups), bit-identical per image to the ungrouped program
+        Nb = N                                   # images per batch (what one image-prep op converts)
+        if self.groups > 1 and not training:
+            N, G = self.groups * N, 1
+        else:
+            G = self.groups
         self.keep = []      # tensors the op array points into
         td = _tdtype(dtype)
         ch = 8 if dtype == L.SAT_BF16 else 4
@@ -174,7 +180,7 @@ class ConvStackProgram:
         wst[:, :, :7, :3] = w1.permute(0, 2, 3, 1)
         wst = wst.reshape(width, 7 * 32).contiguous().to(td)
         self.keep.append(wst)
-        self.img_pad = alloc((G * N, Hp, Wp, 4), zero=True)
+        self.img_pad = alloc((G * N, Hp, Wp, 4), zero=True)           # (eval: N is already groups * Nb)
         self.bn_list = []
         self.stack = stack
         bns = list(stack.bns())
@@ -352,12 +358,12 @@ class ConvStackProgram:
 
         # ---- program ----
         # image prep reads the caller's tensors: one launch per group (G separate image batches), each into its slice
-        self._n_prep = G
-        for g in range(G):
+        self._n_prep = self.groups
+        for g in range(self.groups):
             o = L.SatOp()
             o.kind, o.dtype = L.OP_IMAGE_PREP, dtype
-            o.out = self.img_pad[g * N:].data_ptr()
-            o.N, o.Hin, o.Win, o.Hout, o.Wout, o.pad = N, H, W, Hp, Wp, 3
+            o.out = self.img_pad[g * Nb:].data_ptr()
+            o.N, o.Hin, o.Win, o.Hout, o.Wout, o.pad = Nb, H, W, Hp, Wp, 3
             ops.append(o)
         ops.append(conv_op(self.img_pad, wst, self.c0, N, Hp, Wp, 32, Ho, Wo, width, 7, 1, 2, 0, Hp * Wp * 4, Wp * 4, 4))
         f, s, t = fin_op(stack.bn1, width, N * Ho * Wo, lib.sat_conv_tiles_m(N * Ho * Wo))
@@ -452,7 +458,7 @@ class ConvStackProgram:
         self._use_graph = os.environ.get("SAT_GRAPH", "1") != "0" and torch.device(device).type == "cuda"
         self._runs, self._graphs = [0, 0], [None, None]
         self._running_items = None              # defer_running_stats(): number of redirected BatchNorms
-        if G > 1:
+        if self.groups > 1 and training:
             self.defer_running_stats()
         self._autotune(device, (self.c0, self.c1, self.a1, self.c2, self.a2, self.c3, self.cd, *self.ybuf), alloc)
 

@@ -133,6 +133,30 @@ def test_eval_mode_decode_with_prefetch_gives_the_same_ids():
         assert torch.equal(a, b)
 
 
+def test_eval_mode_grouped_prefetch_concatenates_batches_and_gives_the_same_ids():
+    """eval.py:93-99 with `prefetch_many`: in eval mode BatchNorm is a fixed affine, so the two batches of a program run simply
+    concatenate (one program over 2 x B images): features bitwise equal to the one-batch program's, greedy ids identical"""
+    torch.manual_seed(5)
+    model = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().eval()
+    g = torch.Generator().manual_seed(12)
+    xs = [torch.rand(4, 3, 64, 64, generator=g).cuda() for _ in range(5)]
+    with torch.no_grad():
+        want_f = [model.encoder(x).clone() for x in xs]
+        want = [model.sample(x).clone() for x in xs]
+        got, got_f, grouped = [], [], 0
+        for i, x in enumerate(xs):
+            model.prefetch_many(xs[i + 1:i + 1 + model.encoder.lookahead_depth])
+            grouped = max(grouped, max([len(e["images"]) for e in model.encoder._inflight] or [0]))
+            got_f.append(model.encoder(x).clone())
+            got.append(model.sample(x).clone())
+    torch.cuda.synchronize()
+    assert grouped == 2                                  # a two-batch run really was in flight
+    for a, b in zip(want_f, got_f):
+        assert torch.equal(a, b)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+
+
 def test_prefetched_stack_is_recomputed_after_an_in_place_weight_write():
     torch.manual_seed(9)
     enc = sat.EncoderCNN(32).cuda().eval()
