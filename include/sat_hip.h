@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 13
+#define SAT_ABI_VERSION 14
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -113,7 +113,8 @@ typedef struct sat_op {
     int64_t sN, sH, sW;       /* element strides of in0 for SAT_OP_CONV (lets the stem read a padded NHWC4 image) */
     int64_t count;            /* BN_FINALIZE: elements per channel (N*Hout*Wout) */
     float momentum, eps;
-    int32_t variant;          /* SAT_OP_CONV: 0 = built-in heuristic, >0 = kernel variant chosen by sat_conv_autotune */
+    int32_t variant;          /* SAT_OP_CONV: 0 = built-in heuristic, >0 = kernel variant chosen by sat_conv_autotune; < 0 on entry to
+                               * sat_conv_autotune: choose among the variants of statistics signature -variant only */
     int32_t flags;            /* SAT_OP_CONV, bf16, inference: scale1/shift1 [Cout] set => the epilogue writes
                                * out = acc*scale1[n] + shift1[n] (+ in1[m][n], a residual shaped like out) and, with
                                * bit 0 of flags, ReLU -- BatchNorm (eval) + add + ReLU of a bottleneck without a
@@ -130,7 +131,9 @@ typedef struct sat_op {
     const float* beta1;
     float* running_mean1;
     float* running_var1;
-    void* reserved_ptr;       /* (was out1: the dual-source conv input, removed in ABI 13 -- measured a loss) */
+    const void* w_packed;     /* SAT_OP_CONV, bf16, 3x3 / stride 1 / pad 1, Cin % 64 == 0, Cout % 128 == 0: the weights once more in MFMA
+                               * fragment order (sat_conv_pack_weights) -- lets the tuner pick conv_pw_kernel, which streams them
+                               * straight into registers; NULL = not provided */
     int32_t reserved1[2];     /* (were stat_shards / stat_shards1: sharded accumulators, removed in ABI 13 -- a measured wash) */
     /* SAT_OP_CONV extras for Inception-style stacks (BASELINE configs[3]): flags bit 1 (SAT_CONV_PADW) = the padding differs per
      * axis: `pad` is the vertical one, pad_w the horizontal one (1x7 / 7x1 / 1x3 / 3x1 kernels); ldc = row pitch of `out` in
@@ -180,11 +183,20 @@ int sat_conv_tiles_m(int64_t M);
 int sat_conv_autotune(sat_op* ops /*[host]*/, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
                       sat_stream_t stream);
 /* What fixes the BITS of the BatchNorm column sums a kernel variant (sat_op.variant, 1-based) leaves: two variants with the
- * same signature give bit-identical statistics (the conv output is bit-identical across the ring variants anyway).  The tuner
- * picks a grouped op's variant among those of its ungrouped twin's signature, so that every batch of a grouped launch gets,
- * bit for bit, what the ungrouped launch gives it; callers that load a saved tuning table can check the same.  -1: no such
+ * same signature give bit-identical statistics (the conv output is bit-identical across the ring variants anyway).  A caller
+ * that runs one model through several programs (ungrouped, grouped look-ahead copies) lets its FIRST program tune freely, reads
+ * the signatures of the variants it got, and hands them to the tuner for every other program (sat_op.variant = -signature on
+ * entry to sat_conv_autotune): every batch then gets, bit for bit, the same statistics whichever program runs it.  -1: no such
  * variant. */
 int sat_conv_variant_signature(int variant);
+/* The same for the conv OUTPUT alone (inference programs: no statistics): 100000 + the order in which the variant walks the K axis
+ * (0: tap major -- ring, expansion and stem kernels; 1: channel-block major -- the two LDS-patch 3x3 kernels).  Outputs are
+ * bit-identical within a family; accepted by sat_conv_autotune as a constraint like a statistics signature. */
+int sat_conv_variant_family(int variant);
+/* bf16 weights [Cout][taps][Cin] (the kernels' layout; Cout % 32 == 0, Cin % 64 == 0) -> `packed` (same element count) in the
+ * MFMA fragment order conv_pw_kernel streams into registers: [Cout/32][Cin/64][taps][4][64 lanes][8].  Once per weight version
+ * of a frozen stack (`self.resnet(images)`, models.py:14-15,27). */
+int sat_conv_pack_weights(const void* w, void* packed, int Cout, int Cin, int taps, sat_stream_t stream);
 /* Diagnostics, NOT the hot path (creates events, synchronises `stream`): run ops[0..n) once, in order, and return in
  * op_us[i] [host] the duration in microseconds of every bf16 SAT_OP_CONV launch taken from its own dispatch
  * timestamps (what rocprofv3 --kernel-trace reports for that launch); 0 for the other ops.  bench.py uses it for the

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -49,7 +49,7 @@ class SatOp(C.Structure):
         ("momentum", C.c_float), ("eps", C.c_float),
         ("variant", C.c_int32), ("flags", C.c_int32),
         ("stat_acc", _vp), ("stat_acc1", _vp), ("gamma1", _vp), ("beta1", _vp),
-        ("running_mean1", _vp), ("running_var1", _vp), ("reserved_ptr", _vp),
+        ("running_mean1", _vp), ("running_var1", _vp), ("w_packed", _vp),
         ("reserved1", C.c_int32 * 2),
         ("pad_w", C.c_int32), ("groups", C.c_int32), ("ldc", C.c_int64),
     ]
@@ -68,6 +68,8 @@ SIGNATURES = {
     "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
     "sat_conv_tiles_m": (_i, [_i64]),
     "sat_conv_variant_signature": (_i, [_i]),
+    "sat_conv_variant_family": (_i, [_i]),
+    "sat_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp, _i64, _vp]),
     "sat_run_ops_timed": (_i, [C.POINTER(SatOp), _i, _i, _vp, C.POINTER(C.c_float)]),
     "sat_validate_ids": (_i, [_vp, _i64, _i, _i, _i64, _i64, _vp, _vp]),

@@ -37,6 +37,7 @@ __device__ u32x4 g_zero16;   // zero-initialised device global: the source of ev
 struct ConvArgs {
     const bf16_t* A;
     const bf16_t* B;
+    const bf16_t* Bp;        // the weights once more, in MFMA fragment order (sat_conv_pack_weights; conv_pw_kernel), or NULL
     bf16_t* C;
     float* stat_partial;
     int M, N, K;
@@ -86,7 +87,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 7 || N == 8 || N == 9 || N == 10 || N == 12 ||
-                      N == 15 || N == 16 || N == 18 || N == 19 || N == 20 || N == 21 || N == 22 || N == 24,
+                      N == 15 || N == 16 || N == 17 || N == 18 || N == 19 || N == 20 || N == 21 || N == 22 || N == 24,
                   "add the vmcnt literal");
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -105,6 +106,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if constexpr (N == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
     if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
@@ -610,7 +612,7 @@ int launch_glds(ConvArgs& a, int groups, hipStream_t s) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows).
 // LDS = S * (BM/8 + BN/8) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel
+struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem, pw; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel; pw: conv_pw_kernel
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128}, {128, 3, 8, 0, 0, 128}, {128, 2, 8, 0, 0, 128}, {64, 4, 8, 0, 0, 128}, {64, 3, 8, 0, 0, 128},
     {64, 2, 8, 0, 0, 128}, {128, 4, 4, 0, 0, 128}, {128, 2, 4, 0, 0, 128}, {64, 3, 4, 0, 0, 128}, {64, 2, 4, 0, 0, 128},
@@ -622,6 +624,7 @@ constexpr Variant kVariants[] = {
     {128, 5, 4, 0, 0, 128, 1}, {128, 5, 4, 0, 0, 128, 2}, {128, 5, 4, 0, 0, 128, 4},                                     // register-resident A panel (expansion 1x1 convs, sat_conv_xp.inc)
     {128, 6, 8, 1, 0, 128, 0, 1},                                                                                        // LDS-resident input patch (3x3 / stride 1, sat_conv_pr.inc)
     {64, 1, 4, 0, 0, 128, 0, 0, 1},                                                                                      // persistent stem kernel: weights in registers, input row segments in LDS (sat_conv_stem.inc)
+    {128, 1, 4, 0, 0, 128, 0, 0, 0, 1},                                                                                  // LDS-resident input patch + weights straight into registers from the fragment-ordered copy (3x3 / stride 1, sat_conv_pw.inc)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
@@ -629,6 +632,7 @@ constexpr int kVariantPr = 29;
 #include "sat_conv_xp.inc"
 #include "sat_conv_pr.inc"
 #include "sat_conv_stem.inc"
+#include "sat_conv_pw.inc"
 
 int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
     switch (v) {
@@ -663,6 +667,7 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 28: return launch_xp(a, 4, groups, s);
         case 29: return launch_pr(a, groups, s);
         case 30: return launch_stem(a, groups, s);
+        case 31: return launch_pw(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -671,8 +676,15 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
 // conv_xp_kernel: same MFMA, same K order): the kernel family and, for the ring kernel, the tile rows and the consumer wave
 // grid (rows summed per lane, then the M-waves in order).  Two variants with the same signature leave the same statistics, so a
 // grouped launch may pick any variant of its ungrouped twin's signature and stay bit-identical to it per batch.
+// What fixes the bits of the conv OUTPUT: the order in which the K axis is walked.  0: tap major (ring kernel, conv_xp_kernel, stem
+// kernel: bit-identical outputs), 1: channel-block major (conv_pr_kernel, conv_pw_kernel: bit-identical to each other)
+int output_family(int v) { return (kVariants[v].pr || kVariants[v].pw) ? 1 : 0; }
+constexpr int kFamilySig = 100000;          // signature constraints >= this one name an output family only (inference: no statistics)
+bool signature_matches(int v, int want);
+
 int stat_signature(int v) {
     const Variant& k = kVariants[v];
+    if (k.pw) return 4000;
     if (k.stem) return 3000;
     if (k.pr) return 2000;
     if (k.xp) return 1000;
@@ -681,9 +693,14 @@ int stat_signature(int v) {
     return k.bm * 8 + wgm;
 }
 
+bool signature_matches(int v, int want) {
+    return want >= kFamilySig ? output_family(v) == want - kFamilySig : stat_signature(v) == want;
+}
+
 ConvArgs make_args(const sat_op* op) {
     ConvArgs a = {};
     a.A = (const bf16_t*)op->in0; a.B = (const bf16_t*)op->w; a.C = (bf16_t*)op->out;
+    a.Bp = (const bf16_t*)op->w_packed;
     a.stat_partial = op->stat_partial;
     a.acc = (long long*)op->stat_acc;
     a.in_affine = 0;
@@ -721,6 +738,7 @@ int op_groups(const sat_op* op) { return op->groups > 1 ? op->groups : 1; }
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
+    if (k.pw) return pw_ok(a);
     if (k.stem) return stem_ok(a);
     if (k.pr) return pr_ok(a);
     if (k.xp) return xp_ok(a, k.xp);
@@ -792,14 +810,14 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
 
 constexpr int kTuneTab = 2048;      // channels of the tuner's neutral (scale 1, shift 0) input-BatchNorm table
 
-typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int> TuneKey;
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int> TuneKey;
 static std::map<TuneKey, int> g_tune_cache;
 static std::mutex g_tune_mu;                       // the per-geometry result cache is shared by every caller thread
 
-static TuneKey tune_key(const sat_op* op, int groups) {
+static TuneKey tune_key(const sat_op* op, int groups, int want_sig) {
     return TuneKey(op->N, op->Hin, op->Win, op->Cin, op->Hout, op->Wout, op->Cout, op->KH, op->KW, op->stride,
                    ((op->stat_partial || op->stat_acc) ? 1 : 0) + ((op->scale0 || op->stat_acc1) ? 2 : 0) +
-                       (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0), groups);
+                       (op->scale1 ? 4 : 0) + (op->in1 ? 8 : 0) + (op->w_packed ? 16 : 0), groups, want_sig);
 }
 
 // time every variant the kernel can run for `op` as a launch of `groups` groups (only variants of statistics signature
@@ -819,7 +837,7 @@ static int tune_one(const sat_op* op, int groups, int want_sig, int reps, float*
     int rc = SAT_OK;
     for (int v = 0; v < kNumVariants && rc == SAT_OK; ++v) {
         if (!variant_ok(v, a)) continue;
-        if (want_sig >= 0 && stat_signature(v) != want_sig) continue;
+        if (want_sig >= 0 && !signature_matches(v, want_sig)) continue;
         float tmin = 1e30f;
         for (int round = 0; round < 4 && rc == SAT_OK; ++round) {       // round 0 = warm-up, then best of 3
             if (hipEventRecord(e0, s) != hipSuccess) { rc = SAT_ERR_UNSUPPORTED; break; }
@@ -857,36 +875,24 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
         sat_op* op = ops + i;
         if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) continue;
         const int groups = op_groups(op);
-        // the ungrouped geometry first (grouped ops: its choice fixes the statistics signature the grouped launch must keep, so
-        // that every batch of a group gets, bit for bit, what the ungrouped launch gives it)
-        int v1 = -1;
+        // variant < 0 on entry: only variants of statistics signature -variant (the caller keeps every program of one model on the
+        // signatures of its first one, so that a batch gets the same BatchNorm statistics, bit for bit, whichever program runs it)
+        const int want = op->variant < 0 ? -op->variant : -1;
+        int v = -1;
         {
             std::lock_guard<std::mutex> lk(g_tune_mu);
-            auto it = g_tune_cache.find(tune_key(op, 1));
-            if (it != g_tune_cache.end()) v1 = it->second - 1;
+            auto it = g_tune_cache.find(tune_key(op, groups, want));
+            if (it != g_tune_cache.end()) v = it->second - 1;
         }
-        if (v1 < 0) {
-            rc = tune_one(op, 1, -1, reps, scratch, e0, e1, s, verbose, &v1);
-            if (rc == SAT_ERR_UNSUPPORTED) { rc = SAT_OK; continue; }
+        if (v < 0) {
+            rc = tune_one(op, groups, want, reps, scratch, e0, e1, s, verbose, &v);
+            if (rc == SAT_ERR_UNSUPPORTED) { rc = SAT_OK; op->variant = 0; continue; }
             if (rc != SAT_OK) break;
+            if (want >= 0 && !signature_matches(v, want)) { rc = SAT_ERR_UNSUPPORTED; break; }   // no variant of that signature runs this op
             std::lock_guard<std::mutex> lk(g_tune_mu);
-            g_tune_cache[tune_key(op, 1)] = v1 + 1;
+            g_tune_cache[tune_key(op, groups, want)] = v + 1;
         }
-        if (groups == 1) { op->variant = v1 + 1; continue; }
-        int vg = -1;
-        {
-            std::lock_guard<std::mutex> lk(g_tune_mu);
-            auto it = g_tune_cache.find(tune_key(op, groups));
-            if (it != g_tune_cache.end()) vg = it->second - 1;
-        }
-        if (vg < 0) {
-            rc = tune_one(op, groups, stat_signature(v1), reps, scratch, e0, e1, s, verbose, &vg);
-            if (rc != SAT_OK) break;
-            if (stat_signature(vg) != stat_signature(v1)) vg = v1;      // (the heuristic default of tune_one when nothing qualified)
-            std::lock_guard<std::mutex> lk(g_tune_mu);
-            g_tune_cache[tune_key(op, groups)] = vg + 1;
-        }
-        op->variant = vg + 1;
+        op->variant = v + 1;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -897,4 +903,19 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
 // saved tuning table check that a grouped op's variant matches its ungrouped twin's
 extern "C" int sat_conv_variant_signature(int variant) {
     return (variant >= 1 && variant <= kNumVariants) ? stat_signature(variant - 1) : -1;
+}
+// ... and what fixes the bits of its OUTPUT alone (inference programs, where there are no statistics): 100000 + the K-order family
+extern "C" int sat_conv_variant_family(int variant) {
+    return (variant >= 1 && variant <= kNumVariants) ? kFamilySig + output_family(variant - 1) : -1;
+}
+
+// weights [Cout][KH*KW][Cin] bf16 (the kernels' layout) -> the MFMA fragment order conv_pw_kernel streams into registers; `packed`
+// holds Cout * KH*KW * Cin elements.  Frozen stacks pack once per weight version (ConvStackProgram).
+extern "C" int sat_conv_pack_weights(const void* w, void* packed, int Cout, int Cin, int taps, sat_stream_t stream) {
+    if (!w || !packed || Cout < 32 || (Cout % 32) || Cin < 64 || (Cin % 64) || taps < 1) return SAT_ERR_ARG;
+    const long n16 = (long)Cout * taps * Cin / 8;
+    const int grid = (int)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)packed, Cout, Cin, taps);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
 }

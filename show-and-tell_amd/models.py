@@ -131,6 +131,7 @@ class EncoderCNN(nn.Module):
         self.lookahead_streams = int(env_s) if env_s else None
         self._pf_seq = 0
         self._programs = {}      # insertion-ordered: least recently used first (`_program` re-inserts on a hit)
+        self._lead_sigs = {}     # (shape, mode, weights): BatchNorm statistics signatures of the first program built (`_program`)
         self._inflight = []      # look-ahead (prefetch): [dict(images, taken, inst, ev, prog, sig, vers)], one per program run in flight
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
         # `encoder.resnet.load_state_dict(torchvision_sd)` -- the natural way to load the pretrained ResNet-152 the
@@ -140,6 +141,7 @@ class EncoderCNN(nn.Module):
     def _invalidate(self):
         """cached op programs AND batches in flight belong to the old weights / device / mode"""
         self._programs.clear()
+        self._lead_sigs.clear()
         self.resnet.__dict__.pop("_sig_params", None)       # weights_signature's cached parameter list
         if self._inflight:
             self.drop_lookahead()
@@ -183,7 +185,19 @@ class EncoderCNN(nn.Module):
             if make is not None:
                 prog = make(N, H, W, dt, self.training, images.device)
             else:
-                prog = ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device, groups=groups)
+                # Every program of one (shape, mode, weights) runs its convs on kernel variants of the SAME BatchNorm statistics
+                # signature (tile shape / summation order), so a batch gets bit-identical features whichever program runs it.  The
+                # first program built tunes freely and leads; with the grouped look-ahead on that should be a grouped one (the
+                # tile shapes that win at `lookahead_groups` batches per launch are not the ones that win at one), so build it
+                # first when an ungrouped program is asked for
+                lead = key[:7]
+                grouped_la = dt == L.SAT_BF16 and self.lookahead_depth > 0 and self.lookahead_groups > 1
+                if lead not in self._lead_sigs and groups == 1 and grouped_la:
+                    self._program(images, instance="g0", groups=self.lookahead_groups)
+                prog = ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device, groups=groups,
+                                        signatures=self._lead_sigs.get(lead))
+                if lead not in self._lead_sigs:
+                    self._lead_sigs[lead] = prog.signatures()
             self._programs[key] = prog
             if instance is not None:
                 prog.defer_running_stats()

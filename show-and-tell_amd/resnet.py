@@ -142,8 +142,11 @@ class ConvStackProgram:
     program gives it.  Grouped programs always run with deferred running statistics (`defer_running_stats`), one update per
     consumed batch."""
 
-    def __init__(self, stack, N, H, W, dtype, training, device, groups=1):
+    def __init__(self, stack, N, H, W, dtype, training, device, groups=1, signatures=None):
         self.N, self.H, self.W, self.dtype, self.training, self.groups = N, H, W, dtype, training, int(groups)
+        # statistics signatures (sat_conv_variant_signature) per conv geometry that the tuner has to stay within: those of the
+        # FIRST program built for this model state (`signatures()`), so that every program gives a batch the same bits
+        self._want_sigs = dict(signatures or {})
         if self.groups > 1 and dtype != L.SAT_BF16:
             raise ValueError("grouped programs are for the bf16 stack")
         # eval mode: BatchNorm is a fixed affine, so the batches of a group simply CONCATENATE -- one program over groups * N images
@@ -340,8 +343,17 @@ class ConvStackProgram:
             wt = prep_w(conv).reshape(conv.cout, -1)
             self.keep.append(wt)
             cin = conv.cin
-            return conv_op(x, wt, out, n, hin, win, cin, hout, wout, conv.cout, conv.k, conv.k, conv.stride, conv.pad,
-                           hin * win * cin, win * cin, cin)
+            o = conv_op(x, wt, out, n, hin, win, cin, hout, wout, conv.cout, conv.k, conv.k, conv.stride, conv.pad,
+                        hin * win * cin, win * cin, cin)
+            if dtype == L.SAT_BF16 and conv.k == 3 and conv.stride == 1 and conv.pad == 1 and cin % 64 == 0 and \
+                    conv.cout % 128 == 0 and win <= 31:
+                # frozen weights: a second copy in MFMA fragment order lets the tuner pick conv_pw_kernel (weights straight into
+                # registers, two workgroups per CU)
+                wp = torch.empty_like(wt)
+                L.check(lib.sat_conv_pack_weights(wt.data_ptr(), wp.data_ptr(), conv.cout, cin, 9, L.stream()), "sat_conv_pack_weights")
+                self.keep.append(wp)
+                o.w_packed = wp.data_ptr()
+            return o
 
         def fused_input_bn(cv, s, t):
             """the conv reads the RAW output of its producer and applies that BatchNorm + ReLU to its staged operand in LDS"""
@@ -475,20 +487,27 @@ class ConvStackProgram:
                 table = json.load(f)
         missing = False
         for i in range(self.n_ops):
-            if self.ops[i].kind == L.OP_CONV:
-                v = table.get(self._tune_key(self.ops[i]))
-                if v is None:
+            o = self.ops[i]
+            if o.kind == L.OP_CONV:
+                want = self._want_sigs.get(self._layer_key(o))
+                v = table.get(self._tune_key(o, want))
+                if v is None or (want is not None and not self._matches(int(v), want)):
                     missing = True
+                    o.variant = -want if want is not None else 0      # sat_conv_autotune: stay within this statistics signature
                 else:
-                    self.ops[i].variant = int(v)
+                    o.variant = int(v)
         if not missing:
             return
+        chosen = {i: int(self.ops[i].variant) for i in range(self.n_ops) if self.ops[i].kind == L.OP_CONV}
         for t in buffers:
             t.normal_()
         scratch = alloc((4096,), torch.float32)           # the tuner's neutral BatchNorm table lives in OUR memory
         L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 5, scratch.data_ptr(), scratch.numel() * 4,
                                            L.stream()), "sat_conv_autotune")
         torch.cuda.synchronize()
+        for i, v in chosen.items():
+            if v > 0:
+                self.ops[i].variant = v                   # (entries the table already had stay as loaded)
         if tune_file:
             if os.path.exists(tune_file):                 # another instance / rank may have added entries meanwhile
                 try:
@@ -497,19 +516,51 @@ class ConvStackProgram:
                 except ValueError:
                     pass
             for i in range(self.n_ops):
-                if self.ops[i].kind == L.OP_CONV:
-                    table[self._tune_key(self.ops[i])] = int(self.ops[i].variant)
+                o = self.ops[i]
+                if o.kind == L.OP_CONV:
+                    table[self._tune_key(o, self._want_sigs.get(self._layer_key(o)))] = int(o.variant)
             tmp = "%s.%d.tmp" % (tune_file, os.getpid())          # whole-file replace: other ranks may be reading it
             with open(tmp, "w") as f:
                 json.dump(table, f, indent=0, sort_keys=True)
             os.replace(tmp, tune_file)
 
+    def signatures(self):
+        """{conv layer: signature of the variant this program runs}: the BatchNorm statistics signature (training: tile shape and
+        summation order fix the bits of the statistics) or the output family (inference: only the K order matters).  Hand it to the
+        other programs of the same model state (`signatures=`) and a batch gets bit-identical features from all of them."""
+        out = {}
+        if self.dtype != L.SAT_BF16:
+            return out
+        lib = L.load()
+        for i in range(self.n_ops):
+            o = self.ops[i]
+            if o.kind == L.OP_CONV and int(o.variant) > 0:
+                if o.stat_partial or o.stat_acc:
+                    out[self._layer_key(o)] = int(lib.sat_conv_variant_signature(int(o.variant)))
+                else:
+                    out[self._layer_key(o)] = int(lib.sat_conv_variant_family(int(o.variant)))
+        return out
+
+    def _matches(self, variant, want):
+        lib = L.load()
+        return (lib.sat_conv_variant_family(variant) if want >= 100000 else lib.sat_conv_variant_signature(variant)) == want
+
     @staticmethod
-    def _tune_key(o):
+    def _layer_key(o):
+        """a conv layer whatever the batch: eval-mode look-ahead programs run the same layers on a concatenated batch"""
         fused = (1 if (o.stat_partial or o.stat_acc) else 0) + (2 if (o.scale0 or o.stat_acc1) else 0) + \
-                (4 if o.scale1 else 0) + (8 if o.in1 else 0)
-        return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,g%d" % (o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout, o.KH, o.KW, o.stride, fused,
-                                                        max(int(o.groups), 1))
+                (4 if o.scale1 else 0) + (8 if o.in1 else 0) + (16 if o.w_packed else 0)
+        return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d" % (o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout, o.KH, o.KW, o.stride, fused)
+
+    @staticmethod
+    def _geom_key(o):
+        fused = (1 if (o.stat_partial or o.stat_acc) else 0) + (2 if (o.scale0 or o.stat_acc1) else 0) + \
+                (4 if o.scale1 else 0) + (8 if o.in1 else 0) + (16 if o.w_packed else 0)
+        return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d" % (o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout, o.KH, o.KW, o.stride, fused)
+
+    @classmethod
+    def _tune_key(cls, o, want_sig=None):
+        return "%s,g%d%s" % (cls._geom_key(o), max(int(o.groups), 1), "" if want_sig is None else ",s%d" % want_sig)
 
     def __del__(self):
         for g in getattr(self, "_graphs", ()):

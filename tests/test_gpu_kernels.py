@@ -107,7 +107,7 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 31
+NUM_CONV_VARIANTS = 32
 PLAIN_CONV_VARIANTS = list(range(1, 27))      # ring kernel variants (27..29: conv_xp_kernel, 30: conv_pr_kernel -- their own tests)
 
 
@@ -290,6 +290,125 @@ def test_conv3x3_lds_resident_patch_with_fused_input_bn_relu(lib, N, H, W, Cin, 
         np.testing.assert_allclose(gx["rv"].cpu().numpy(), (0.9 + 0.1 * var * M / (M - 1)).numpy(), rtol=1e-4)
 
 
+
+def _pack_weights(lib, wd, Cout, Cin, taps):
+    """the fragment-ordered copy of bf16 weights [Cout][taps*Cin] that conv_pw_kernel streams into registers"""
+    packed = torch.empty_like(wd)
+    L.check(lib.sat_conv_pack_weights(wd.data_ptr(), packed.data_ptr(), Cout, Cin, taps, st()))
+    return packed
+
+
+def test_pack_weights_is_the_mfma_fragment_order(lib):
+    """sat_conv_pack_weights: packed[nb][cb][tap][ks][lane = h*32 + r][e] = w[32 nb + r][tap][64 cb + 16 ks + 8 h + e]"""
+    Cout, Cin, taps = 64, 128, 9
+    w = torch.arange(Cout * taps * Cin, dtype=torch.float32).reshape(Cout, taps, Cin) % 251
+    wd = cu(w.bfloat16().reshape(Cout, -1).contiguous())
+    got = _pack_weights(lib, wd, Cout, Cin, taps).float().cpu().reshape(Cout // 32, Cin // 64, taps, 4, 2, 32, 8)
+    sync()
+    src = w.bfloat16().float().reshape(Cout // 32, 32, taps, Cin // 64, 4, 2, 8)          # nb r tap cb ks h e
+    assert torch.equal(got, src.permute(0, 3, 2, 4, 5, 1, 6).contiguous())
+    assert lib.sat_conv_pack_weights(wd.data_ptr(), wd.data_ptr(), 48, Cin, taps, st()) != 0      # Cout % 32
+    assert lib.sat_conv_pack_weights(wd.data_ptr(), wd.data_ptr(), Cout, 96, taps, st()) != 0      # Cin % 64
+
+
+@pytest.mark.parametrize("stat_mode", ["slab", "atomic", "eval"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(64, 14, 14, 256, 256), (5, 28, 28, 128, 128), (7, 7, 7, 512, 128), (2, 5, 31, 64, 128),
+                                            (1, 3, 3, 128, 256), (3, 15, 13, 64, 384)])
+def test_conv3x3_weights_in_registers_is_bit_identical_to_the_lds_patch_kernel(lib, N, H, W, Cin, Cout, stat_mode):
+    """conv_pw_kernel (variant 32: the input patch in LDS, the weights streamed straight into registers from the fragment-ordered
+    copy, two workgroups per CU) against conv_pr_kernel (variant 30: same K order, so the output is BITWISE equal; the column sums
+    agree to rounding) and the f64 definition; `eval`: the fixed BatchNorm affine + ReLU in the epilogue (against the ring kernel's);
+    image borders, rows of several images in one tile, a ragged last tile, one to eight channel blocks; models.py:27."""
+    g = torch.Generator().manual_seed(N * 19 + W + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    osc, osh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+
+    def run(v):
+        o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1, stats=(stat_mode == "slab"))
+        o.variant = v
+        extra = [_pack_weights(lib, keep[1], Cout, Cin, 9)]
+        o.w_packed = extra[0].data_ptr()
+        acc = None
+        if stat_mode == "atomic":
+            acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc = acc.data_ptr()
+        if stat_mode == "eval":
+            extra += [cu(osc), cu(osh)]
+            o.scale1, o.shift1, o.flags = extra[1].data_ptr(), extra[2].data_ptr(), 1
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+        sync()
+        return keep, acc
+
+    want, wacc = run(1 if stat_mode == "eval" else 30)
+    got, gacc = run(32)
+    out = got[2].float().cpu().double()
+    assert torch.isfinite(out).all()
+    if stat_mode == "eval":
+        ref = torch.clamp(ref * osc.double() + osh.double(), min=0)
+        d = (got[2].float() - want[2].float()).abs()            # the ring kernel walks K tap major: equal to f32 summation order
+        assert d.max().item() <= 2.0 ** -6 * max(1.0, want[2].float().abs().max().item())
+        assert (d > 0).float().mean().item() < 0.05
+    else:
+        assert torch.equal(got[2], want[2])
+    assert (out - ref).abs().max().item() < 3e-2
+    if stat_mode == "slab":
+        torch.testing.assert_close(got[3], want[3], rtol=1e-4, atol=2e-3)
+    elif stat_mode == "atomic":
+        torch.testing.assert_close(gacc.double() / 2 ** 22, wacc.double() / 2 ** 22, rtol=1e-4, atol=5e-3)
+        assert int(gacc[1].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("derive", [False, True])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(64, 14, 14, 256, 256), (5, 28, 28, 128, 128), (3, 9, 13, 64, 256), (2, 7, 7, 512, 128)])
+def test_conv3x3_weights_in_registers_with_fused_input_bn_relu(lib, N, H, W, Cin, Cout, derive):
+    """conv_pw_kernel with the operand's BatchNorm + ReLU (bn1 of a bottleneck) applied to each 64-channel slice of the patch in LDS:
+    output and statistics slabs BITWISE / to rounding those of conv_pr_kernel (same transform, same K order), running statistics
+    updated once and the other parity cleared when the table is derived from the producer's integer sums; models.py:27."""
+    g = torch.Generator().manual_seed(N * 13 + W + Cin)
+    x = (torch.randn(N, Cin, H, W, generator=g) * 1.5 + 0.2).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).bfloat16().float()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2 + 0.3
+    xf = x.float().permute(0, 2, 3, 1).reshape(-1, Cin).double()
+    M = xf.shape[0]
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
+    shift = (beta.double() - mean * scale.double()).float()
+
+    def run(v):
+        o, keep, _ = _conv_op(L.SAT_BF16, x.float().permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1)
+        o.variant = v
+        extra = {"wp": _pack_weights(lib, keep[1], Cout, Cin, 9)}
+        o.w_packed = extra["wp"].data_ptr()
+        if derive:
+            iacc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
+            iacc[0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
+            iacc[0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
+            iacc[1] = 777
+            gd, bd, rm, rv = cu(gamma), cu(beta), cu(torch.zeros(Cin)), cu(torch.ones(Cin))
+            o.stat_acc1, o.gamma1, o.beta1 = iacc.data_ptr(), gd.data_ptr(), bd.data_ptr()
+            o.running_mean1, o.running_var1 = rm.data_ptr(), rv.data_ptr()
+            o.count, o.momentum, o.eps = M, 0.1, 1e-5
+            extra.update(iacc=iacc, gd=gd, bd=bd, rm=rm, rv=rv)
+        else:
+            sd, td = cu(scale), cu(shift)
+            o.scale0, o.shift0 = sd.data_ptr(), td.data_ptr()
+            extra.update(sd=sd, td=td)
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+        sync()
+        return keep, extra
+
+    want, wx = run(30)
+    got, gx = run(32)
+    assert torch.isfinite(got[2].float()).all()
+    assert torch.equal(got[2], want[2])
+    torch.testing.assert_close(got[3], want[3], rtol=1e-4, atol=2e-3)
+    if derive:
+        assert int(gx["iacc"][1].abs().sum()) == 0
+        assert torch.equal(gx["rm"], wx["rm"]) and torch.equal(gx["rv"], wx["rv"])
+
+
 def _stem_op(x_pad, w, Ho, Wo, groups=1):
     """the op program's stem conv (resnet.ConvStackProgram): a 7 x 1 kernel over rows of 8 pixels x 4 channels of a zero-bordered
     NHWC4 image, stride 2; x_pad bf16 [G*N][Hp][Wp][4] on the device, w bf16 [64][224]"""
@@ -341,7 +460,7 @@ def test_conv_stem_kernel_is_bit_identical_to_the_ring_kernel(lib, N, H, W):
     np.testing.assert_allclose(res[31][1][0, :, 0].cpu().double().sum(0).numpy(), ref.sum(0).numpy(), rtol=0, atol=2e-3 * ref.shape[0] ** 0.5 + 1e-3)
 
 
-@pytest.mark.parametrize("kind", ["ring", "ring_wide", "xp", "pr", "stem"])
+@pytest.mark.parametrize("kind", ["ring", "ring_wide", "xp", "pr", "pw", "stem"])
 def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
     """sat_op.groups = 3: three batches in ONE launch (grid.y = group; activations, statistics slabs / integer accumulators and the
     operand-BatchNorm accumulators + running-statistics log moved by their group strides, weights shared) against three launches,
@@ -370,14 +489,14 @@ def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
             assert torch.equal(outg[k * M:(k + 1) * M], out1) and torch.equal(partg[k], part1[0])
         return
     geo = {"ring": (4, 13, 11, 128, 192, 1, 2), "ring_wide": (4, 14, 14, 256, 512, 1, 22), "xp": (5, 12, 12, 256, 1024, 1, 28),
-           "pr": (5, 14, 14, 128, 256, 3, 30)}[kind]
+           "pr": (5, 14, 14, 128, 256, 3, 30), "pw": (5, 14, 14, 128, 256, 3, 32)}[kind]
     N, H, W, Cin, Cout, k, variant = geo
     pad = 1 if k == 3 else 0
     x = (torch.randn(G * N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
     w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
     gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
     M = N * H * W
-    with_in_bn = kind in ("xp", "pr")
+    with_in_bn = kind in ("xp", "pr", "pw")
 
     def run(xs, groups):
         o, keep, _ = _conv_op(L.SAT_BF16, xs.float(), w.float(), 1, pad, stats=False)
@@ -385,6 +504,9 @@ def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
         acc = torch.zeros(groups, 2, 2, Cout, dtype=torch.int64, device="cuda")
         o.stat_acc = acc.data_ptr()
         extra = {"acc": acc}
+        if kind == "pw":
+            extra["wp"] = _pack_weights(lib, keep[1], Cout, Cin, 9)
+            o.w_packed = extra["wp"].data_ptr()
         if with_in_bn:
             iacc = torch.zeros(groups, 2, 2, Cin, dtype=torch.int64, device="cuda")
             for q in range(groups):

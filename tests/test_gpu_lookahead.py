@@ -41,9 +41,10 @@ def _run(lookahead, groups=1, steps=9, B=8, img=64):
 def test_lookahead_is_bitwise_identical_to_sequential(groups, depth):
     """losses, parameters, the head's and EVERY conv-stack BatchNorm's running statistics and num_batches_tracked -- with one
     program per batch in flight (groups 1) and with GROUPED programs (`ConvStackProgram(groups=G)`: every launch of the frozen
-    stack covers G look-ahead batches, per-batch statistics; the tuner keeps a grouped conv within its ungrouped twin's
-    statistics signature): each batch gets, bit for bit, what its own sequential run gives it"""
-    a, _ = _run(0)
+    stack covers G look-ahead batches, per-batch statistics; every program of a model runs kernel variants of the statistics
+    signatures its first -- grouped -- program chose): each batch gets, bit for bit, what the same model gives it when nothing
+    runs ahead"""
+    a, _ = _run(0, groups)
     b, grouped_runs = _run(depth, groups)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
@@ -231,7 +232,8 @@ def test_train_eval_alternation_keeps_every_program():
     enc.eval()
     sweep()
     ids = {k: id(v) for k, v in enc._programs.items()}
-    assert len(ids) == 2 * (enc._n_slots() + 1)            # per mode: the forward's own program + one instance per run slot
+    # per mode: the forward's own program + one instance per run slot + the grouped program that leads the kernel choice
+    assert len(ids) == 2 * (enc._n_slots() + 2)
     for _ in range(2):
         enc.train()
         sweep()

@@ -332,7 +332,7 @@ def test_default_program_fuses_bn1_where_the_patch_kernel_runs():
     enc = sat.EncoderCNN(64, compute_dtype="bf16").cuda().train()
     with torch.no_grad():
         enc.pooled_features(torch.randn(4, 3, 224, 224, device="cuda"))
-    prog = next(iter(enc._programs.values()))
+    prog = next(v for k, v in enc._programs.items() if k[7] is None)
     ops = [prog.ops[i] for i in range(prog.n_ops)]
     fused3x3 = [o for o in ops if o.kind == L.OP_CONV and o.KH == 3 and o.stat_acc1]
     assert len(fused3x3) == 44

@@ -191,3 +191,48 @@ def bench_gemm_bf16(reps=30):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gemm16":
     bench_gemm_bf16()
+
+
+def bench_quant(reps=20):
+    """Workgroup-count quantisation of the layer-3 convs: the launch time as a function of the batch (rows = batch x 196), with the
+    variants the grouped program runs (ring 128x128 two per CU, conv_pr_kernel, conv_xp_kernel 4 column tiles).  If the time is a
+    step function of workgroups / CUs, a 128-row tile wastes 23 % of the chip at M = 12544 x G (196 G workgroups per 256 CUs)."""
+    lib = L.load()
+    geoms = [(14, 14, 1024, 256, 1, 0, 3, 0), (14, 14, 256, 256, 3, 1, 30, 1), (14, 14, 256, 256, 3, 1, 32, 1), (28, 28, 128, 128, 3, 1, 30, 1),
+             (28, 28, 128, 128, 3, 1, 32, 1), (14, 14, 256, 1024, 1, 0, 29, 1)]
+    if len(sys.argv) > 2:
+        geoms = [g for g in geoms if str(g[6]) in sys.argv[2].split(",")]
+    for (H, W, Cin, Cout, k, pad, variant, fused) in geoms:
+        for N in (32, 42, 43, 64, 83, 84, 96, 128, 166, 168, 192, 250, 256):
+            if H == 28:
+                N = max(N // 4, 1)
+            x = torch.randn(N, H, W, Cin, device="cuda").bfloat16()
+            w = (torch.randn(Cout, k * k * Cin, device="cuda") / (Cin * k * k) ** 0.5).bfloat16()
+            out = torch.empty(N * H * W, Cout, device="cuda", dtype=torch.bfloat16)
+            acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+            sc, sh = torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1
+            o = L.SatOp()
+            o.kind, o.dtype = L.OP_CONV, L.SAT_BF16
+            o.in0, o.w, o.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+            o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, H, W, Cin, H, W, Cout
+            o.KH, o.KW, o.stride, o.pad = k, k, 1, pad
+            o.sN, o.sH, o.sW = H * W * Cin, W * Cin, Cin
+            o.stat_acc, o.variant = acc.data_ptr(), variant
+            if k == 3:
+                wp = torch.empty_like(w)
+                L.check(lib.sat_conv_pack_weights(w.data_ptr(), wp.data_ptr(), Cout, Cin, 9, L.stream()))
+                o.w_packed = wp.data_ptr()
+            if fused:
+                o.scale0, o.shift0 = sc.data_ptr(), sh.data_ptr()
+            ops = (L.SatOp * 1)(o)
+            us = time_ops(ops, 1, reps)
+            M = N * H * W
+            tiles = -(-M // 128)
+            fl = 2.0 * M * Cout * k * k * Cin
+            print("K=%4d N=%4d variant %2d batch %3d: M=%6d = %5.1f row tiles of 128 (%.2f x 256)  %6.1f us  %4.0f TFLOP/s  %.3f us per row tile" %
+                  (k * k * Cin, Cout, variant, N, M, M / 128, tiles / 256, us, fl / us / 1e6, us / tiles))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "quant":
+    bench_quant()
+
