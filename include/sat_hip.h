@@ -182,6 +182,12 @@ int sat_conv_tiles_m(int64_t M);
  * the tuner runs): like every other entry point, this one allocates no device memory. */
 int sat_conv_autotune(sat_op* ops /*[host]*/, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
                       sat_stream_t stream);
+/* The same, and in cand[n_ops][topk] [host] the `topk` fastest variants of every op (1-based, fastest first, 0 = no more; all 0
+ * for ops the tuner does not handle).  A replayed launch finds its operand warm, a launch inside the program does not, and the two
+ * rankings differ by a few microseconds either way: a caller that can time its whole program (sat_run_ops_timed) makes the final
+ * choice among the candidates IN the program (resnet.ConvStackProgram._autotune). */
+int sat_conv_autotune_topk(sat_op* ops /*[host]*/, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
+                           sat_stream_t stream, int topk, int32_t* cand /*[host]*/);
 /* What fixes the BITS of the BatchNorm column sums a kernel variant (sat_op.variant, 1-based) leaves: two variants with the
  * same signature give bit-identical statistics (the conv output is bit-identical across the ring variants anyway).  A caller
  * that runs one model through several programs (ungrouped, grouped look-ahead copies) lets its FIRST program tune freely, reads

@@ -71,6 +71,7 @@ SIGNATURES = {
     "sat_conv_variant_family": (_i, [_i]),
     "sat_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp, _i64, _vp]),
+    "sat_conv_autotune_topk": (_i, [C.POINTER(SatOp), _i, _i, _vp, _i64, _vp, _i, C.POINTER(C.c_int32)]),
     "sat_run_ops_timed": (_i, [C.POINTER(SatOp), _i, _i, _vp, C.POINTER(C.c_float)]),
     "sat_validate_ids": (_i, [_vp, _i64, _i, _i, _i64, _i64, _vp, _vp]),
     "sat_fc_bn1d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),

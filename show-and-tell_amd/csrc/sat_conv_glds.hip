@@ -803,15 +803,17 @@ int sat_conv_glds_launch(const sat_op* op, int parity, hipStream_t s) {
     return launch_variant(v, a, op_groups(op), s);
 }
 
+#include <algorithm>
 #include <map>
 #include <mutex>
+#include <vector>
 #include <tuple>
 #include <stdio.h>
 
 constexpr int kTuneTab = 2048;      // channels of the tuner's neutral (scale 1, shift 0) input-BatchNorm table
 
 typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int> TuneKey;
-static std::map<TuneKey, int> g_tune_cache;
+static std::map<TuneKey, std::vector<int>> g_tune_cache;      // variants (0-based) by ascending replay time
 static std::mutex g_tune_mu;                       // the per-geometry result cache is shared by every caller thread
 
 static TuneKey tune_key(const sat_op* op, int groups, int want_sig) {
@@ -824,7 +826,7 @@ static TuneKey tune_key(const sat_op* op, int groups, int want_sig) {
 // `want_sig` when >= 0); returns the fastest in *best_v.  Tuning launches write the op's own output buffer and touch no
 // statistics / running buffers.
 static int tune_one(const sat_op* op, int groups, int want_sig, int reps, float* scratch, hipEvent_t e0, hipEvent_t e1, hipStream_t s,
-                    bool verbose, int* best_v) {
+                    bool verbose, std::vector<int>* ranked) {
     ConvArgs a = make_args(op);
     a.acc = nullptr;
     if (a.in_affine) {           // ... nor derive from / clear the live accumulators: the neutral table stands in
@@ -832,8 +834,7 @@ static int tune_one(const sat_op* op, int groups, int want_sig, int reps, float*
         a.in_scale = scratch; a.in_shift = scratch + kTuneTab;
         if (a.Cin > 512 || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;
     }
-    float best = 1e30f;
-    *best_v = heuristic_variant(a);
+    std::vector<std::pair<float, int>> timed;
     int rc = SAT_OK;
     for (int v = 0; v < kNumVariants && rc == SAT_OK; ++v) {
         if (!variant_ok(v, a)) continue;
@@ -850,17 +851,45 @@ static int tune_one(const sat_op* op, int groups, int want_sig, int reps, float*
         }
         if (verbose) fprintf(stderr, "  tune M=%d N=%d K=%d G=%d v%d(%d,%d,%d,%s) %.2f us\n", a.M, a.N, a.K, groups, v, kVariants[v].bn,
                              kVariants[v].s, kVariants[v].nw, kVariants[v].spec ? (kVariants[v].pf ? "spec+pf" : "spec") : (kVariants[v].pf ? "pf" : "-"), tmin * 1e3f);
-        if (tmin < best) { best = tmin; *best_v = v; }
+        timed.emplace_back(tmin, v);
     }
-    if (verbose && rc == SAT_OK)
-        fprintf(stderr, "tune M=%d N=%d K=%d G=%d -> v%d %.2f us (%.0f TFLOP/s)\n", a.M, a.N, a.K, groups, *best_v, best * 1e3f,
-                2.0 * groups * a.M * a.N * a.K / (best * 1e-3) / 1e12);
+    if (rc != SAT_OK) return rc;
+    std::sort(timed.begin(), timed.end());
+    ranked->clear();
+    for (auto& tv : timed) ranked->push_back(tv.second);
+    if (verbose && !timed.empty())
+        fprintf(stderr, "tune M=%d N=%d K=%d G=%d -> v%d %.2f us (%.0f TFLOP/s)\n", a.M, a.N, a.K, groups, timed[0].second, timed[0].first * 1e3f,
+                2.0 * groups * a.M * a.N * a.K / (timed[0].first * 1e-3) / 1e12);
     return rc;
 }
 
-extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
-                                 sat_stream_t stream) {
-    if (!ops || n_ops < 0 || reps < 1) return SAT_ERR_ARG;
+// the candidates of one op by ascending replay time (cached per geometry, group count and signature constraint); empty: the op
+// is not a bf16 conv / has nothing to choose from (the launch falls back on the heuristic)
+static int ranked_variants(sat_op* op, int reps, float* scratch, hipEvent_t e0, hipEvent_t e1, hipStream_t s, bool verbose,
+                           std::vector<int>* ranked) {
+    ranked->clear();
+    if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) return SAT_OK;
+    const int groups = op_groups(op);
+    // variant < 0 on entry: only variants of signature -variant (the caller keeps every program of one model on the signatures of
+    // its first one, so that a batch gets the same bits whichever program runs it)
+    const int want = op->variant < 0 ? -op->variant : -1;
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune_cache.find(tune_key(op, groups, want));
+        if (it != g_tune_cache.end()) { *ranked = it->second; return SAT_OK; }
+    }
+    int rc = tune_one(op, groups, want, reps, scratch, e0, e1, s, verbose, ranked);
+    if (rc == SAT_ERR_UNSUPPORTED) { ranked->clear(); return want >= 0 ? rc : SAT_OK; }
+    if (rc != SAT_OK) return rc;
+    if (want >= 0 && ranked->empty()) return SAT_ERR_UNSUPPORTED;       // no variant of that signature runs this op
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tune_cache[tune_key(op, groups, want)] = *ranked;
+    return SAT_OK;
+}
+
+static int autotune_impl(sat_op* ops, int n_ops, int reps, float* scratch, int64_t scratch_bytes, sat_stream_t stream, int topk,
+                         int32_t* cand) {
+    if (!ops || n_ops < 0 || reps < 1 || topk < 1) return SAT_ERR_ARG;
     if (!scratch || scratch_bytes < (int64_t)(2 * kTuneTab * sizeof(float))) return SAT_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const bool verbose = getenv("SAT_TUNE_VERBOSE") != nullptr;
@@ -871,32 +900,31 @@ extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratc
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SAT_ERR_UNSUPPORTED;
     int rc = SAT_OK;
+    std::vector<int> ranked;
     for (int i = 0; i < n_ops && rc == SAT_OK; ++i) {
-        sat_op* op = ops + i;
-        if (op->kind != SAT_OP_CONV || op->dtype != SAT_BF16 || (op->Cout % 8)) continue;
-        const int groups = op_groups(op);
-        // variant < 0 on entry: only variants of statistics signature -variant (the caller keeps every program of one model on the
-        // signatures of its first one, so that a batch gets the same BatchNorm statistics, bit for bit, whichever program runs it)
-        const int want = op->variant < 0 ? -op->variant : -1;
-        int v = -1;
-        {
-            std::lock_guard<std::mutex> lk(g_tune_mu);
-            auto it = g_tune_cache.find(tune_key(op, groups, want));
-            if (it != g_tune_cache.end()) v = it->second - 1;
-        }
-        if (v < 0) {
-            rc = tune_one(op, groups, want, reps, scratch, e0, e1, s, verbose, &v);
-            if (rc == SAT_ERR_UNSUPPORTED) { rc = SAT_OK; op->variant = 0; continue; }
-            if (rc != SAT_OK) break;
-            if (want >= 0 && !signature_matches(v, want)) { rc = SAT_ERR_UNSUPPORTED; break; }   // no variant of that signature runs this op
-            std::lock_guard<std::mutex> lk(g_tune_mu);
-            g_tune_cache[tune_key(op, groups, want)] = v + 1;
-        }
-        op->variant = v + 1;
+        rc = ranked_variants(ops + i, reps, scratch, e0, e1, s, verbose, &ranked);
+        if (rc != SAT_OK) break;
+        if (cand)
+            for (int k = 0; k < topk; ++k) cand[(long)i * topk + k] = k < (int)ranked.size() ? ranked[k] + 1 : 0;
+        if (ops[i].kind == SAT_OP_CONV && ops[i].dtype == SAT_BF16) ops[i].variant = ranked.empty() ? 0 : ranked[0] + 1;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
+}
+
+extern "C" int sat_conv_autotune(sat_op* ops, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
+                                 sat_stream_t stream) {
+    return autotune_impl(ops, n_ops, reps, scratch, scratch_bytes, stream, 1, nullptr);
+}
+
+// the same, and the `topk` fastest variants of every op (1-based, fastest first, 0 = no more) in cand[n_ops][topk] [host]: a
+// caller that can time its whole program (sat_run_ops_timed) picks among them IN the program -- a replayed launch finds its
+// operand warm, a launch in the program does not, and the two rankings differ by a few microseconds either way
+extern "C" int sat_conv_autotune_topk(sat_op* ops, int n_ops, int reps, float* scratch, int64_t scratch_bytes,
+                                      sat_stream_t stream, int topk, int32_t* cand) {
+    if (!cand) return SAT_ERR_ARG;
+    return autotune_impl(ops, n_ops, reps, scratch, scratch_bytes, stream, topk, cand);
 }
 
 // the statistics signature of a variant number as stored in sat_op.variant (1-based; 0 / out of range: -1): callers that load a
