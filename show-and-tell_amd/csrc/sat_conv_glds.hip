@@ -37,7 +37,8 @@ __device__ u32x4 g_zero16;   // zero-initialised device global: the source of ev
 struct ConvArgs {
     const bf16_t* A;
     const bf16_t* B;
-    const bf16_t* Bp;        // the weights once more, in MFMA fragment order (sat_conv_pack_weights; conv_pw_kernel), or NULL
+    const bf16_t* Bp;        // the weights once more, in MFMA fragment order (sat_conv_pack_weights; conv_pw_kernel / conv_aw_kernel), or NULL
+    long in_bytes;           // bytes of one group's input tensor (conv_aw_kernel reads it through a bounds-checked buffer)
     bf16_t* C;
     float* stat_partial;
     int M, N, K;
@@ -612,7 +613,7 @@ int launch_glds(ConvArgs& a, int groups, hipStream_t s) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows).
 // LDS = S * (BM/8 + BN/8) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem, pw; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel; pw: conv_pw_kernel
+struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem, pw, aw; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel; pw: conv_pw_kernel; aw: conv_aw_kernel
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128}, {128, 3, 8, 0, 0, 128}, {128, 2, 8, 0, 0, 128}, {64, 4, 8, 0, 0, 128}, {64, 3, 8, 0, 0, 128},
     {64, 2, 8, 0, 0, 128}, {128, 4, 4, 0, 0, 128}, {128, 2, 4, 0, 0, 128}, {64, 3, 4, 0, 0, 128}, {64, 2, 4, 0, 0, 128},
@@ -625,6 +626,7 @@ constexpr Variant kVariants[] = {
     {128, 6, 8, 1, 0, 128, 0, 1},                                                                                        // LDS-resident input patch (3x3 / stride 1, sat_conv_pr.inc)
     {64, 1, 4, 0, 0, 128, 0, 0, 1},                                                                                      // persistent stem kernel: weights in registers, input row segments in LDS (sat_conv_stem.inc)
     {128, 1, 4, 0, 0, 128, 0, 0, 0, 1},                                                                                  // LDS-resident input patch + weights straight into registers from the fragment-ordered copy (3x3 / stride 1, sat_conv_pw.inc)
+    {128, 3, 4, 0, 0, 128, 0, 0, 0, 0, 1},                                                                               // 1x1: activations through registers into LDS, weights straight into registers (sat_conv_aw.inc)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
@@ -633,6 +635,7 @@ constexpr int kVariantPr = 29;
 #include "sat_conv_pr.inc"
 #include "sat_conv_stem.inc"
 #include "sat_conv_pw.inc"
+#include "sat_conv_aw.inc"
 
 int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
     switch (v) {
@@ -668,6 +671,7 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 29: return launch_pr(a, groups, s);
         case 30: return launch_stem(a, groups, s);
         case 31: return launch_pw(a, groups, s);
+        case 32: return launch_aw(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -684,6 +688,7 @@ bool signature_matches(int v, int want);
 
 int stat_signature(int v) {
     const Variant& k = kVariants[v];
+    if (k.aw) return 5000;
     if (k.pw) return 4000;
     if (k.stem) return 3000;
     if (k.pr) return 2000;
@@ -701,6 +706,7 @@ ConvArgs make_args(const sat_op* op) {
     ConvArgs a = {};
     a.A = (const bf16_t*)op->in0; a.B = (const bf16_t*)op->w; a.C = (bf16_t*)op->out;
     a.Bp = (const bf16_t*)op->w_packed;
+    a.in_bytes = (long)op->N * op->sN * 2;
     a.stat_partial = op->stat_partial;
     a.acc = (long long*)op->stat_acc;
     a.in_affine = 0;
@@ -738,6 +744,7 @@ int op_groups(const sat_op* op) { return op->groups > 1 ? op->groups : 1; }
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
+    if (k.aw) return aw_ok(a);
     if (k.pw) return pw_ok(a);
     if (k.stem) return stem_ok(a);
     if (k.pr) return pr_ok(a);

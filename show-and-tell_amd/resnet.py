@@ -348,12 +348,14 @@ class ConvStackProgram:
             cin = conv.cin
             o = conv_op(x, wt, out, n, hin, win, cin, hout, wout, conv.cout, conv.k, conv.k, conv.stride, conv.pad,
                         hin * win * cin, win * cin, cin)
-            if dtype == L.SAT_BF16 and conv.k == 3 and conv.stride == 1 and conv.pad == 1 and cin % 64 == 0 and \
-                    conv.cout % 128 == 0 and win <= 31:
-                # frozen weights: a second copy in MFMA fragment order lets the tuner pick conv_pw_kernel (weights straight into
-                # registers, two workgroups per CU)
+            pw_geom = conv.k == 3 and conv.stride == 1 and conv.pad == 1 and win <= 31
+            aw_geom = conv.k == 1 and conv.pad == 0
+            if dtype == L.SAT_BF16 and cin % 64 == 0 and conv.cout % 128 == 0 and (pw_geom or aw_geom):
+                # frozen weights: a second copy in MFMA fragment order lets the tuner pick conv_pw_kernel (3x3) / conv_aw_kernel (1x1):
+                # weights straight into registers, two workgroups per CU
                 wp = torch.empty_like(wt)
-                L.check(lib.sat_conv_pack_weights(wt.data_ptr(), wp.data_ptr(), conv.cout, cin, 9, L.stream()), "sat_conv_pack_weights")
+                L.check(lib.sat_conv_pack_weights(wt.data_ptr(), wp.data_ptr(), conv.cout, cin, conv.k * conv.k, L.stream()),
+                        "sat_conv_pack_weights")
                 self.keep.append(wp)
                 o.w_packed = wp.data_ptr()
             return o

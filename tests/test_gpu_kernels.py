@@ -107,7 +107,7 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 32
+NUM_CONV_VARIANTS = 33
 PLAIN_CONV_VARIANTS = list(range(1, 27))      # ring kernel variants (27..29: conv_xp_kernel, 30: conv_pr_kernel -- their own tests)
 
 
@@ -409,6 +409,112 @@ def test_conv3x3_weights_in_registers_with_fused_input_bn_relu(lib, N, H, W, Cin
         assert torch.equal(gx["rm"], wx["rm"]) and torch.equal(gx["rv"], wx["rv"])
 
 
+
+@pytest.mark.parametrize("mode", ["slab", "atomic", "eval", "eval_residual"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride", [(64, 14, 14, 1024, 256, 1), (5, 28, 28, 128, 512, 1), (7, 7, 7, 512, 2048, 1), (3, 9, 13, 64, 128, 1),
+                                                   (4, 14, 14, 256, 512, 2), (2, 15, 13, 128, 128, 2), (1, 3, 3, 320, 256, 1)])
+def test_conv1x1_weights_in_registers_is_bit_identical_to_the_ring_kernel(lib, N, H, W, Cin, Cout, stride, mode):
+    """conv_aw_kernel (variant 33: 1x1 convs with the activations staged global -> registers -> LDS and the weights streamed straight
+    into registers from the fragment-ordered copy, two workgroups per CU) against the ring kernel (variant 1: same K order, so the
+    output is BITWISE equal; column sums to rounding) and the f64 definition; stride 2 (the projection shortcuts), ragged last tiles,
+    1 to 16 K-steps (the tail of the three-step pipeline), the inference epilogue with and without the residual; models.py:27."""
+    g = torch.Generator().manual_seed(N * 23 + W + Cin + stride)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, stride, 0).permute(0, 2, 3, 1).reshape(-1, Cout)
+    osc, osh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    res = torch.randn(ref.shape[0], Cout, generator=g).bfloat16()
+
+    def run(v):
+        o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), stride, 0, stats=(mode == "slab"))
+        o.variant = v
+        extra = [_pack_weights(lib, keep[1], Cout, Cin, 1)]
+        o.w_packed = extra[0].data_ptr()
+        acc = None
+        if mode == "atomic":
+            acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc = acc.data_ptr()
+        if mode.startswith("eval"):
+            extra += [cu(osc), cu(osh)]
+            o.scale1, o.shift1, o.flags = extra[1].data_ptr(), extra[2].data_ptr(), 1
+            if mode == "eval_residual":
+                extra.append(cu(res))
+                o.in1 = extra[3].data_ptr()
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+        sync()
+        return keep, acc
+
+    want, wacc = run(1)
+    got, gacc = run(33)
+    assert torch.isfinite(got[2].float()).all()
+    assert torch.equal(got[2], want[2])
+    want_ref = ref
+    if mode.startswith("eval"):
+        want_ref = ref * osc.double() + osh.double()
+        if mode == "eval_residual":
+            want_ref = want_ref.bfloat16().double() + res.double()
+        want_ref = torch.clamp(want_ref, min=0)
+    assert (got[2].float().cpu().double() - want_ref).abs().max().item() < 4e-2
+    if mode == "slab":
+        torch.testing.assert_close(got[3], want[3], rtol=1e-4, atol=2e-3)
+    elif mode == "atomic":
+        torch.testing.assert_close(gacc.double() / 2 ** 22, wacc.double() / 2 ** 22, rtol=1e-4, atol=5e-3)
+        assert int(gacc[1].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("derive", [False, True])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(64, 14, 14, 256, 1024), (5, 28, 28, 128, 512), (16, 7, 7, 512, 2048), (3, 9, 13, 64, 256)])
+def test_conv1x1_weights_in_registers_with_fused_input_bn_relu(lib, N, H, W, Cin, Cout, derive):
+    """conv_aw_kernel with the operand's BatchNorm + ReLU (bn2 in front of conv3) applied to the activation registers on their way
+    to LDS: output BITWISE that of the ring kernel's in-LDS transform (variant 1; same scalar form, same K order), statistics slabs
+    to rounding; rows past M (ragged last tile: 16 x 49 rows) stay zero in the column sums; table precomputed or derived from the
+    producer's integer sums (running statistics updated once, the other parity cleared); models.py:27."""
+    g = torch.Generator().manual_seed(N * 13 + W + Cin)
+    x = (torch.randn(N, Cin, H, W, generator=g) * 1.5 + 0.2).bfloat16()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).bfloat16().float()
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2 + 0.3
+    xf = x.float().permute(0, 2, 3, 1).reshape(-1, Cin).double()
+    M = xf.shape[0]
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
+    shift = (beta.double() - mean * scale.double()).float()
+    a = torch.clamp(x.float() * scale[None, :, None, None] + shift[None, :, None, None], min=0).bfloat16().float()
+    ref = F.conv2d(a.double(), w.double()).permute(0, 2, 3, 1).reshape(-1, Cout)
+
+    def run(v):
+        o, keep, _ = _conv_op(L.SAT_BF16, x.float().permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 0)
+        o.variant = v
+        extra = {"wp": _pack_weights(lib, keep[1], Cout, Cin, 1)}
+        o.w_packed = extra["wp"].data_ptr()
+        if derive:
+            iacc = torch.zeros(2, 2, Cin, dtype=torch.int64, device="cuda")
+            iacc[0, 0] = torch.round(xf.sum(0) * 4194304.0).long().cuda()
+            iacc[0, 1] = torch.round((xf ** 2).sum(0) * 4194304.0).long().cuda()
+            iacc[1] = 777
+            gd, bd, rm, rv = cu(gamma), cu(beta), cu(torch.zeros(Cin)), cu(torch.ones(Cin))
+            o.stat_acc1, o.gamma1, o.beta1 = iacc.data_ptr(), gd.data_ptr(), bd.data_ptr()
+            o.running_mean1, o.running_var1 = rm.data_ptr(), rv.data_ptr()
+            o.count, o.momentum, o.eps = M, 0.1, 1e-5
+            extra.update(iacc=iacc, gd=gd, bd=bd, rm=rm, rv=rv)
+        else:
+            sd, td = cu(scale), cu(shift)
+            o.scale0, o.shift0 = sd.data_ptr(), td.data_ptr()
+            extra.update(sd=sd, td=td)
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+        sync()
+        return keep, extra
+
+    want, wx = run(1)
+    got, gx = run(33)
+    assert torch.isfinite(got[2].float()).all()
+    assert torch.equal(got[2], want[2])
+    assert (got[2].float().cpu().double() - ref).abs().max().item() < 3e-2 + 4e-3 * ref.abs().max().item()
+    torch.testing.assert_close(got[3], want[3], rtol=1e-4, atol=2e-3)
+    if derive:
+        assert int(gx["iacc"][1].abs().sum()) == 0
+        assert torch.equal(gx["rm"], wx["rm"]) and torch.equal(gx["rv"], wx["rv"])
+
+
 def _stem_op(x_pad, w, Ho, Wo, groups=1):
     """the op program's stem conv (resnet.ConvStackProgram): a 7 x 1 kernel over rows of 8 pixels x 4 channels of a zero-bordered
     NHWC4 image, stride 2; x_pad bf16 [G*N][Hp][Wp][4] on the device, w bf16 [64][224]"""
@@ -460,7 +566,7 @@ def test_conv_stem_kernel_is_bit_identical_to_the_ring_kernel(lib, N, H, W):
     np.testing.assert_allclose(res[31][1][0, :, 0].cpu().double().sum(0).numpy(), ref.sum(0).numpy(), rtol=0, atol=2e-3 * ref.shape[0] ** 0.5 + 1e-3)
 
 
-@pytest.mark.parametrize("kind", ["ring", "ring_wide", "xp", "pr", "pw", "stem"])
+@pytest.mark.parametrize("kind", ["ring", "ring_wide", "xp", "pr", "pw", "aw", "stem"])
 def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
     """sat_op.groups = 3: three batches in ONE launch (grid.y = group; activations, statistics slabs / integer accumulators and the
     operand-BatchNorm accumulators + running-statistics log moved by their group strides, weights shared) against three launches,
@@ -489,14 +595,14 @@ def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
             assert torch.equal(outg[k * M:(k + 1) * M], out1) and torch.equal(partg[k], part1[0])
         return
     geo = {"ring": (4, 13, 11, 128, 192, 1, 2), "ring_wide": (4, 14, 14, 256, 512, 1, 22), "xp": (5, 12, 12, 256, 1024, 1, 28),
-           "pr": (5, 14, 14, 128, 256, 3, 30), "pw": (5, 14, 14, 128, 256, 3, 32)}[kind]
+           "pr": (5, 14, 14, 128, 256, 3, 30), "pw": (5, 14, 14, 128, 256, 3, 32), "aw": (5, 12, 12, 256, 1024, 1, 33)}[kind]
     N, H, W, Cin, Cout, k, variant = geo
     pad = 1 if k == 3 else 0
     x = (torch.randn(G * N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
     w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
     gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
     M = N * H * W
-    with_in_bn = kind in ("xp", "pr", "pw")
+    with_in_bn = kind in ("xp", "pr", "pw", "aw")
 
     def run(xs, groups):
         o, keep, _ = _conv_op(L.SAT_BF16, xs.float(), w.float(), 1, pad, stats=False)
@@ -504,8 +610,8 @@ def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
         acc = torch.zeros(groups, 2, 2, Cout, dtype=torch.int64, device="cuda")
         o.stat_acc = acc.data_ptr()
         extra = {"acc": acc}
-        if kind == "pw":
-            extra["wp"] = _pack_weights(lib, keep[1], Cout, Cin, 9)
+        if kind in ("pw", "aw"):
+            extra["wp"] = _pack_weights(lib, keep[1], Cout, Cin, k * k)
             o.w_packed = extra["wp"].data_ptr()
         if with_in_bn:
             iacc = torch.zeros(groups, 2, 2, Cin, dtype=torch.int64, device="cuda")
