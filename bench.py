@@ -464,7 +464,7 @@ def conv_roofline(torch, sat, model, images, wl, what, groups=1):
     if groups > 1:
         what = "pass of the grouped program = %d batches of %d images" % (groups, wl["batch"])
     return {"bound": "mfma", "batches_per_launch": groups,
-            "kernel": "bf16 implicit-GEMM conv launches (%d per %s: conv_glds_kernel ring variants, conv_xp_kernel for the expansion 1x1 convs, conv_pr_kernel for the 3x3 convs; autotuned per geometry)" % (n_conv, what),
+            "kernel": "bf16 implicit-GEMM conv launches (%d per %s: conv_pw_kernel for the 3x3 convs, conv_aw_kernel / conv_xp_kernel / conv_glds_kernel ring variants for the 1x1 convs, conv_stem_kernel; chosen per geometry by timing in the program)" % (n_conv, what),
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "algorithmic_gflop_per_launch": round(conv_flops / n_conv / 1e9, 3),

@@ -129,7 +129,7 @@ def _tdtype(dtype):
 
 # BatchNorm statistics as integer atomics straight from the conv epilogue up to this many 128-row tiles; beyond (the stem,
 # layer 1) the conv writes per-tile slabs and a wide reducer launch folds them into the same accumulators
-ATOMIC_MAX_TILES = 128
+ATOMIC_MAX_TILES = 128      # (measured again with the round-4 kernels: 400 / 1600 slow the convs by 2 / 6 % for the 21 / 37 reducer launches they save)
 
 
 _PROGRAM_PICKS = {}      # tune key -> variant chosen in a program of this process (ConvStackProgram._pick_in_program)

@@ -10,8 +10,11 @@ import sys
 from collections import defaultdict
 
 
+CONV_KERNELS = ('conv_glds_kernel', 'conv_xp_kernel', 'conv_pr_kernel', 'conv_stem_kernel', 'conv_pw_kernel', 'conv_aw_kernel')
+
+
 def cls(n):
-    if 'conv_glds_kernel' in n or 'conv_xp_kernel' in n or 'conv_pr_kernel' in n or 'conv_stem_kernel' in n:
+    if any(k in n for k in CONV_KERNELS):
         return 'conv'
     if 'bn_act_kernel' in n or 'bn_relu' in n or 'bn_strided' in n:
         return 'bn apply'
@@ -46,7 +49,7 @@ def main():
           % (nsteps, wall, tot / nsteps, tot / nsteps / wall))
     for k in sorted(busy, key=lambda k: -busy[k]):
         print("  %-28s %5d launches/step  %7.3f ms/step of spans" % (k, cnt[k] // nsteps, busy[k] / nsteps))
-    is_conv = lambda r: any(k in r['Kernel_Name'] for k in ('conv_glds_kernel', 'conv_xp_kernel', 'conv_pr_kernel', 'conv_stem_kernel'))
+    is_conv = lambda r: any(k in r['Kernel_Name'] for k in CONV_KERNELS)
     conv_win = [r for r in win if is_conv(r)]
     # bench.py's roofline leg: the conv launches after the last optimizer step run in sequence, alone
     tail = [r for r in rows if r['s'] > adam[-1]['e'] and is_conv(r)]

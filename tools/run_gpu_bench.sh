@@ -11,6 +11,8 @@ timeout -k 10 600 python bench.py --steps ${STEPS:-20} --warmup 5 > gpurun_out/b
 rc=$?
 cat gpurun_out/bench.json; tail -n 5 gpurun_out/bench.err
 if [ $rc -ne 0 ]; then echo "bench failed rc=$rc"; exit $rc; fi
+# ... and the strictly sequential schedule's own entries (there the ungrouped program leads the kernel choice)
+timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-mode --no-lookahead --repeats 1 > gpurun_out/bench_seq.json 2> gpurun_out/bench_seq.err || tail -3 gpurun_out/bench_seq.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 14 --warmup 3 --no-cpu-baseline --no-f32-mode --repeats 1 > $R/gpurun_out/prof_run.log 2>&1

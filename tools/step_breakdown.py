@@ -17,8 +17,7 @@ def short(n):
     m = re.search(r'conv_pr_kernel<([^>]*)>', n)       # LDS-resident input patch (3x3 convs)
     if m:
         return 'conv<pr:' + m.group(1).replace(' ', '') + '>'
-    if 'conv_stem_kernel' in n:                         # persistent stem kernel (sat_conv_stem.inc)
-        return 'conv<stem>'
+XX
     if 'bn_act_kernel' in n:
         return 'bn_add' if ('_Accum, bool' in n or 'Lb1' in n) else 'bn_relu'
     for k in ['bn_finalize', 'maxpool', 'avgpool', 'image_prep', 'lstm_persist', 'lstm_bwd_step', 'skinny', 'gemm_kernel', 'lstm_bwd_point', 'ce_rows',
