@@ -30,10 +30,11 @@ def main():
         r['s'], r['e'] = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     rows.sort(key=lambda r: r['s'])
     adam = [r for r in rows if 'clamp_adam' in r['Kernel_Name']]
-    if len(adam) < 12:
-        raise SystemExit("need a trace with at least 12 training steps")
-    # steady state: skip the warm-up steps + the timed region's pipeline fill at the front and the drain at the back
-    i0, i1 = 5, len(adam) - 4
+    if len(adam) < 18:
+        raise SystemExit("need a trace with at least 18 training steps")
+    # steady state: skip the warm-up steps + the timed region's pipeline fill at the front and the drain at the back (the last
+    # `lookahead_depth` = 6 steps start no new conv stack: their batches ran ahead already)
+    i0, i1 = 6, len(adam) - 8
     a0, a1 = adam[i0], adam[i1]
     nsteps = i1 - i0
     t0, t1 = a0['e'], a1['e']

@@ -15,7 +15,7 @@ if [ $rc -ne 0 ]; then echo "bench failed rc=$rc"; exit $rc; fi
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-mode --no-lookahead --repeats 1 > gpurun_out/bench_seq.json 2> gpurun_out/bench_seq.err || tail -3 gpurun_out/bench_seq.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 14 --warmup 3 --no-cpu-baseline --no-f32-mode --repeats 1 > $R/gpurun_out/prof_run.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-mode --repeats 1 > $R/gpurun_out/prof_run.log 2>&1
 rc=$?
 tail -n 3 $R/gpurun_out/prof_run.log
 # the same command with strictly sequential steps (--no-lookahead): per-launch spans there are the kernels alone

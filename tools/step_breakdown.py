@@ -17,7 +17,14 @@ def short(n):
     m = re.search(r'conv_pr_kernel<([^>]*)>', n)       # LDS-resident input patch (3x3 convs)
     if m:
         return 'conv<pr:' + m.group(1).replace(' ', '') + '>'
-XX
+    if 'conv_stem_kernel' in n:                         # persistent stem kernel (sat_conv_stem.inc)
+        return 'conv<stem>'
+    m = re.search(r'conv_pw_kernel<([^>]*)>', n)       # LDS-resident input patch, weights straight into registers (3x3 convs)
+    if m:
+        return 'conv<pw:' + m.group(1).replace(' ', '') + '>'
+    m = re.search(r'conv_aw_kernel<([^>]*)>', n)       # 1x1 convs, weights straight into registers
+    if m:
+        return 'conv<aw:' + m.group(1).replace(' ', '') + '>'
     if 'bn_act_kernel' in n:
         return 'bn_add' if ('_Accum, bool' in n or 'Lb1' in n) else 'bn_relu'
     for k in ['bn_finalize', 'maxpool', 'avgpool', 'image_prep', 'lstm_persist', 'lstm_bwd_step', 'skinny', 'gemm_kernel', 'lstm_bwd_point', 'ce_rows',
