@@ -31,7 +31,7 @@ def main():
     agg = defaultdict(lambda: defaultdict(float))
     for e in step:
         k = short(e["name"])
-        k = "conv_glds_kernel (all variants)" if k.startswith("conv<") else k
+        k = "conv (all kernels)" if k.startswith("conv<") else k
         agg[k]["launches"] += 1
         agg[k]["duration_us"] += (e["end"] - e["start"]) / 1e3
         for n, v in e["c"].items():
