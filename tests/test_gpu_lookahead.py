@@ -242,3 +242,39 @@ def test_train_eval_alternation_keeps_every_program():
     assert {k: id(v) for k, v in enc._programs.items()} == ids          # same objects: nothing was evicted and rebuilt
 
 
+
+
+def test_program_builds_and_their_tuning_passes_leave_the_model_untouched(tmp_path, monkeypatch):
+    """Building the op programs (the grouped leader, the forward's own, the look-ahead instances) times kernel variants on random data and,
+    for the final choice, runs the WHOLE program several times (`ConvStackProgram._pick_in_program`): no running statistic, counter or
+    parameter of the model may move, the statistics accumulators are handed over zeroed, and the choices round-trip through
+    SAT_TUNE_FILE: a second model loads them instead of tuning and computes the same bits (models.py:14-15: the stack is frozen)."""
+    import json
+    tune = tmp_path / "tune.json"
+    monkeypatch.setenv("SAT_TUNE_FILE", str(tune))
+    torch.manual_seed(3)
+    arch = dict(layers=(1, 2, 1, 1), width=64)            # wide enough for the weights-in-registers kernels (Cin % 64, Cout % 128)
+    enc = sat.EncoderCNN(32, arch=arch, compute_dtype="bf16").cuda().train()
+    before = {k: v.clone() for k, v in enc.state_dict().items()}
+    x = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    enc.build_lookahead(x)
+    prog = enc._program(x)
+    torch.cuda.synchronize()
+    after = enc.state_dict()
+    for k, v in before.items():
+        assert torch.equal(v, after[k]), k
+    assert prog._parity == 0 and prog._runs == [0, 0]        # (built and tuned, never run by a caller)
+    for acc in prog.stat_accs:
+        assert int(acc.abs().sum()) == 0
+    table = json.loads(tune.read_text())
+    assert any(",g2" in k for k in table) and any(",g1,s" in k for k in table)      # the grouped leader's entries and the constrained followers'
+    with torch.no_grad():
+        want = enc(x).clone()
+    variants = [int(prog.ops[i].variant) for i in range(prog.n_ops)]
+    torch.manual_seed(3)
+    enc2 = sat.EncoderCNN(32, arch=arch, compute_dtype="bf16").cuda().train()
+    with torch.no_grad():
+        got = enc2(x).clone()
+    prog2 = enc2._program(x)
+    assert [int(prog2.ops[i].variant) for i in range(prog2.n_ops)] == variants
+    assert torch.equal(got, want)
