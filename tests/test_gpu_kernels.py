@@ -1400,6 +1400,37 @@ def test_wide_tile_output_stores_are_stable_over_many_launches(lib, variant):
             assert torch.equal(out, first), rep
 
 
+@pytest.mark.parametrize("kind", ["pw", "aw"])
+def test_weights_in_registers_kernels_repeat_bit_for_bit_under_full_occupancy(lib, kind):
+    """conv_pw_kernel / conv_aw_kernel hand LDS buffers over with raw barriers and counted waits (triple-buffered patch slices with the
+    fetch issued from inline asm; activations staged through registers into three LDS buffers): a race there would show as launches
+    that differ.  The real layer-3 geometry with the fused operand BatchNorm at the row count of a two-batch launch (392 / 1568
+    workgroups: CUs with two resident workgroups next to CUs with one), 30 launches: every launch bit-identical to the first,
+    statistics included."""
+    g = torch.Generator().manual_seed(len(kind))
+    k, Cin, Cout, variant = (3, 256, 256, 32) if kind == "pw" else (1, 256, 1024, 33)
+    N, H, W, G = 128, 14, 14, 1
+    x = (torch.randn(G * N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+    o, keep, _ = _conv_op(L.SAT_BF16, x.float(), w.float(), 1, k // 2, stats=False)
+    wp = _pack_weights(lib, keep[1], Cout, Cin, k * k)
+    acc = torch.zeros(G, 2, 2, Cout, dtype=torch.int64, device="cuda")
+    sc, sh = cu(torch.rand(Cin, generator=g) + 0.5), cu(torch.randn(Cin, generator=g) * 0.2)
+    o.N, o.groups, o.variant, o.w_packed, o.stat_acc = N, G, variant, wp.data_ptr(), acc.data_ptr()
+    o.scale0, o.shift0 = sc.data_ptr(), sh.data_ptr()
+    first = None
+    for rep in range(30):
+        keep[2].fill_(float("nan"))
+        acc.zero_()
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+        out, a = keep[2].clone(), acc.clone()
+        if first is None:
+            first = (out, a)
+            assert torch.isfinite(out.float()).all() and int(a[:, 0].abs().sum()) > 0
+        else:
+            assert torch.equal(out, first[0]) and torch.equal(a, first[1]), rep
+
+
 @pytest.mark.parametrize("M,N,K,ks,bias", [(128, 128, 64, 1, False), (200, 260, 192, 1, True), (1216, 1000, 512, 1, True),
                                            (300, 512, 1280, 3, False), (77, 64, 4096, 16, False)])
 def test_gemm_bf16_nt_vs_f64_of_the_same_bf16_operands(lib, M, N, K, ks, bias):
