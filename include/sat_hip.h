@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 14
+#define SAT_ABI_VERSION 15
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -161,6 +161,9 @@ int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
  * running = (1-momentum)*running + momentum*batch for every item, one launch, bit-identical to the in-kernel update.  The
  * caller orders the calls like the batches (nn.BatchNorm2d momentum update, train.py:128 `encoder.train()`). */
 int sat_bn_running_apply(const sat_bn_running_item* items /*[device]*/, int n_items, float momentum, sat_stream_t stream);
+/* counters[i] += value for n int64 counters [device]: `num_batches_tracked += 1` of every BatchNorm of a stack in one launch
+ * (nn.BatchNorm2d / BatchNorm1d forward in training mode, models.py:27-28 under train.py:128 `encoder.train()`). */
+int sat_counter_add(int64_t* counters /*[device]*/, int n, int64_t value, sat_stream_t stream);
 int sat_run_ops_parity(const sat_op* ops /*[host]*/, int n_ops, int parity, sat_stream_t stream);
 /* The same program as ONE hipGraph launch (the reference's `self.resnet(images)` issues ~1500 eager kernels per
  * forward, models.py:27; here the host enqueues one graph).  sat_graph_create records ops[0..n) for the given step

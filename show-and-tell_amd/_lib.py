@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "sat_graph_destroy": (_i, [_vp]),
     "sat_conv_bn_relu_fwd": (_i, [C.POINTER(SatOp), C.POINTER(SatOp), C.POINTER(SatOp), _vp]),
     "sat_conv_tiles_m": (_i, [_i64]),
+    "sat_counter_add": (_i, [_vp, _i, _i64, _vp]),
     "sat_conv_variant_signature": (_i, [_i]),
     "sat_conv_variant_family": (_i, [_i]),
     "sat_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -184,3 +185,9 @@ def require_gpu(t, name="tensor"):
     if not t.is_cuda:
         raise RuntimeError("show-and-tell_amd: %s must live on the MI355X (got a %s tensor); the HIP path has no CPU fallback"
                            % (name, t.device))
+
+
+def counter_add(t, value=1):
+    """t += value for an int64 device tensor (BatchNorm's `num_batches_tracked`), through the library: no torch operator computes
+    anything on the product path"""
+    check(load().sat_counter_add(t.data_ptr(), t.numel(), value, stream()), "sat_counter_add")

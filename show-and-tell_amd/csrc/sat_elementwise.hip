@@ -942,6 +942,20 @@ extern "C" int sat_bn_running_apply(const sat_bn_running_item* items, int n_item
     return SAT_OK;
 }
 
+// nn.BatchNorm*.num_batches_tracked += 1 for every BatchNorm of a stack (one flat int64 tensor behind all of them): the last integer
+// add of the product path that was a torch operator
+__global__ void counter_add_kernel(long long* p, int n, long long v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += v;
+}
+extern "C" int sat_counter_add(int64_t* counters, int n, int64_t value, sat_stream_t stream) {
+    if (!counters || n < 0) return SAT_ERR_ARG;
+    if (n == 0) return SAT_OK;
+    hipLaunchKernelGGL(counter_add_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (long long*)counters, n, (long long)value);
+    SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
 int sat_bn_eval_batch_launch(const sat_op* op, hipStream_t s) {
     if (!op->in0 || op->count < 1 || op->count > 65535) return SAT_ERR_ARG;
     hipLaunchKernelGGL(bn_eval_batch_kernel, dim3((int)op->count), dim3(256), 0, s, (const sat_bn_eval_item*)op->in0, op->eps);

@@ -383,7 +383,7 @@ class EncoderCNN(nn.Module):
         out = _HeadFn.apply(pooled, self.resnet.fc.weight, self.resnet.fc.bias, self.bn.weight, self.bn.bias,
                             self.bn.running_mean, self.bn.running_var, self.training)
         if self.training:
-            self.bn.num_batches_tracked += 1
+            L.counter_add(self.bn.num_batches_tracked)
         return out
 
 

@@ -687,7 +687,7 @@ class ConvStackProgram:
         if self._running_items:
             L.check(L.load().sat_bn_running_apply(self._running_tables[group].data_ptr(), self._running_items, BN_MOMENTUM, L.stream()),
                     "sat_bn_running_apply")
-            self.stack._nbt_flat += 1
+            L.counter_add(self.stack._nbt_flat)
 
     def pooled_of(self, group=0):
         """pooled features f32 [N, feature_dim] of one group's batch (a view of the program's output buffer)"""
@@ -727,7 +727,7 @@ class ConvStackProgram:
         self._runs[p] += 1
         self._parity ^= 1
         if self.training and self._running_items is None:
-            self.stack._nbt_flat += 1
+            L.counter_add(self.stack._nbt_flat)
         return self.pooled
 
 
@@ -744,7 +744,7 @@ def _run_timed(self, images):
     self._runs[p] += 1
     self._parity ^= 1
     if self.training and self._running_items is None:
-        self.stack._nbt_flat += 1
+        L.counter_add(self.stack._nbt_flat)
     return self.pooled, [float(us[i]) for i in range(self.n_ops) if self.ops[i].kind == L.OP_CONV]
 
 

@@ -211,7 +211,7 @@ class TrainStep:
                                         L.ptr(bn.running_mean), L.ptr(bn.running_var), BN1D_MOMENTUM, BN_EPS, 1, B, F, E,
                                         L.ptr(bufs["feats"]), L.ptr(bufs["xhat"]), L.ptr(bufs["rstd"]),
                                         L.ptr(bufs["head_ws"]), bufs["head_ws"].numel() * 4, st), "sat_fc_bn1d_fwd")
-            bn.num_batches_tracked += 1
+            L.counter_add(bn.num_batches_tracked)
             feats_in = bufs["feats"]
         layers = [dec.lstm.layer(l) for l in range(dec.num_layers)]
         loss_slot = flat.grads[flat.loss_slot:flat.loss_slot + 1]
