@@ -679,9 +679,9 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
 // What fixes the BITS of a variant's BatchNorm column sums (the conv output itself is bit-identical across ring variants and
 // conv_xp_kernel: same MFMA, same K order): the kernel family and, for the ring kernel, the tile rows and the consumer wave
 // grid (rows summed per lane, then the M-waves in order).  Two variants with the same signature leave the same statistics, so a
-// grouped launch may pick any variant of its ungrouped twin's signature and stay bit-identical to it per batch.
-// What fixes the bits of the conv OUTPUT: the order in which the K axis is walked.  0: tap major (ring kernel, conv_xp_kernel, stem
-// kernel: bit-identical outputs), 1: channel-block major (conv_pr_kernel, conv_pw_kernel: bit-identical to each other)
+// grouped launch and an ungrouped one on variants of one signature give a batch the same bits.
+// What fixes the bits of the conv OUTPUT: the order in which the K axis is walked.  0: tap major (ring kernel, conv_xp_kernel,
+// conv_aw_kernel, stem kernel: bit-identical outputs), 1: channel-block major (conv_pr_kernel, conv_pw_kernel: bit-identical to each other)
 int output_family(int v) { return (kVariants[v].pr || kVariants[v].pw) ? 1 : 0; }
 constexpr int kFamilySig = 100000;          // signature constraints >= this one name an output family only (inference: no statistics)
 bool signature_matches(int v, int want);
@@ -935,7 +935,7 @@ extern "C" int sat_conv_autotune_topk(sat_op* ops, int n_ops, int reps, float* s
 }
 
 // the statistics signature of a variant number as stored in sat_op.variant (1-based; 0 / out of range: -1): callers that load a
-// saved tuning table check that a grouped op's variant matches its ungrouped twin's
+// saved tuning table check that a constrained op's variant still has the signature its leader program chose
 extern "C" int sat_conv_variant_signature(int variant) {
     return (variant >= 1 && variant <= kNumVariants) ? stat_signature(variant - 1) : -1;
 }

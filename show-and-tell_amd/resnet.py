@@ -140,10 +140,12 @@ class ConvStackProgram:
 
     groups = G > 1 (bf16, training): the program runs G independent batches in every launch (`sat_op.groups`, grid.y =
     group): activations are [G][N]..., every BatchNorm keeps per-group batch statistics, weights are shared.  Each group is,
-    instruction for instruction, the ungrouped program on its batch (the tuner keeps a grouped conv within its ungrouped twin's
-    statistics signature), so a batch's pooled features and BatchNorm statistics are bit-identical to what the ungrouped
-    program gives it.  Grouped programs always run with deferred running statistics (`defer_running_stats`), one update per
-    consumed batch."""
+    instruction for instruction, the ungrouped program on its batch as long as both run kernel variants of the same statistics
+    signature: the first program built for a model state tunes freely, every other one gets its `signatures()` as a constraint
+    (`signatures=`; `EncoderCNN._program` builds the grouped one first), so a batch's pooled features and BatchNorm statistics
+    are bit-identical whichever program runs it.  Grouped programs always run with deferred running statistics
+    (`defer_running_stats`), one update per consumed batch.  groups > 1 in eval mode: BatchNorm is a fixed affine there, so the
+    batches of a group simply concatenate into one program over groups * N images (no `sat_op.groups`)."""
 
     def __init__(self, stack, N, H, W, dtype, training, device, groups=1, signatures=None):
         self.N, self.H, self.W, self.dtype, self.training, self.groups = N, H, W, dtype, training, int(groups)
