@@ -265,6 +265,8 @@ class ConvStackProgram:
         # conv2 where conv_pr_kernel can run it (3x3 / stride 1, 128 <= planes <= 512, rows of <= 31 pixels: the transform
         # touches each 64-channel slice of the LDS-resident input patch once per workgroup).  Measured (round 3, bench.py, A/B on
         # one box): 15.37 -> 15.95 k img/s with three stacks in flight: 44 of the 50 normalise+ReLU launches of ResNet-152 disappear
+        # (round 4, with the weights-in-registers kernels: un-fusing bn1 / bn2 / both makes the convs 2 / 1.5 / 4 % faster in sequence and
+        # the step 0.5 / 2 / 4 % slower -- the separate passes' bytes still cost more than the transforms)
         fuse_in_bn = dtype == L.SAT_BF16
         fuse_bn1 = training and dtype == L.SAT_BF16
         fuse_out_bn = (not training) and dtype == L.SAT_BF16
