@@ -113,7 +113,7 @@ class InceptionProgram(ConvStackProgram):
     def __init__(self, stack, N, H, W, dtype, training, device):
         self.N, self.H, self.W, self.dtype, self.training, self.stack = N, H, W, dtype, training, stack
         self.groups, self._n_prep = 1, 1                   # one batch per launch; ops[0] is the image prep (ConvStackProgram.run)
-        self.keep, self.bn_list = [], []
+        self.keep, self.bn_list, self.stat_accs, self._want_sigs = [], [], [], {}
         td = torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
         esz = 2 if dtype == L.SAT_BF16 else 4
         ch = 16 // esz
@@ -182,6 +182,7 @@ class InceptionProgram(ConvStackProgram):
                 ops.extend([o, f, a])
             elif atomic:
                 acc = alloc((2, 1, 2, cv.cout), torch.int64, zero=True)
+                self.stat_accs.append(acc)
                 if tiles <= 128:
                     o.stat_acc = acc.data_ptr()
                     ops.append(o)
@@ -316,7 +317,6 @@ class InceptionProgram(ConvStackProgram):
         self._use_graph = os.environ.get("SAT_GRAPH", "1") != "0" and torch.device(device).type == "cuda"
         self._runs, self._graphs = [0, 0], [None, None]
         self._running_items = None
-        if dtype == L.SAT_BF16 and os.environ.get("SAT_AUTOTUNE", "1") != "0" and torch.device(device).type == "cuda":
-            scratch = alloc((4096,), torch.float32)         # per-geometry kernel selection, as on the ResNet path
-            L.check(lib.sat_conv_autotune(self.ops, self.n_ops, 3, scratch.data_ptr(), scratch.numel() * 4, L.stream()), "sat_conv_autotune")
-            torch.cuda.synchronize()
+        # per-geometry kernel selection, as on the ResNet path: the tuner's three fastest variants per geometry, the final choice by
+        # timing whole-program passes (ConvStackProgram._autotune; no activation buffer needs re-randomising: the tuner only times)
+        self._autotune(device, (), alloc)
