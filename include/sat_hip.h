@@ -131,9 +131,9 @@ typedef struct sat_op {
     const float* beta1;
     float* running_mean1;
     float* running_var1;
-    const void* w_packed;     /* SAT_OP_CONV, bf16, 3x3 / stride 1 / pad 1, Cin % 64 == 0, Cout % 128 == 0: the weights once more in MFMA
-                               * fragment order (sat_conv_pack_weights) -- lets the tuner pick conv_pw_kernel, which streams them
-                               * straight into registers; NULL = not provided */
+    const void* w_packed;     /* SAT_OP_CONV, bf16, Cin % 64 == 0, Cout % 128 == 0, 3x3 / stride 1 / pad 1 or 1x1 / pad 0: the weights once more in
+                               * MFMA fragment order (sat_conv_pack_weights) -- lets the tuner pick conv_pw_kernel (3x3) / conv_aw_kernel
+                               * (1x1), which stream them straight into registers; NULL = not provided */
     int32_t reserved1[2];     /* (were stat_shards / stat_shards1: sharded accumulators, removed in ABI 13 -- a measured wash) */
     /* SAT_OP_CONV extras for Inception-style stacks (BASELINE configs[3]): flags bit 1 (SAT_CONV_PADW) = the padding differs per
      * axis: `pad` is the vertical one, pad_w the horizontal one (1x7 / 7x1 / 1x3 / 3x1 kernels); ldc = row pitch of `out` in
