@@ -627,6 +627,7 @@ constexpr Variant kVariants[] = {
     {64, 1, 4, 0, 0, 128, 0, 0, 1},                                                                                      // persistent stem kernel: weights in registers, input row segments in LDS (sat_conv_stem.inc)
     {128, 1, 4, 0, 0, 128, 0, 0, 0, 1},                                                                                  // LDS-resident input patch + weights straight into registers from the fragment-ordered copy (3x3 / stride 1, sat_conv_pw.inc)
     {128, 3, 4, 0, 0, 128, 0, 0, 0, 0, 1},                                                                               // 1x1: activations through registers into LDS, weights straight into registers (sat_conv_aw.inc)
+    {256, 3, 8, 0, 0, 128, 0, 0, 0, 0, 2},                                                                               // ... eight waves, 256-column tiles: the activations staged once per row tile
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
@@ -671,7 +672,8 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 29: return launch_pr(a, groups, s);
         case 30: return launch_stem(a, groups, s);
         case 31: return launch_pw(a, groups, s);
-        case 32: return launch_aw(a, groups, s);
+        case 32: return launch_aw<4>(a, groups, s);
+        case 33: return launch_aw<8>(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -688,7 +690,7 @@ bool signature_matches(int v, int want);
 
 int stat_signature(int v) {
     const Variant& k = kVariants[v];
-    if (k.aw) return 5000;
+    if (k.aw) return 5000;          // (a lane's 64 rows, then the two halves: the same for the four- and the eight-wave form)
     if (k.pw) return 4000;
     if (k.stem) return 3000;
     if (k.pr) return 2000;
@@ -744,7 +746,7 @@ int op_groups(const sat_op* op) { return op->groups > 1 ? op->groups : 1; }
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
-    if (k.aw) return aw_ok(a);
+    if (k.aw) return aw_ok(a, k.aw == 2 ? 8 : 4);
     if (k.pw) return pw_ok(a);
     if (k.stem) return stem_ok(a);
     if (k.pr) return pr_ok(a);

@@ -107,7 +107,7 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 33
+NUM_CONV_VARIANTS = 34
 PLAIN_CONV_VARIANTS = list(range(1, 27))      # ring kernel variants (27..29: conv_xp_kernel, 30: conv_pr_kernel -- their own tests)
 
 
@@ -410,14 +410,18 @@ def test_conv3x3_weights_in_registers_with_fused_input_bn_relu(lib, N, H, W, Cin
 
 
 
+@pytest.mark.parametrize("variant", [33, 34])
 @pytest.mark.parametrize("mode", ["slab", "atomic", "eval", "eval_residual"])
 @pytest.mark.parametrize("N,H,W,Cin,Cout,stride", [(64, 14, 14, 1024, 256, 1), (5, 28, 28, 128, 512, 1), (7, 7, 7, 512, 2048, 1), (3, 9, 13, 64, 128, 1),
                                                    (4, 14, 14, 256, 512, 2), (2, 15, 13, 128, 128, 2), (1, 3, 3, 320, 256, 1)])
-def test_conv1x1_weights_in_registers_is_bit_identical_to_the_ring_kernel(lib, N, H, W, Cin, Cout, stride, mode):
+def test_conv1x1_weights_in_registers_is_bit_identical_to_the_ring_kernel(lib, N, H, W, Cin, Cout, stride, mode, variant):
     """conv_aw_kernel (variant 33: 1x1 convs with the activations staged global -> registers -> LDS and the weights streamed straight
-    into registers from the fragment-ordered copy, two workgroups per CU) against the ring kernel (variant 1: same K order, so the
+    into registers from the fragment-ordered copy, two workgroups per CU; variant 34: eight waves, 256-column tiles, the activations
+    staged once per row tile) against the ring kernel (variant 1: same K order, so the
     output is BITWISE equal; column sums to rounding) and the f64 definition; stride 2 (the projection shortcuts), ragged last tiles,
     1 to 16 K-steps (the tail of the three-step pipeline), the inference epilogue with and without the residual; models.py:27."""
+    if variant == 34 and Cout % 256:
+        pytest.skip("the eight-wave form needs Cout % 256 == 0")
     g = torch.Generator().manual_seed(N * 23 + W + Cin + stride)
     x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
     w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).bfloat16().float()
@@ -445,7 +449,7 @@ def test_conv1x1_weights_in_registers_is_bit_identical_to_the_ring_kernel(lib, N
         return keep, acc
 
     want, wacc = run(1)
-    got, gacc = run(33)
+    got, gacc = run(variant)
     assert torch.isfinite(got[2].float()).all()
     assert torch.equal(got[2], want[2])
     want_ref = ref
@@ -462,9 +466,10 @@ def test_conv1x1_weights_in_registers_is_bit_identical_to_the_ring_kernel(lib, N
         assert int(gacc[1].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("variant", [33, 34])
 @pytest.mark.parametrize("derive", [False, True])
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(64, 14, 14, 256, 1024), (5, 28, 28, 128, 512), (16, 7, 7, 512, 2048), (3, 9, 13, 64, 256)])
-def test_conv1x1_weights_in_registers_with_fused_input_bn_relu(lib, N, H, W, Cin, Cout, derive):
+def test_conv1x1_weights_in_registers_with_fused_input_bn_relu(lib, N, H, W, Cin, Cout, derive, variant):
     """conv_aw_kernel with the operand's BatchNorm + ReLU (bn2 in front of conv3) applied to the activation registers on their way
     to LDS: output BITWISE that of the ring kernel's in-LDS transform (variant 1; same scalar form, same K order), statistics slabs
     to rounding; rows past M (ragged last tile: 16 x 49 rows) stay zero in the column sums; table precomputed or derived from the
@@ -505,7 +510,7 @@ def test_conv1x1_weights_in_registers_with_fused_input_bn_relu(lib, N, H, W, Cin
         return keep, extra
 
     want, wx = run(1)
-    got, gx = run(33)
+    got, gx = run(variant)
     assert torch.isfinite(got[2].float()).all()
     assert torch.equal(got[2], want[2])
     assert (got[2].float().cpu().double() - ref).abs().max().item() < 3e-2 + 4e-3 * ref.abs().max().item()
@@ -566,7 +571,7 @@ def test_conv_stem_kernel_is_bit_identical_to_the_ring_kernel(lib, N, H, W):
     np.testing.assert_allclose(res[31][1][0, :, 0].cpu().double().sum(0).numpy(), ref.sum(0).numpy(), rtol=0, atol=2e-3 * ref.shape[0] ** 0.5 + 1e-3)
 
 
-@pytest.mark.parametrize("kind", ["ring", "ring_wide", "xp", "pr", "pw", "aw", "stem"])
+@pytest.mark.parametrize("kind", ["ring", "ring_wide", "xp", "pr", "pw", "aw", "aw8", "stem"])
 def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
     """sat_op.groups = 3: three batches in ONE launch (grid.y = group; activations, statistics slabs / integer accumulators and the
     operand-BatchNorm accumulators + running-statistics log moved by their group strides, weights shared) against three launches,
@@ -595,14 +600,14 @@ def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
             assert torch.equal(outg[k * M:(k + 1) * M], out1) and torch.equal(partg[k], part1[0])
         return
     geo = {"ring": (4, 13, 11, 128, 192, 1, 2), "ring_wide": (4, 14, 14, 256, 512, 1, 22), "xp": (5, 12, 12, 256, 1024, 1, 28),
-           "pr": (5, 14, 14, 128, 256, 3, 30), "pw": (5, 14, 14, 128, 256, 3, 32), "aw": (5, 12, 12, 256, 1024, 1, 33)}[kind]
+           "pr": (5, 14, 14, 128, 256, 3, 30), "pw": (5, 14, 14, 128, 256, 3, 32), "aw": (5, 12, 12, 256, 1024, 1, 33), "aw8": (5, 12, 12, 256, 1024, 1, 34)}[kind]
     N, H, W, Cin, Cout, k, variant = geo
     pad = 1 if k == 3 else 0
     x = (torch.randn(G * N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
     w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
     gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
     M = N * H * W
-    with_in_bn = kind in ("xp", "pr", "pw", "aw")
+    with_in_bn = kind in ("xp", "pr", "pw", "aw", "aw8")
 
     def run(xs, groups):
         o, keep, _ = _conv_op(L.SAT_BF16, xs.float(), w.float(), 1, pad, stats=False)
@@ -610,7 +615,7 @@ def test_grouped_conv_launch_equals_one_launch_per_batch(lib, kind):
         acc = torch.zeros(groups, 2, 2, Cout, dtype=torch.int64, device="cuda")
         o.stat_acc = acc.data_ptr()
         extra = {"acc": acc}
-        if kind in ("pw", "aw"):
+        if kind in ("pw", "aw", "aw8"):
             extra["wp"] = _pack_weights(lib, keep[1], Cout, Cin, k * k)
             o.w_packed = extra["wp"].data_ptr()
         if with_in_bn:
@@ -1400,7 +1405,7 @@ def test_wide_tile_output_stores_are_stable_over_many_launches(lib, variant):
             assert torch.equal(out, first), rep
 
 
-@pytest.mark.parametrize("kind", ["pw", "aw"])
+@pytest.mark.parametrize("kind", ["pw", "aw", "aw8"])
 def test_weights_in_registers_kernels_repeat_bit_for_bit_under_full_occupancy(lib, kind):
     """conv_pw_kernel / conv_aw_kernel hand LDS buffers over with raw barriers and counted waits (triple-buffered patch slices with the
     fetch issued from inline asm; activations staged through registers into three LDS buffers): a race there would show as launches
@@ -1408,7 +1413,7 @@ def test_weights_in_registers_kernels_repeat_bit_for_bit_under_full_occupancy(li
     workgroups: CUs with two resident workgroups next to CUs with one), 30 launches: every launch bit-identical to the first,
     statistics included."""
     g = torch.Generator().manual_seed(len(kind))
-    k, Cin, Cout, variant = (3, 256, 256, 32) if kind == "pw" else (1, 256, 1024, 33)
+    k, Cin, Cout, variant = (3, 256, 256, 32) if kind == "pw" else (1, 256, 1024, 33 if kind == "aw" else 34)
     N, H, W, G = 128, 14, 14, 1
     x = (torch.randn(G * N, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
     w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()

@@ -198,7 +198,7 @@ def bench_quant(reps=20):
     variants the grouped program runs (ring 128x128 two per CU, conv_pr_kernel, conv_xp_kernel 4 column tiles).  If the time is a
     step function of workgroups / CUs, a 128-row tile wastes 23 % of the chip at M = 12544 x G (196 G workgroups per 256 CUs)."""
     lib = L.load()
-    geoms = [(14, 14, 1024, 256, 1, 0, 3, 0), (14, 14, 1024, 256, 1, 0, 33, 0), (14, 14, 256, 256, 3, 1, 30, 1), (14, 14, 256, 256, 3, 1, 32, 1),
+    geoms = [(14, 14, 1024, 256, 1, 0, 3, 0), (14, 14, 1024, 256, 1, 0, 33, 0), (14, 14, 1024, 256, 1, 0, 34, 0), (14, 14, 256, 256, 3, 1, 30, 1), (14, 14, 256, 256, 3, 1, 32, 1),
              (28, 28, 128, 128, 3, 1, 30, 1), (28, 28, 128, 128, 3, 1, 32, 1), (14, 14, 256, 1024, 1, 0, 29, 1), (14, 14, 256, 1024, 1, 0, 33, 1)]
     if len(sys.argv) > 2:
         geoms = [g for g in geoms if str(g[6]) in sys.argv[2].split(",")]
