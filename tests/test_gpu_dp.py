@@ -248,3 +248,25 @@ def test_bench_py_decode_workload_shards_by_image_over_two_ranks():
     assert out["n_gpus"] == 2 and out["unit"] == "captions/sec" and out["config"]["global_batch"] == 128
     assert out["config"]["beam_size"] == 5 and out["config"]["features_finite"] is True
     assert out["config"]["ids_shape"] == [64, 20] and out["value"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_bench_py_single_gpu_line_carries_every_contract_key():
+    """the line the driver parses at N = 1 (`python bench.py --gpus 1 --steps K --warmup W`): contract keys, the `roofline` object of
+    the dominant kernel (achieved / peak / frac consistent, traffic either null or measured on this very library build) and the
+    `cpu_baseline` object (oracle port on the host's cores, rank 0, bounded sample)"""
+    out = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--repeats", "1"], {})
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["unit"] == "images/sec" and out["dtype"] == "bf16" and out["data"] == "synthetic" and out["vs_baseline"] is None
+    assert "configs[1]" in out["config"]["workload"] and out["config"]["global_batch"] == 64
+    assert abs(out["value"] - 64 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-2
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 1e6
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "images/sec" and c["value"] > 0 and c["cores"] >= 1 and c["threads"] >= 1 and c["sample"]
+    assert out["roofline_lstm"]["frac_of_f32_mfma_peak"] > 0 and out["f32_parity_mode"]["value"] > 0 and out["sequential_schedule"]["value"] > 0
