@@ -223,6 +223,11 @@ def bench_quant(reps=20):
             o.w_packed = wp.data_ptr()
             if fused:
                 o.scale0, o.shift0 = sc.data_ptr(), sh.data_ptr()
+            if os.environ.get("SAT_MB_EPILOGUE") == "1":      # the inference epilogue: affine + residual + ReLU instead of statistics
+                osc, osh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda") * 0.1
+                res = torch.randn(N * H * W, Cout, device="cuda").bfloat16()
+                o.stat_acc = None
+                o.scale1, o.shift1, o.in1, o.flags = osc.data_ptr(), osh.data_ptr(), res.data_ptr(), 1
             ops = (L.SatOp * 1)(o)
             us = time_ops(ops, 1, reps)
             M = N * H * W
