@@ -144,6 +144,24 @@ def test_inception_bf16_vs_oracle_within_the_bf16_noise_floor():
         assert torch.equal(g, got[0])
 
 
+def test_building_an_inception_program_leaves_the_model_untouched():
+    """the shared tuner times whole-program passes on random images before the first real forward (ConvStackProgram._pick_in_program):
+    running statistics, counters and parameters of the stack stay as they were, the statistics accumulators are handed over zeroed"""
+    enc, _, _ = _encoder("bf16", seed=8)
+    enc.train()
+    before = {k: v.clone() for k, v in enc.state_dict().items()}
+    x = torch.randn(4, 3, 299, 299, generator=torch.Generator().manual_seed(9)).cuda()
+    prog = enc._program(x)
+    torch.cuda.synchronize()
+    after = enc.state_dict()
+    for k, v in before.items():
+        assert torch.equal(v, after[k]), k
+    assert prog._parity == 0 and prog._runs == [0, 0] and prog.stat_accs
+    for acc in prog.stat_accs:
+        assert int(acc.abs().sum()) == 0
+    assert all(int(prog.ops[i].variant) > 0 for i in range(prog.n_ops) if prog.ops[i].kind == sat._lib.OP_CONV)
+
+
 @pytest.mark.timeout(900)
 def test_cfg4_train_step_inception_encoder_two_layer_lstm_vs_oracle():
     """BASELINE configs[3]: Inception-v3 299x299 + embed 512 / hidden 1024 / 2 LSTM layers, one whole train.py:126-146 iteration
