@@ -252,14 +252,14 @@ def cpu_baseline(torch, seed, wl, workload):
     dt = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
     rate64 = B * n / dt
-    # the oracle is slower per image at batch 64 than at the probe's batch 16 on these hosts: with a CPU quota of 16 cores the
-    # conv stack's batch-64 working set (a layer-1 activation is 64 x 256 x 56 x 56 x 4 B = 205 MB, im2col buffers on top) leaves
-    # the last-level-cache share of those cores, and at batch 16 it does not; the BEST rate found is the baseline, both are reported
-    common.update(value=round(max(rate64, rate16), 2), unit="images/sec", threads=threads,
-                  images_per_sec_batch64=round(rate64, 2))
+    # `value` is the rate at the WORKLOAD's batch (64: like for like with the GPU line).  The oracle is slower per image there than
+    # at the probe's batch 16 on these hosts -- with a CPU quota of 16 cores the conv stack's batch-64 working set (a layer-1
+    # activation is 64 x 256 x 56 x 56 x 4 B = 205 MB, im2col buffers on top) leaves the last-level-cache share of those cores, at
+    # batch 16 it does not -- so the batch-16 rate rides along as an extra
+    common.update(value=round(rate64, 2), unit="images/sec", threads=threads, images_per_sec_batch64=round(rate64, 2))
     common["images_per_sec_batch%d" % pb] = round(rate16, 2)
-    common["sample"] = ("CPU oracle (%s, torch-CPU fp32) on the same shapes: %d timed steps at batch %d and one at batch %d, at the best of "
-                        "%s torch threads (%d); value = the better of the two rates"
+    common["sample"] = ("CPU oracle (%s, torch-CPU fp32) on the same shapes: %d timed steps at batch %d (= value) and one at batch %d "
+                        "(extra field), at the best of %s torch threads (%d)"
                         % ("oracle/inception.py + oracle/train_step.py" if workload == "inception" else "oracle/train_step.py full_step",
                            n, B, pb, cands, threads))
     return common
@@ -464,7 +464,7 @@ def conv_roofline(torch, sat, model, images, wl, what, groups=1):
     if groups > 1:
         what = "pass of the grouped program = %d batches of %d images" % (groups, wl["batch"])
     return {"bound": "mfma", "batches_per_launch": groups,
-            "kernel": "bf16 implicit-GEMM conv launches (%d per %s: conv_pw_kernel for the 3x3 convs, conv_aw_kernel / conv_xp_kernel / conv_glds_kernel ring variants for the 1x1 convs, conv_stem_kernel; chosen per geometry by timing in the program)" % (n_conv, what),
+            "kernel": "bf16 implicit-GEMM conv launches (%d per %s: conv_pw_kernel for the 3x3 convs, conv_aw_kernel / conv_xp_kernel / conv_glds_kernel ring variants for the 1x1 convs, conv_stem_kernel; per geometry the variant the committed table show-and-tell_amd/tune/gfx950.json names -- no timing at start-up)" % (n_conv, what),
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "algorithmic_gflop_per_launch": round(conv_flops / n_conv / 1e9, 3),
@@ -517,7 +517,9 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-        if world > 1 and not os.environ.get("SAT_TUNE_FILE"):
+        if world > 1 and timed_tuning() and not os.environ.get("SAT_TUNE_FILE"):
+            # (only with SAT_AUTOTUNE=1 / force: by default every rank takes its kernel variants from the committed table,
+            # show-and-tell_amd/tune/gfx950.json, and nothing is timed)
             # ONE autotune per node, not one per rank: local rank 0 times the conv variants first (alone on its device, nothing of
             # another rank's competing for the host or -- when ranks share a device -- for the GPU), writes the table, and the
             # other ranks load it: every rank runs the same kernels, so the frozen stack sums in the same order on every rank
@@ -542,7 +544,7 @@ def main():
         dp.cap_lookahead()    # ... with the look-ahead depth that path runs at
     images, caps, lengths = synth_batch(torch, wl["batch"], wl["vocab"], wl["cap_len"], wl["image"], dev, 123 + rank)
     global_tokens = world * sum(l - 1 for l in lengths)
-    if use_dist and world > 1:
+    if use_dist and world > 1 and timed_tuning():
         # build (and autotune) the conv-stack programs on rank 0 first, then everywhere from rank 0's table
         if rank == 0:
             model.encoder._program(images)
@@ -646,6 +648,11 @@ def main():
         dist.destroy_process_group()
 
 
+def timed_tuning():
+    """SAT_AUTOTUNE=1 / force: kernel variants of geometries outside the committed table are chosen by timing (tune.py)"""
+    return os.environ.get("SAT_AUTOTUNE", "").strip().lower() in ("1", "time", "force")
+
+
 def timed_regions(args, torch, dist, dev, use_dist, region):
     """`--repeats` timed regions, each bracketed by barrier + synchronize on both sides, MAX over ranks"""
     dts = []
@@ -683,7 +690,7 @@ def run_decode(args, torch, dist, sat, wl, dev, rank, world, use_dist, backend):
         for i in range(48):
             model.encoder(batches[i % nb])
     model.eval()
-    if use_dist and world > 1:
+    if use_dist and world > 1 and timed_tuning():
         if rank == 0:
             model.encoder._program(batches[0])
             if args.lookahead:

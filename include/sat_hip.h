@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 15
+#define SAT_ABI_VERSION 16
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -202,6 +202,14 @@ int sat_conv_variant_signature(int variant);
  * (0: tap major -- ring, expansion and stem kernels; 1: channel-block major -- the two LDS-patch 3x3 kernels).  Outputs are
  * bit-identical within a family; accepted by sat_conv_autotune as a constraint like a statistics signature. */
 int sat_conv_variant_family(int variant);
+/* Kernel selection WITHOUT timing (the default since ABI 16: the arithmetic of a run must not depend on a stopwatch).  A tuned
+ * choice is a variant NUMBER, valid for the build it was measured on: sat_conv_num_variants() stamps a saved table
+ * (show-and-tell_amd/tune/gfx950.json).  For a geometry no table names, sat_conv_default_variant gives the variant (1-based) the op
+ * runs: the built-in heuristic, or -- want_sig >= 0 (a statistics signature / output family as above) and the heuristic's choice
+ * has another one -- the first variant of that signature the op can run; 0 if there is none.  A function of the op's geometry
+ * only: every process, rank and box gets the same answer (config.py:15 `random_seed`: same seed, same bits). */
+int sat_conv_num_variants(void);
+int sat_conv_default_variant(const sat_op* op /*[host]*/, int want_sig);
 /* bf16 weights [Cout][taps][Cin] (the kernels' layout; Cout % 32 == 0, Cin % 64 == 0) -> `packed` (same element count) in the
  * MFMA fragment order conv_pw_kernel streams into registers: [Cout/32][Cin/64][taps][4][64 lanes][8].  Once per weight version
  * of a frozen stack (`self.resnet(images)`, models.py:14-15,27). */

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -70,6 +70,8 @@ SIGNATURES = {
     "sat_counter_add": (_i, [_vp, _i, _i64, _vp]),
     "sat_conv_variant_signature": (_i, [_i]),
     "sat_conv_variant_family": (_i, [_i]),
+    "sat_conv_num_variants": (_i, []),
+    "sat_conv_default_variant": (_i, [C.POINTER(SatOp), _i]),
     "sat_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sat_conv_autotune": (_i, [C.POINTER(SatOp), _i, _i, _vp, _i64, _vp]),
     "sat_conv_autotune_topk": (_i, [C.POINTER(SatOp), _i, _i, _vp, _i64, _vp, _i, C.POINTER(C.c_int32)]),
@@ -145,22 +147,27 @@ SIGNATURES = {
 _lib = None
 
 
+def open_library(path):
+    """dlopen one build of the library and bind every declared symbol (tests bind the -DSAT_TESTHOOKS build this way)"""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "show-and-tell_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sat_version() != ABI_VERSION:
+        raise RuntimeError("%s: ABI version mismatch" % path)
+    return lib
+
+
 def load():
     """dlopen libsat_hip.so once; raises RuntimeError (never falls back) when it is missing."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                "show-and-tell_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
-        lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
-            fn.restype = res
-            fn.argtypes = args
-        if lib.sat_version() != ABI_VERSION:
-            raise RuntimeError("libsat_hip.so ABI version mismatch")
-        _lib = lib
+        _lib = open_library(LIB_PATH)
     return _lib
 
 

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import tune as T
 from .models import IdGuard
 from .pack import PackInfo
 
@@ -150,11 +151,18 @@ class VggProgram:
         self.features = self.fmap.view(N, self.P, c) if dtype == L.SAT_F32 else alloc((N, self.P, c), torch.float32)
         self.ops = (L.SatOp * len(ops))(*ops)
         self.n_ops = len(ops)
-        if dtype == L.SAT_BF16 and os.environ.get("SAT_AUTOTUNE", "1") != "0":
-            scratch = alloc((4096,), torch.float32)
-            L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 3, scratch.data_ptr(), scratch.numel() * 4, L.stream()),
-                    "sat_conv_autotune")
-            torch.cuda.synchronize()
+        if dtype == L.SAT_BF16:
+            # kernel variant per conv geometry: the committed table, the geometry-only default for anything it does not name;
+            # timing only on request (tune.py: SAT_AUTOTUNE=1 / force)
+            missing = T.assign(self.ops, self.n_ops)
+            if missing and T.mode() in ("time", "force"):
+                scratch = alloc((4096,), torch.float32)
+                L.check(L.load().sat_conv_autotune(self.ops, self.n_ops, 3, scratch.data_ptr(), scratch.numel() * 4, L.stream()),
+                        "sat_conv_autotune")
+                torch.cuda.synchronize()
+                T.save(self.ops, self.n_ops)
+            elif missing:
+                T.defaults(self.ops, missing)
 
     @torch.no_grad()
     def refresh_weights(self):

@@ -946,6 +946,23 @@ extern "C" int sat_conv_variant_family(int variant) {
     return (variant >= 1 && variant <= kNumVariants) ? kFamilySig + output_family(variant - 1) : -1;
 }
 
+// number of kernel variants of this build (a saved tuning table names variants by number: it is only valid for the build it was made on)
+extern "C" int sat_conv_num_variants(void) { return kNumVariants; }
+
+// The variant (1-based) a bf16 SAT_OP_CONV runs when nothing was tuned for its geometry: the built-in heuristic, or -- when a
+// statistics signature / output family is asked for (want_sig >= 0) and the heuristic's choice has another one -- the first variant
+// of that signature the op can run.  Depends on the op's geometry only: every process, rank and box gets the same answer.  0: none.
+extern "C" int sat_conv_default_variant(const sat_op* op, int want_sig) {
+    if (!op || op->kind != SAT_OP_CONV || op->dtype != SAT_BF16) return 0;
+    ConvArgs a;
+    if (prepare_args(op, 0, a) != SAT_OK) return 0;
+    const int hv = heuristic_variant(a);
+    if (variant_ok(hv, a) && (want_sig < 0 || signature_matches(hv, want_sig))) return hv + 1;
+    for (int v = 0; v < kNumVariants; ++v)
+        if (variant_ok(v, a) && (want_sig < 0 || signature_matches(v, want_sig))) return v + 1;
+    return 0;
+}
+
 // weights [Cout][KH*KW][Cin] bf16 (the kernels' layout) -> the MFMA fragment order conv_pw_kernel streams into registers; `packed`
 // holds Cout * KH*KW * Cin elements.  Frozen stacks pack once per weight version (ConvStackProgram).
 extern "C" int sat_conv_pack_weights(const void* w, void* packed, int Cout, int Cin, int taps, sat_stream_t stream) {

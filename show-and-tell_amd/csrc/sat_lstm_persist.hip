@@ -43,7 +43,7 @@ struct PersistArgs {
     unsigned* xch;        // [2 parities][groups][8 rows][H] self-tagged words, zeroed per call
     unsigned* err;        // sticky timeout word (zeroed per call; the CALLER reads it back: sat_lstm_fwd_status_offset)
     unsigned spin_limit;  // sweeps a workgroup waits for its group before it gives up
-    int dbg_stall;        // diagnostics (SAT_LSTM_DEBUG_STALL=1): workgroup 0 never publishes -> its group times out
+    int dbg_stall;        // test build only (-DSAT_TESTHOOKS, SAT_LSTM_DEBUG_STALL=1): workgroup 0 never publishes -> its group times out; always 0 in the product library
     int H, T, B, members;
     int prefix[kMaxT + 1];
 };
@@ -473,8 +473,10 @@ int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, flo
     a.H = H; a.T = T; a.B = B; a.members = members;
     const char* sl = getenv("SAT_LSTM_SPIN_LIMIT");
     a.spin_limit = (sl && atol(sl) > 0) ? (unsigned)atol(sl) : kSpinLimit;
+#ifdef SAT_TESTHOOKS        // fault injection exists only in the test build of the library (tests/_build/libsat_hip_testhooks.so)
     const char* ds = getenv("SAT_LSTM_DEBUG_STALL");
     a.dbg_stall = (ds && ds[0] == '1') ? 1 : 0;
+#endif
     a.prefix[0] = 0;
     for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
     hipError_t e = hipMemsetAsync(workspace, 0, (size_t)need, s);
@@ -508,8 +510,10 @@ int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* 
     a.H = H; a.T = T; a.B = B; a.members = members;
     const char* sl = getenv("SAT_LSTM_SPIN_LIMIT");
     a.spin_limit = (sl && atol(sl) > 0) ? (unsigned)atol(sl) : kSpinLimit;
+#ifdef SAT_TESTHOOKS
     const char* ds = getenv("SAT_LSTM_DEBUG_STALL");
     a.dbg_stall = (ds && ds[0] == '2') ? 1 : 0;
+#endif
     a.prefix[0] = 0;
     for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
     // Tags are epoch * 128 + step + 1 with a process-wide call counter, so the exchange is never cleared per call.  Invariant
@@ -523,8 +527,9 @@ int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* 
         std::lock_guard<std::mutex> lk(mu);
         if (++epoch >= (1u << 24)) { epoch = 1; ++generation; }
         a.epoch = epoch;
+        if (seen.size() > 4096) seen.clear();      // bounded; a forgotten buffer is cleared again only if the epoch has wrapped since the process began
         auto it = seen.find(xch);
-        if (it == seen.end()) seen.emplace(xch, generation);
+        if (it == seen.end()) { seen.emplace(xch, generation); clear = generation > 1; }
         else if (it->second != generation) { it->second = generation; clear = true; }
     }
     hipError_t e = hipMemsetAsync(err, 0, 64, s);

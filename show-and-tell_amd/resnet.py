@@ -18,13 +18,13 @@ conv3 applies bn2+ReLU to its operand in LDS.  Inference (bf16): every BatchNorm
 the producing conv's epilogue with the residual add and the ReLU.  The whole program replays as one hipGraph.
 """
 import ctypes as C
-import json
 import os
 
 import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import tune as T
 
 RESNET152 = dict(layers=(3, 8, 36, 3), width=64)
 BN_EPS = 1e-5
@@ -484,28 +484,20 @@ class ConvStackProgram:
         self._autotune(device, (self.c0, self.c1, self.a1, self.c2, self.a2, self.c3, self.cd, *self.ybuf), alloc)
 
     def _autotune(self, device, buffers, alloc):
-        """Build-time kernel selection per conv geometry (bf16): time every variant on this program's own buffers.
-        The choice is timing dependent and the tile shape fixes the BatchNorm summation order, so bf16 results are
-        bit-reproducible across processes only with the same choices: SAT_TUNE_FILE=<json> saves them / loads them back."""
-        if self.dtype != L.SAT_BF16 or os.environ.get("SAT_AUTOTUNE", "1") == "0" or torch.device(device).type != "cuda":
+        """Kernel selection per conv geometry (bf16).  Default: the COMMITTED table (`tune.py`, `tune/gfx950.json`: the BASELINE
+        geometries, measured once) and, for a geometry it does not name, the library's geometry-only default -- no stopwatch, so
+        every process, rank and box runs the same kernels and the same seed gives the same bits (round 4: a timing-based choice
+        moved the first-forward CE by 1.2e-3 between two processes).  SAT_AUTOTUNE=1 times the geometries the table does not name
+        on this program's own buffers (the tuner's three fastest per geometry, the final choice IN the program); SAT_TUNE_FILE=<json>
+        saves / reloads those."""
+        if self.dtype != L.SAT_BF16 or torch.device(device).type != "cuda":
             return
-        tune_file = os.environ.get("SAT_TUNE_FILE")
-        table = {}
-        if tune_file and os.path.exists(tune_file):
-            with open(tune_file) as f:
-                table = json.load(f)
-        missing = False
-        for i in range(self.n_ops):
-            o = self.ops[i]
-            if o.kind == L.OP_CONV:
-                want = self._want_sigs.get(self._layer_key(o))
-                v = table.get(self._tune_key(o, want))
-                if v is None or (want is not None and not self._matches(int(v), want)):
-                    missing = True
-                    o.variant = -want if want is not None else 0      # sat_conv_autotune: stay within this statistics signature
-                else:
-                    o.variant = int(v)
+        want_of = lambda o: self._want_sigs.get(self._layer_key(o))
+        missing = T.assign(self.ops, self.n_ops, want_of)
         if not missing:
+            return
+        if T.mode() not in ("time", "force"):
+            T.defaults(self.ops, missing, want_of)
             return
         chosen = {i: int(self.ops[i].variant) for i in range(self.n_ops) if self.ops[i].kind == L.OP_CONV}
         for t in buffers:
@@ -521,21 +513,7 @@ class ConvStackProgram:
                 self.ops[i].variant = v                   # (entries the table already had stay as loaded)
         if topk > 1:
             self._pick_in_program(cand, topk, {i for i, v in chosen.items() if v > 0}, device)
-        if tune_file:
-            if os.path.exists(tune_file):                 # another instance / rank may have added entries meanwhile
-                try:
-                    with open(tune_file) as f:
-                        table.update(json.load(f))
-                except ValueError:
-                    pass
-            for i in range(self.n_ops):
-                o = self.ops[i]
-                if o.kind == L.OP_CONV:
-                    table[self._tune_key(o, self._want_sigs.get(self._layer_key(o)))] = int(o.variant)
-            tmp = "%s.%d.tmp" % (tune_file, os.getpid())          # whole-file replace: other ranks may be reading it
-            with open(tmp, "w") as f:
-                json.dump(table, f, indent=0, sort_keys=True)
-            os.replace(tmp, tune_file)
+        T.save(self.ops, self.n_ops, want_of)
 
     def _pick_in_program(self, cand, topk, fixed, device):
         """The final choice among the tuner's `topk` fastest variants per conv geometry, made IN the program: a replayed launch finds
@@ -566,17 +544,28 @@ class ConvStackProgram:
             self.ops[g].in0 = im.data_ptr()
         us = (C.c_float * self.n_ops)()
         total = {key: [0.0] * len(v) for key, v in lists.items()}
-        for k in range(depth):
-            for key, ix in classes.items():
-                v = lists[key][min(k, len(lists[key]) - 1)]
-                for i in ix:
-                    self.ops[i].variant = v
-            for rep in range(6):                          # parity pairs; the first pair warms up
-                L.check(lib.sat_run_ops_timed(self.ops, self.n_ops, rep & 1, L.stream(), us), "sat_run_ops_timed")
-                if rep >= 2:
-                    for key, ix in classes.items():
-                        if k < len(lists[key]):
-                            total[key][k] += sum(us[i] for i in ix)
+        try:
+            for k in range(depth):
+                for key, ix in classes.items():
+                    v = lists[key][min(k, len(lists[key]) - 1)]
+                    for i in ix:
+                        self.ops[i].variant = v
+                for rep in range(6):                          # parity pairs; the first pair warms up
+                    L.check(lib.sat_run_ops_timed(self.ops, self.n_ops, rep & 1, L.stream(), us), "sat_run_ops_timed")
+                    if rep >= 2:
+                        for key, ix in classes.items():
+                            if k < len(lists[key]):
+                                total[key][k] += sum(us[i] for i in ix)
+        finally:
+            # the passes ran with real momentum on the model's running statistics (ungrouped programs defer theirs only after the
+            # build): put them back whatever happened, before anybody else can read them
+            torch.cuda.synchronize()
+            for acc in self.stat_accs:
+                acc.zero_()
+            for bn, (m, v) in zip(bns, saved):
+                bn.running_mean.copy_(m)
+                bn.running_var.copy_(v)
+            self._parity, self._runs = 0, [0, 0]
         verbose = os.environ.get("SAT_TUNE_VERBOSE") is not None
         for key, ix in classes.items():
             best = min(range(len(lists[key])), key=lambda k: total[key][k])
@@ -587,13 +576,6 @@ class ConvStackProgram:
             for i in ix:
                 self.ops[i].variant = lists[key][best]
             _PROGRAM_PICKS[key] = lists[key][best]
-        torch.cuda.synchronize()
-        for acc in self.stat_accs:
-            acc.zero_()
-        for bn, (m, v) in zip(bns, saved):
-            bn.running_mean.copy_(m)
-            bn.running_var.copy_(v)
-        self._parity, self._runs = 0, [0, 0]
 
     def signatures(self):
         """{conv layer: signature of the variant this program runs}: the BatchNorm statistics signature (training: tile shape and
@@ -613,25 +595,11 @@ class ConvStackProgram:
         return out
 
     def _matches(self, variant, want):
-        lib = L.load()
-        return (lib.sat_conv_variant_family(variant) if want >= 100000 else lib.sat_conv_variant_signature(variant)) == want
+        return T.matches(variant, want)
 
-    @staticmethod
-    def _layer_key(o):
-        """a conv layer whatever the batch: eval-mode look-ahead programs run the same layers on a concatenated batch"""
-        fused = (1 if (o.stat_partial or o.stat_acc) else 0) + (2 if (o.scale0 or o.stat_acc1) else 0) + \
-                (4 if o.scale1 else 0) + (8 if o.in1 else 0) + (16 if o.w_packed else 0)
-        return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d" % (o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout, o.KH, o.KW, o.stride, fused)
-
-    @staticmethod
-    def _geom_key(o):
-        fused = (1 if (o.stat_partial or o.stat_acc) else 0) + (2 if (o.scale0 or o.stat_acc1) else 0) + \
-                (4 if o.scale1 else 0) + (8 if o.in1 else 0) + (16 if o.w_packed else 0)
-        return "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d" % (o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout, o.KH, o.KW, o.stride, fused)
-
-    @classmethod
-    def _tune_key(cls, o, want_sig=None):
-        return "%s,g%d%s" % (cls._geom_key(o), max(int(o.groups), 1), "" if want_sig is None else ",s%d" % want_sig)
+    _layer_key = staticmethod(T.layer_key)
+    _geom_key = staticmethod(T.geom_key)
+    _tune_key = staticmethod(T.tune_key)
 
     def __del__(self):
         for g in getattr(self, "_graphs", ()):

@@ -268,12 +268,20 @@ class TrainStep:
         """Block until the device-side verdicts of the last submitted batch are known: raises IndexError on a bad caption id,
         RuntimeError when a persistent LSTM recurrence gave up (`watch.ResidencyWatch`; see `optimizer_step`)."""
         self.model.decoder.id_guard().poll(block=True)
+        self._retire_fixed_lag(0)          # data-parallel steps: every flag still in flight, oldest first (same order on every rank)
         from .watch import ResidencyWatch
         ResidencyWatch.get(self.model.decoder.linear.weight.device).poll(block=True)
 
     FAULT_NOTE = ("the parameter update of that step and of every step submitted since was SKIPPED on the device (on every rank in "
-                  "data-parallel training): parameters and Adam moments are exactly those before the faulted step and the step "
-                  "count has been rolled back; repeat the batches")
+                  "data-parallel training, where every rank raises this at the same step): parameters and Adam moments are exactly "
+                  "those before the faulted step and the step count has been rolled back; repeat the batches.  What is NOT rolled "
+                  "back: the BatchNorm running statistics and num_batches_tracked (the frozen stack's and the head's) have seen the "
+                  "dropped batches once already")
+
+    # data-parallel steps look at step k - DP_FAULT_LAG's (all-reduced, hence rank-identical) fault flag right after submitting step
+    # k, BLOCKING: every rank then raises at the same step, with the same steps dropped (ADVICE r4).  A lag of 2 keeps the host up
+    # to two steps ahead of the device, which is all the look-ahead needs.
+    DP_FAULT_LAG = 2
 
     def _on_fault(self, step_before):
         """host side of a raised fault: per-step launches from now on, step count back to where the first dropped update found
@@ -282,12 +290,48 @@ class TrainStep:
         self.step_count = step_before
         self._fault_sticky.zero_()
 
-    def optimizer_step(self, lr=None):
+    def _watch_fixed_lag(self, before, lag):
+        """The host half of the fault path for DATA-PARALLEL steps.  The device half is rank-consistent by construction (the flag
+        rides the all-reduce); the host half must be too: with the non-blocking poll of the single-rank path, ranks could see
+        the flag one step apart, the early one would clear its sticky word, and the late one's next update -- no longer dropped --
+        would mix a retried batch with a later one while both rolled their step counts back.  Here every rank copies
+        the step's REDUCED flag to pinned memory and, after submitting step k, waits for the copy of step k - lag: same flag, same
+        point in the loop, same decision on every rank.  While the faulted rank's sticky word is set, every rank's reduced flag is
+        non-zero, so the steps between the fault and the raise are dropped everywhere; the raise rolls the step count back to the
+        faulted step's on every rank and clears the sticky word."""
+        if getattr(self, "_dp_host", None) is None:
+            self._dp_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+            self._dp_pending, self._dp_slot = [], 0
+        slot = self._dp_slot
+        self._dp_slot = (slot + 1) % 8
+        self._dp_host[slot:slot + 1].copy_(self.fault_slot.view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._dp_pending.append((slot, ev, before))
+        self._retire_fixed_lag(lag)
+
+    def _retire_fixed_lag(self, keep):
+        pend = getattr(self, "_dp_pending", None)
+        while pend and len(pend) > keep:
+            slot, ev, before = pend.pop(0)
+            ev.synchronize()
+            code = int(self._dp_host[slot])
+            if code != 0:
+                torch.cuda.synchronize()
+                pend.clear()
+                self._dp_host.zero_()
+                self._on_fault(before)
+                raise RuntimeError("show-and-tell_amd: a persistent LSTM recurrence of a training step timed out waiting for its "
+                                   "workgroups to be resident together (reduced fault flag 0x%x: on this rank or another); %s.  "
+                                   "Later calls use the form without a device-wide wait" % (code & 0xffffffff, self.FAULT_NOTE))
+
+    def optimizer_step(self, lr=None, fixed_lag=None):
         """clip_gradient + Adam (train.py:145-146) as one launch over the flat buffers, GUARDED on the device by the step's
         fault flag: when a persistent LSTM launch of this step (any rank's, after the all-reduce) gave up waiting for its
         workgroups, the launch drops the whole update -- the garbage gradients never reach parameters or moments -- and so does
         every later one until the host has seen the flag (sticky), raised RuntimeError (at the latest on the next submit;
-        `check_ids()` at once) and rolled the step count back."""
+        `check_ids()` at once) and rolled the step count back.  fixed_lag (data-parallel steps): look at the flag of the step
+        submitted `fixed_lag` steps ago, blocking, instead of polling (`_watch_fixed_lag`)."""
         before = self.step_count
         self.step_count += 1
         f = self.flat
@@ -296,6 +340,9 @@ class TrainStep:
                                                      self.eps, float(self.grad_clip), self.step_count, L.ptr(self.fault_slot),
                                                      L.stream()), "sat_clamp_adam_step_guarded")
         torch.autograd.graph.increment_version(self._params_list)     # written through raw pointers: bump `_version` like torch would
+        if fixed_lag is not None:
+            self._watch_fixed_lag(before, int(fixed_lag))
+            return
         from .watch import ResidencyWatch
         ResidencyWatch.get(f.params.device).submit(self.fault_slot.view(torch.int32), "a persistent LSTM recurrence of a training step",
                                                    lambda: self._on_fault(before), note=self.FAULT_NOTE)
@@ -441,5 +488,8 @@ class DataParallelStep:
         for w in works:
             w.wait()                 # every bucket is reduced before clamp + Adam read the gradients
         loss = loss.clone()          # the slot in the flat gradient buffer is overwritten by the next step
-        eng.optimizer_step(lr)
+        if self.world > 1 and hasattr(eng, "DP_FAULT_LAG"):
+            eng.optimizer_step(lr, fixed_lag=eng.DP_FAULT_LAG)     # rank-consistent fault handling (TrainStep._watch_fixed_lag)
+        else:
+            eng.optimizer_step(lr)
         return loss

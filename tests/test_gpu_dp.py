@@ -80,6 +80,79 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------------
+# a persistent LSTM launch gives up on ONE rank: every rank must drop the same steps and raise at the same step
+HOOKS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libsat_hip_testhooks.so")
+
+
+def stall_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SAT_LIB"] = HOOKS_LIB              # the -DSAT_TESTHOOKS build: the product library has no fault injection
+    sat = importlib.import_module("show-and-tell_amd")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    feats, caps = make_batch()
+    model = make_model(sat)
+    ts = sat.TrainStep(model)
+    dp = sat.DataParallelStep(ts)
+    f, c, ln, tokens = sat.dp_shard(feats.cuda(), caps.cuda(), LENGTHS, rank, world)
+    log = {"raised_at": None, "msg": ""}
+    for i in range(2):
+        dp.step((f, c, ln), tokens)
+    ts.check_ids()
+    before = [t.clone() for t in (ts.flat.params, ts.flat.m, ts.flat.v)]
+    count = ts.step_count
+    for i in range(2, 8):
+        if i == 2 and rank == 1:                   # the third step's forward recurrence gives up on rank 1 ONLY
+            os.environ["SAT_LSTM_DEBUG_STALL"], os.environ["SAT_LSTM_SPIN_LIMIT"] = "1", "128"
+        try:
+            dp.step((f, c, ln), tokens)
+        except RuntimeError as e:
+            log["raised_at"], log["msg"] = i, str(e)
+            break
+        finally:
+            os.environ.pop("SAT_LSTM_DEBUG_STALL", None)
+            os.environ.pop("SAT_LSTM_SPIN_LIMIT", None)
+    torch.cuda.synchronize()
+    log["unchanged"] = all(torch.equal(a, b) for a, b in zip(before, (ts.flat.params, ts.flat.m, ts.flat.v)))
+    log["count_ok"] = ts.step_count == count
+    # training goes on (per-step launches now), the replicas stay bit-identical
+    for i in range(2):
+        dp.step((f, c, ln), tokens)
+    ts.check_ids()
+    log["count_after"] = ts.step_count - count
+    log["params"] = ts.flat.params.detach().cpu()
+    torch.save(log, out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_fault_on_one_rank_is_handled_identically_on_every_rank(tmp_path):
+    """ADVICE r4 (trainer.py): the device half of the fault path was rank-consistent (the flag rides the all-reduce), the host half
+    was not -- ranks polled without blocking, could raise one step apart, and then disagreed about which updates were dropped and
+    about Adam's step count.  Now data-parallel steps look at the REDUCED flag of the step submitted `DP_FAULT_LAG` steps ago,
+    blocking: rank 1's forward recurrence is made to give up in step 3 (test build of the library, SAT_LSTM_DEBUG_STALL on rank 1
+    only); BOTH ranks must raise in the same step, with parameters, moments and step count exactly those after step 2, and stay
+    bit-identical replicas afterwards.  train.py:43-44 (nn.DataParallel) / train.py:144-146"""
+    out = str(tmp_path / "stall.pt")
+    port = 31600 + os.getpid() % 2000
+    try:
+        mp.spawn(stall_worker, args=(2, port, out), nprocs=2, join=True)
+    except Exception as e:
+        if "gloo" in str(e).lower() and "cuda" in str(e).lower():
+            pytest.skip("gloo cannot reduce device tensors in this build: %s" % str(e)[:200])
+        raise
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    sat = importlib.import_module("show-and-tell_amd")
+    lag = sat.TrainStep.DP_FAULT_LAG
+    assert r0["raised_at"] == r1["raised_at"] == 2 + lag, (r0["raised_at"], r1["raised_at"])
+    for r in (r0, r1):
+        assert "SKIPPED on the device" in r["msg"] and "running statistics" in r["msg"]
+        assert r["unchanged"] and r["count_ok"] and r["count_after"] == 2
+    assert torch.equal(r0["params"], r1["params"])
+
+
+# ------------------------------------------------------------------------------------------------------
 # full model under DP: encoder (per-rank BatchNorm batch statistics, as nn.DataParallel replicas have them,
 # train.py:43-44), head gradients in bucket 2, checked against the CPU oracle run PER SHARD
 ARCH = dict(layers=(1, 1, 1, 1), width=8)
@@ -220,7 +293,7 @@ def _bench(args, env_extra, timeout=900):
 @pytest.mark.timeout(1200)
 def test_bench_py_gpus2_runs_its_real_multi_rank_branch_on_one_device():
     """The driver's SCALE run is `bench.py --gpus N` on a node this build never sees: run the REAL N = 2 child tree here (spawned
-    ranks, process group, rank-0-first autotune, DataParallelStep with its bucket all-reduces and the look-ahead spread over two
+    ranks, process group, kernel variants from the committed table on every rank, DataParallelStep with its bucket all-reduces and the look-ahead spread over two
     streams, barrier + MAX-over-ranks timing, one JSON line) -- both ranks on the one device, transport gloo instead of RCCL
     (SAT_BENCH_BACKEND / SAT_BENCH_SHARE_DEVICE; RCCL refuses two ranks on one device).  Everything but the transport is the
     code the 8-GPU run executes (train.py:43-44's nn.DataParallel replaced by one process per GPU)."""
@@ -237,6 +310,25 @@ def test_bench_py_gpus2_runs_its_real_multi_rank_branch_on_one_device():
     assert out["scaling"] == "weak" and out["metric"].startswith("images/sec")
     assert "f32_parity_mode" not in out and "cpu_baseline" not in out              # rank-0-only extras stay off at N > 1
     assert 0 < out["roofline"]["frac"] < 1
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("workload", ["train", "decode"])
+def test_bench_py_gpus4_rehearsal_on_one_device(workload):
+    """Towards the shape the driver's 8-GPU node runs first: `bench.py --gpus 4` -- ranks 2 and 3 exist, `decode_shard` / `dp_shard`
+    see a world beyond two, several processes build their op programs from the committed variant table at once -- on the one
+    device over gloo.  FOUR ranks, not eight: this pool kills a job with more than six processes on its GPU (the test session is
+    one of them), so N = 8 itself can only run on the driver's node.  One run, no loops.  train.py:43-44"""
+    import math
+    out = _bench(["--gpus", "4", "--workload", workload, "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline"],
+                 {"SAT_BENCH_BACKEND": "gloo", "SAT_BENCH_SHARE_DEVICE": "1"}, timeout=1100)
+    assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 256 and out["config"]["parallelism"].startswith("dp4")
+    assert out["config"]["backend"] == "gloo" and out["value"] > 0
+    if workload == "train":
+        assert math.isfinite(out["config"]["final_loss"]) and 8.5 < out["config"]["final_loss"] < 9.6
+        assert "committed table" in out["roofline"]["kernel"]       # every rank took its kernel variants from the same file
+    else:
+        assert out["config"]["features_finite"] is True and out["config"]["ids_shape"] == [64, 20]
 
 
 @pytest.mark.timeout(1200)

@@ -1287,11 +1287,13 @@ def test_fixed_point_statistics_hold_for_small_magnitude_channels(lib):
     assert (((got_v - unb).abs()) / (unb + 1e-5)).max().item() < 2e-3
 
 
-def test_persistent_lstm_timeout_is_reported_not_swallowed(lib, monkeypatch):
+def test_persistent_lstm_timeout_is_reported_not_swallowed(hooks_lib, monkeypatch):
     """ADVICE r2 / VERDICT r2 (robustness 10): a spin timeout inside the persistent recurrence sets the workspace's status word;
     `watch.ResidencyWatch` reads it back behind the call and raises, and the process falls back to one launch per step.
-    SAT_LSTM_DEBUG_STALL=1 makes workgroup 0 withhold its hidden state, SAT_LSTM_SPIN_LIMIT shortens the wait (models.py:52)."""
+    SAT_LSTM_DEBUG_STALL=1 makes workgroup 0 withhold its hidden state (TEST build of the library only: `hooks_lib`),
+    SAT_LSTM_SPIN_LIMIT shortens the wait (models.py:52)."""
     import importlib
+    lib = hooks_lib
     sat = importlib.import_module("show-and-tell_amd")
     M = importlib.import_module("show-and-tell_amd.models")
     torch.manual_seed(11)
@@ -1323,13 +1325,14 @@ def test_persistent_lstm_timeout_is_reported_not_swallowed(lib, monkeypatch):
 
 
 @pytest.mark.parametrize("stall", ["1", "2"])
-def test_a_stalled_train_step_never_reaches_the_parameters(lib, monkeypatch, stall):
+def test_a_stalled_train_step_never_reaches_the_parameters(hooks_lib, monkeypatch, stall):
     """ADVICE r3: a persistent LSTM launch that gives up (forward: SAT_LSTM_DEBUG_STALL=1, backward: =2) leaves garbage gradients;
     `TrainStep` folds the status words into the step's fault flag ON THE DEVICE (sat_step_fault_flag) and clamp + Adam read it
     (sat_clamp_adam_step_guarded): parameters, Adam moments and the step count must be bit for bit those before the faulted step
     -- also for a step submitted after it and before the host has seen the flag -- the RuntimeError must say so, and training
     continues with per-step launches.  train.py:144-146 / models.py:52"""
     import importlib
+    lib = hooks_lib
     sat = importlib.import_module("show-and-tell_amd")
     torch.manual_seed(3)
     model = sat.ShowAndTell(32, 64, 150, 1, arch=dict(layers=(1, 1, 1, 1), width=8), compute_dtype="f32").cuda().train()
@@ -1564,7 +1567,7 @@ def test_lstm_layer_bf16_pipe_gemms_vs_exact_f32(lib, B, T, In, H):
 
 @pytest.mark.parametrize("B,T,In,H,ragged", [(64, 19, 256, 512, False), (64, 19, 256, 512, True), (16, 7, 32, 64, True), (5, 4, 36, 48, True),
                                              (24, 12, 64, 128, True)])
-def test_lstm_bwd_persistent_recurrence_equals_per_step_launches(lib, B, T, In, H, ragged, monkeypatch):
+def test_lstm_bwd_persistent_recurrence_equals_per_step_launches(lib, B, T, In, H, ragged, monkeypatch, request):
     """sat_lstm_bwd with the FULL workspace (the backward recurrence as ONE persistent launch: W_hh quarter per wave in registers,
     per-group exchange of the d(pre-activation) rows, dc in a register) against the same entry point with the minimal workspace
     (one fused launch per step): DG and every gradient to 2e-6 relative of the largest entry (another K summation order); status
@@ -1589,7 +1592,7 @@ def test_lstm_bwd_persistent_recurrence_equals_per_step_launches(lib, B, T, In, 
     soff = lib.sat_lstm_bwd_status_offset(N, B, In, H)
     assert soff == full - 64
 
-    def run(nbytes):
+    def run(nbytes, lib=lib):
         DG = torch.full((N, 4 * H), float("nan"), device="cuda")
         dwi, dwh = torch.full((4 * H, In), float("nan"), device="cuda"), torch.full((4 * H, H), float("nan"), device="cuda")
         dbi, dbh, dX = torch.empty(4 * H, device="cuda"), torch.empty(4 * H, device="cuda"), torch.full((N, In), float("nan"), device="cuda")
@@ -1609,6 +1612,8 @@ def test_lstm_bwd_persistent_recurrence_equals_per_step_launches(lib, B, T, In, 
         assert (pers[key] - step[key]).abs().max().item() < 2e-6 * scale + 1e-9, (key, (pers[key] - step[key]).abs().max().item(), scale)
     if lib.sat_lstm_fwd_ws_bytes(B, H) > 0 and B >= 16:
         monkeypatch.setenv("SAT_LSTM_DEBUG_STALL", "2")
-        monkeypatch.setenv("SAT_LSTM_SPIN_LIMIT", "128")
         _, status = run(full)
+        assert status == 0                       # the PRODUCT library has no fault-injection switch: the variable does nothing
+        monkeypatch.setenv("SAT_LSTM_SPIN_LIMIT", "128")
+        _, status = run(full, request.getfixturevalue("hooks_lib"))      # the test build (-DSAT_TESTHOOKS) withholds a hand-off
         assert status != 0                       # reported, not swallowed (watch.ResidencyWatch raises on it)
