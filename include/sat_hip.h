@@ -63,8 +63,27 @@ enum {
     SAT_OP_MAXPOOL3S2 = 10,/* out = maxpool 3x3 / stride 2 / no padding of in0 (NHWC, Cout channels; ldc = output row pitch) */
     SAT_OP_AVGPOOL3 = 11,  /* out = avgpool 3x3 / stride 1 / pad 1, count_include_pad (divide by 9) of in0 (NHWC, Cout channels) */
     SAT_OP_MAXPOOL2 = 9,   /* out = maxpool 2x2 / stride 2 of in0 (NHWC; Hin, Win even; Cout channels): VGG16, model2.py:15-16 */
-    SAT_OP_BN_EVAL_BATCH = 8 /* eval mode: in0 = DEVICE array of `count` sat_bn_eval_item; every item's (scale, shift)
+    SAT_OP_BN_EVAL_BATCH = 8,/* eval mode: in0 = DEVICE array of `count` sat_bn_eval_item; every item's (scale, shift)
                               * from its running statistics in ONE launch (replaces one BN_FINALIZE per layer); eps */
+    /* Train-mode bn3 of a bottleneck WITHOUT a pass over conv3's output (models.py:27, BatchNorm2d with batch statistics): mean and
+     * variance of c3 = a2 W3^T are a linear / quadratic form of conv3's INPUT a2 = relu(bn2(c2)): mean_c = w_c . mu,
+     * var_c = w_c^T (G / M - mu mu^T) w_c with G = a2^T a2 (P x P, P = planes).  Four ops in front of conv3, which then runs with
+     * the inference epilogue (scale1 / shift1 = the table, in1 = the residual, flags bit 0 = ReLU; SAT_CONV_GROUP_TABLE when grouped):
+     * the raw conv3 tensor and the SAT_OP_BN_ADD_RELU launch (42 % of the stack's memory traffic in round 4) never exist.
+     * bf16 only; P in {128, 256, 384, 512}.  All honour `groups`. */
+    SAT_OP_GRAM = 12,        /* in0 = raw conv2 output [G][M = N*Hout*Wout][P = Cout]; its BatchNorm + ReLU as on a conv's fused input
+                              * (stat_acc1 / gamma1 / beta1 / count / eps, or scale0 / shift0): read only, nothing cleared or updated;
+                              * out = f32 slabs [G][sat_gram_slab_floats(M, P)]: per row slab the partial 128 x 128 tiles of G (upper
+                              * triangle of tile pairs) and the P column sums, f32 MFMA accumulate */
+    SAT_OP_GRAM_COV = 13,    /* in0 = those slabs (same N / Hout / Wout / Cout); slabs summed in slab order in f64, cov = G / M - mu mu^T
+                              * rounded to f32 and split exactly into three bf16 terms: out = bf16 [G][3][P][P]; scale_out = mu as
+                              * DOUBLE [G][P] */
+    SAT_OP_GEMM_BF16_NT = 14,/* out f32 [M = N*Hout*Wout][Cout] = in0 bf16 [M][K = Cin] x w bf16 [Cout][K]^T (sat_gemm_bf16_nt); here:
+                              * T [G * 3 P][Cout] = cov3 x conv3's weight matrix */
+    SAT_OP_BN_FROM_GRAM = 15 /* in0 = T f32 [G][3 P][Cout], w = conv3's weights bf16 [Cout][P = Cin], in1 = mu f64 [G][P]; gamma / beta /
+                              * running_mean / running_var / momentum / eps / count (= M) of bn3: var_c = sum_i w[c][i] (T0+T1+T2)[i][c],
+                              * mean_c = w_c . mu in f64 -> scale_out = f32 table [G][2][Cout] (scale row, shift row); running statistics
+                              * updated in place (grouped: the deferred log [G][2][Cout]) */
 };
 
 /* one BatchNorm of an eval-mode stack (all pointers device memory, C floats each) */
@@ -153,6 +172,14 @@ typedef struct sat_op {
     int64_t ldc;
 } sat_op;
 #define SAT_CONV_PADW 2
+#define SAT_CONV_GROUP_TABLE 4   /* SAT_OP_CONV flags: scale1 / shift1 are PER GROUP, [G][2][Cout] apart (the table SAT_OP_BN_FROM_GRAM writes), and
+                                  * in1 (the residual) is per group like `out`: lets a grouped train-mode program run conv3 with the
+                                  * inference epilogue */
+/* slab geometry of SAT_OP_GRAM: rows per slab and slab count are functions of (M, P) only -- never of `groups` -- so a batch's
+ * statistics are summed in the same order in the grouped and the ungrouped program; floats of ONE group's slab buffer */
+int sat_gram_rows_per_slab(int64_t M, int P);
+int sat_gram_slabs(int64_t M, int P);
+int64_t sat_gram_slab_floats(int64_t M, int P);
 int sat_run_ops(const sat_op* ops /*[host]*/, int n_ops, sat_stream_t stream);
 /* same, with the step parity (0/1) that selects the half of every stat_acc buffer in use */
 /* Deferred running statistics.  A program built with its sat_op running_mean / running_var pointers aimed at PRIVATE, zeroed

@@ -16,7 +16,9 @@ OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_M
 OP_BN_EVAL_BATCH = 8
 OP_MAXPOOL2 = 9
 OP_MAXPOOL3S2, OP_AVGPOOL3 = 10, 11
+OP_GRAM, OP_GRAM_COV, OP_GEMM_BF16_NT, OP_BN_FROM_GRAM = 12, 13, 14, 15
 CONV_PADW = 2
+CONV_GROUP_TABLE = 4
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -70,6 +72,9 @@ SIGNATURES = {
     "sat_counter_add": (_i, [_vp, _i, _i64, _vp]),
     "sat_conv_variant_signature": (_i, [_i]),
     "sat_conv_variant_family": (_i, [_i]),
+    "sat_gram_rows_per_slab": (_i, [_i64, _i]),
+    "sat_gram_slabs": (_i, [_i64, _i]),
+    "sat_gram_slab_floats": (_i64, [_i64, _i]),
     "sat_conv_num_variants": (_i, []),
     "sat_conv_default_variant": (_i, [C.POINTER(SatOp), _i]),
     "sat_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -6,7 +6,7 @@ OUT=../libsat_hip.so
 FLAGS="${SAT_EXTRA_FLAGS} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 pids=()
-for f in sat_gemm sat_gemm_bf16 sat_conv_glds sat_lstm_persist sat_skinny sat_elementwise sat_attend sat_beam sat_host; do
+for f in sat_gemm sat_gemm_bf16 sat_conv_glds sat_lstm_persist sat_skinny sat_elementwise sat_attend sat_beam sat_gram sat_host; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ sat_common.h -nt build/$f.o ] || [ sat_internal.h -nt build/$f.o ] || [ sat_conv_xp.inc -nt build/$f.o ] || [ sat_conv_pr.inc -nt build/$f.o ] || [ sat_conv_stem.inc -nt build/$f.o ] || [ sat_conv_pw.inc -nt build/$f.o ] || [ sat_conv_aw.inc -nt build/$f.o ] || [ ../../include/sat_hip.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
@@ -19,6 +19,6 @@ if [ ! -f build/sat_lstm_persist_testhooks.o ] || [ sat_lstm_persist.hip -nt bui
   hipcc $FLAGS -DSAT_TESTHOOKS -c sat_lstm_persist.hip -o build/sat_lstm_persist_testhooks.o
 fi
 mkdir -p ../../tests/_build
-hipcc --offload-arch=gfx950 -shared -fPIC build/sat_gemm.o build/sat_gemm_bf16.o build/sat_conv_glds.o build/sat_lstm_persist_testhooks.o build/sat_skinny.o build/sat_elementwise.o build/sat_attend.o build/sat_beam.o build/sat_host.o -o ../../tests/_build/libsat_hip_testhooks.so
-hipcc --offload-arch=gfx950 -shared -fPIC build/sat_gemm.o build/sat_gemm_bf16.o build/sat_conv_glds.o build/sat_lstm_persist.o build/sat_skinny.o build/sat_elementwise.o build/sat_attend.o build/sat_beam.o build/sat_host.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC build/sat_gemm.o build/sat_gemm_bf16.o build/sat_conv_glds.o build/sat_lstm_persist_testhooks.o build/sat_skinny.o build/sat_elementwise.o build/sat_attend.o build/sat_beam.o build/sat_gram.o build/sat_host.o -o ../../tests/_build/libsat_hip_testhooks.so
+hipcc --offload-arch=gfx950 -shared -fPIC build/sat_gemm.o build/sat_gemm_bf16.o build/sat_conv_glds.o build/sat_lstm_persist.o build/sat_skinny.o build/sat_elementwise.o build/sat_attend.o build/sat_beam.o build/sat_gram.o build/sat_host.o -o $OUT
 echo "built $OUT"

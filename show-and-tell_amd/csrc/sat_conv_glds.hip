@@ -79,6 +79,7 @@ struct ConvArgs {
     // per-batch pointer moves by its group stride (elements of its own type), nothing else changes: each group is the very
     // instruction sequence of the ungrouped launch on its batch (same tiles, same summation order, own statistics)
     long gs_a, gs_c, gs_partial, gs_acc, gs_in_acc, gs_in_run;
+    long gs_out_tab;         // SAT_CONV_GROUP_TABLE: out_scale / out_shift move by this many floats per group (the table SAT_OP_BN_FROM_GRAM writes), else 0
 };
 // fixed-point scale of the atomic statistics is SAT_STAT_SCALE (sat_internal.h)
 constexpr double kStatScale = SAT_STAT_SCALE;
@@ -128,6 +129,7 @@ __device__ __forceinline__ ConvArgs group_args(const ConvArgs& q) {
         p.A += g * q.gs_a;
         p.C += g * q.gs_c;
         if (p.residual) p.residual += g * q.gs_c;
+        if (p.out_scale) { p.out_scale += g * q.gs_out_tab; p.out_shift += g * q.gs_out_tab; }
         if (p.stat_partial) p.stat_partial += g * q.gs_partial;
         if (p.acc) p.acc += g * q.gs_acc;
         if (p.in_acc) p.in_acc += g * q.gs_in_acc;
@@ -738,6 +740,7 @@ ConvArgs make_args(const sat_op* op) {
     a.gs_acc = 4L * a.N;                        // [2 parities][2][N]
     a.gs_in_acc = 4L * a.Cin;
     a.gs_in_run = 2L * a.Cin;                   // [mean row][var row]
+    a.gs_out_tab = (op->flags & SAT_CONV_GROUP_TABLE) ? 2L * a.N : 0L;      // [scale row][shift row] per group
     return a;
 }
 
@@ -793,7 +796,8 @@ int prepare_args(const sat_op* op, int parity, ConvArgs& a) {
     if (op_groups(op) > 1) {
         // grouped: batch statistics only (a fixed affine needs no groups: eval-mode batches simply concatenate), running
         // statistics in the per-group [mean row][var row] log layout
-        if (a.out_scale || a.residual || (a.in_affine && !a.in_acc)) return SAT_ERR_UNSUPPORTED;
+        // (train-mode conv3 behind SAT_OP_BN_FROM_GRAM: a per-group (scale, shift) table and a per-group residual, SAT_CONV_GROUP_TABLE)
+        if (((a.out_scale || a.residual) && !(op->flags & SAT_CONV_GROUP_TABLE)) || (a.in_affine && !a.in_acc)) return SAT_ERR_UNSUPPORTED;
         if (a.in_running_mean && a.in_running_var != a.in_running_mean + a.Cin) return SAT_ERR_ARG;
         if (a.stat_partial && op->tiles_m < sat_cdiv(a.M, 128)) return SAT_ERR_ARG;
         if (op_groups(op) > 65535) return SAT_ERR_ARG;

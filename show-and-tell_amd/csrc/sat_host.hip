@@ -40,6 +40,10 @@ extern "C" int sat_run_ops_parity(const sat_op* ops, int n_ops, int parity, sat_
             case SAT_OP_MAXPOOL2: rc = sat_maxpool2_launch(op, s); break;
             case SAT_OP_MAXPOOL3S2: rc = sat_pool3_launch(op, false, s); break;
             case SAT_OP_AVGPOOL3: rc = sat_pool3_launch(op, true, s); break;
+            case SAT_OP_GRAM: rc = sat_gram_launch(op, parity, s); break;
+            case SAT_OP_GRAM_COV: rc = sat_gram_cov_launch(op, s); break;
+            case SAT_OP_GEMM_BF16_NT: rc = sat_gemm_bf16_op_launch(op, s); break;
+            case SAT_OP_BN_FROM_GRAM: rc = sat_bn_from_gram_launch(op, s); break;
             default: rc = SAT_ERR_UNSUPPORTED;
         }
         if (rc != SAT_OK) return rc;

@@ -12,6 +12,11 @@ int sat_bn_relu_maxpool_launch(const sat_op* op, int parity, hipStream_t s);
 int sat_avgpool_launch(const sat_op* op, hipStream_t s);
 int sat_maxpool2_launch(const sat_op* op, hipStream_t s);
 int sat_pool3_launch(const sat_op* op, bool avg, hipStream_t s);
+// bn3 from the Gram matrix of conv3's input (sat_gram.hip)
+int sat_gram_launch(const sat_op* op, int parity, hipStream_t s);
+int sat_gram_cov_launch(const sat_op* op, hipStream_t s);
+int sat_gemm_bf16_op_launch(const sat_op* op, hipStream_t s);
+int sat_bn_from_gram_launch(const sat_op* op, hipStream_t s);
 
 // f32 operands on the bf16 matrix pipe (sat_gemm_bf16.hip): C[M,N] = op(A) op(B)^T + bias + bias2, operands row-major [rows][K]
 // (kmajor 0) or [K][rows] (kmajor 1), cast / transposed into bf16 copies in `scratch`

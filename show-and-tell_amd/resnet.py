@@ -271,6 +271,25 @@ class ConvStackProgram:
         fuse_bn1 = training and dtype == L.SAT_BF16
         fuse_out_bn = (not training) and dtype == L.SAT_BF16
         self.stat_accs = []
+        # bf16 training: bn3 + residual add + ReLU in conv3's EPILOGUE, with bn3's batch statistics taken from the Gram matrix of
+        # conv3's input (csrc/sat_gram.hip: mean_c = w_c . mu, var_c = w_c^T cov(a2) w_c) -- the raw conv3 tensor and the
+        # normalise+add launch (42 % of the stack's memory traffic in round 4, at the HBM roof) never exist.  The kernels run
+        # non-projection bottlenecks with planes in {128, 256, 384, 512} (44 of ResNet-152's 50); MEASURED (round 5, interleaved on
+        # one box, profiles/r05_gram_ab.txt) it pays only where the normalise+add pass is large against the chain's four small
+        # launches: planes 128 (layer 2: +1 % on the step); at planes 256 (layer 3: 35 of the 44) the chain costs 30-45 us per
+        # bottleneck against the 19-37 us launch it removes and the step LOSES 9 % -- so the default fuses planes <= 128 only
+        # (SAT_GRAM_MAX_PLANES=512: every eligible bottleneck; SAT_GRAM_BN3=0: none, the three-launch form everywhere)
+        gram_bn3 = training and dtype == L.SAT_BF16 and os.environ.get("SAT_GRAM_BN3", "1") != "0"
+        gram_pmax = int(os.environ.get("SAT_GRAM_MAX_PLANES", "128"))
+        self.gram_blocks = 0
+        gram_geo = [(N * g_[2] * g_[3], g_[5]) for g_ in geo
+                    if g_[6] == 1 and g_[4] == g_[5] * 4 and g_[5] % 128 == 0 and g_[5] <= gram_pmax] if gram_bn3 else []
+        if gram_geo:
+            self.gram_slabs = alloc((G * max(lib.sat_gram_slab_floats(m_, p_) for m_, p_ in gram_geo),), torch.float32)
+            pmax = max(p_ for _, p_ in gram_geo)
+            self.gram_cov3 = alloc((G * 3 * pmax * pmax,), torch.bfloat16)
+            self.gram_mu = alloc((G * pmax,), torch.float64)
+            self.gram_T = alloc((G * 3 * max(p_ * p_ * 4 for _, p_ in gram_geo),), torch.float32)
 
         eval_items = []
 
@@ -442,6 +461,43 @@ class ConvStackProgram:
             f, s2, t2 = fin_op(blk.bn2, planes, N * h2 * w2, tm2)
             add(f)
             c3buf = ynext if inplace else self.c3
+            if (gram_bn3 and blk.downsample is None and stride == 1 and inpl == planes * 4 and planes % 128 == 0 and planes <= gram_pmax
+                    and bnref.get(s2.data_ptr()) is not None):
+                # bn3's batch statistics from the Gram matrix of conv3's input, then conv3 with bn3 + residual + ReLU in its epilogue
+                M3, P3, N3 = N * h2 * w2, planes, planes * 4
+                cv3 = fused_input_bn(std_conv(blk.conv3, self.c2, ynext, N, h2, w2, h2, w2), s2, t2)
+                gr = L.SatOp()
+                gr.kind, gr.dtype, gr.groups = L.OP_GRAM, dtype, G
+                gr.in0, gr.out = self.c2.data_ptr(), self.gram_slabs.data_ptr()
+                gr.N, gr.Hout, gr.Wout, gr.Cout = N, h2, w2, P3
+                acc2, bn2_, cnt2 = bnref[s2.data_ptr()]
+                gr.stat_acc1, gr.gamma1, gr.beta1 = acc2, bn2_.weight.data_ptr(), bn2_.bias.data_ptr()
+                gr.count, gr.eps = cnt2, BN_EPS
+                co = L.SatOp()
+                co.kind, co.dtype, co.groups = L.OP_GRAM_COV, dtype, G
+                co.in0, co.out, co.scale_out = self.gram_slabs.data_ptr(), self.gram_cov3.data_ptr(), self.gram_mu.data_ptr()
+                co.N, co.Hout, co.Wout, co.Cout = N, h2, w2, P3
+                gm = L.SatOp()
+                gm.kind, gm.dtype = L.OP_GEMM_BF16_NT, dtype
+                gm.in0, gm.w, gm.out = self.gram_cov3.data_ptr(), cv3.w, self.gram_T.data_ptr()
+                gm.N, gm.Hout, gm.Wout, gm.Cin, gm.Cout = G * 3 * P3, 1, 1, P3, N3
+                tab = alloc((G, 2, N3), torch.float32)
+                fb = L.SatOp()
+                fb.kind, fb.dtype, fb.groups = L.OP_BN_FROM_GRAM, dtype, G
+                fb.in0, fb.in1, fb.w, fb.scale_out = self.gram_T.data_ptr(), self.gram_mu.data_ptr(), cv3.w, tab.data_ptr()
+                fb.gamma, fb.beta = blk.bn3.weight.data_ptr(), blk.bn3.bias.data_ptr()
+                fb.running_mean, fb.running_var = blk.bn3.running_mean.data_ptr(), blk.bn3.running_var.data_ptr()
+                fb.Cin, fb.Cout, fb.count, fb.momentum, fb.eps = P3, N3, M3, BN_MOMENTUM, BN_EPS
+                cv3.scale1, cv3.shift1 = tab[0, 0].data_ptr(), tab[0, 1].data_ptr()
+                cv3.in1 = y.data_ptr()
+                cv3.flags = 1 | L.CONV_GROUP_TABLE
+                cv3.stat_partial, cv3.stat_acc = None, None       # no statistics of its own: bn3's came from its input
+                new_scale_shift(N3)                               # (keeps the BatchNorm numbering of the three-launch form)
+                self.bn_list.append(blk.bn3)
+                ops.extend([gr, co, gm, fb, cv3])
+                self.gram_blocks += 1
+                y, ynext = ynext, y
+                continue
             if fuse_in_bn and planes <= 512 and planes % 64 == 0:
                 # conv3 reads the RAW c2 and applies bn2 + ReLU to its A operand in LDS: a2 never exists in HBM
                 ops.append(fused_input_bn(std_conv(blk.conv3, self.c2, c3buf, N, h2, w2, h2, w2), s2, t2))
