@@ -615,7 +615,7 @@ int launch_glds(ConvArgs& a, int groups, hipStream_t s) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows).
 // LDS = S * (BM/8 + BN/8) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem, pw, aw; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel; pw: conv_pw_kernel; aw: conv_aw_kernel
+struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem, pw, aw, ap; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel; pw: conv_pw_kernel; aw: conv_aw_kernel
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128}, {128, 3, 8, 0, 0, 128}, {128, 2, 8, 0, 0, 128}, {64, 4, 8, 0, 0, 128}, {64, 3, 8, 0, 0, 128},
     {64, 2, 8, 0, 0, 128}, {128, 4, 4, 0, 0, 128}, {128, 2, 4, 0, 0, 128}, {64, 3, 4, 0, 0, 128}, {64, 2, 4, 0, 0, 128},
@@ -630,6 +630,7 @@ constexpr Variant kVariants[] = {
     {128, 1, 4, 0, 0, 128, 0, 0, 0, 1},                                                                                  // LDS-resident input patch + weights straight into registers from the fragment-ordered copy (3x3 / stride 1, sat_conv_pw.inc)
     {128, 3, 4, 0, 0, 128, 0, 0, 0, 0, 1},                                                                               // 1x1: activations through registers into LDS, weights straight into registers (sat_conv_aw.inc)
     {256, 3, 8, 0, 0, 128, 0, 0, 0, 0, 2},                                                                               // ... eight waves, 256-column tiles: the activations staged once per row tile
+    {128, 2, 4, 0, 0, 128, 0, 0, 0, 0, 0, 1},                                                                            // expansion 1x1 (K = 256): weights resident in registers, the workgroup persistent over row tiles (sat_conv_ap.inc)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
@@ -639,6 +640,7 @@ constexpr int kVariantPr = 29;
 #include "sat_conv_stem.inc"
 #include "sat_conv_pw.inc"
 #include "sat_conv_aw.inc"
+#include "sat_conv_ap.inc"
 
 int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
     switch (v) {
@@ -676,6 +678,7 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 31: return launch_pw(a, groups, s);
         case 32: return launch_aw<4>(a, groups, s);
         case 33: return launch_aw<8>(a, groups, s);
+        case 34: return launch_ap(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -692,6 +695,7 @@ bool signature_matches(int v, int want);
 
 int stat_signature(int v) {
     const Variant& k = kVariants[v];
+    if (k.ap) return 6000;          // (a lane's 64 rows of a tile, the tiles of a worker in order, then the two halves)
     if (k.aw) return 5000;          // (a lane's 64 rows, then the two halves: the same for the four- and the eight-wave form)
     if (k.pw) return 4000;
     if (k.stem) return 3000;
@@ -749,6 +753,7 @@ int op_groups(const sat_op* op) { return op->groups > 1 ? op->groups : 1; }
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
+    if (k.ap) return ap_ok(a);
     if (k.aw) return aw_ok(a, k.aw == 2 ? 8 : 4);
     if (k.pw) return pw_ok(a);
     if (k.stem) return stem_ok(a);

@@ -92,6 +92,7 @@ def stall_worker(rank, world, port, out):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     feats, caps = make_batch()
+    torch.manual_seed(77)                          # (the encoder head is random-initialised: the same on both ranks, like a broadcast)
     model = make_model(sat)
     ts = sat.TrainStep(model)
     dp = sat.DataParallelStep(ts)
@@ -117,11 +118,12 @@ def stall_worker(rank, world, port, out):
     log["unchanged"] = all(torch.equal(a, b) for a, b in zip(before, (ts.flat.params, ts.flat.m, ts.flat.v)))
     log["count_ok"] = ts.step_count == count
     # training goes on (per-step launches now), the replicas stay bit-identical
-    for i in range(2):
-        dp.step((f, c, ln), tokens)
+    log["before"] = before[0].cpu()
+    log["losses_after"] = [float(dp.step((f, c, ln), tokens).item()) for _ in range(2)]
     ts.check_ids()
     log["count_after"] = ts.step_count - count
     log["params"] = ts.flat.params.detach().cpu()
+    log["slices"] = dict(ts.flat.slices)
     torch.save(log, out + ".%d" % rank)
     dist.barrier()
     dist.destroy_process_group()
@@ -149,7 +151,10 @@ def test_a_fault_on_one_rank_is_handled_identically_on_every_rank(tmp_path):
     for r in (r0, r1):
         assert "SKIPPED on the device" in r["msg"] and "running statistics" in r["msg"]
         assert r["unchanged"] and r["count_ok"] and r["count_after"] == 2
-    assert torch.equal(r0["params"], r1["params"])
+    assert torch.equal(r0["before"], r1["before"])                # replicas were bit-identical going in ...
+    assert r0["losses_after"] == r1["losses_after"]
+    diff = {k: (r0["params"][o:o + n] - r1["params"][o:o + n]).abs().max().item() for k, (o, n, _) in r0["slices"].items()}
+    assert torch.equal(r0["params"], r1["params"]), diff         # ... and still are
 
 
 # ------------------------------------------------------------------------------------------------------
