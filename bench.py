@@ -558,7 +558,7 @@ def main():
     # (EncoderCNN.prefetch).  Warm-up leaves nothing in flight, so the timed region holds exactly K conv-stack passes and K
     # decoder passes: pipeline fill (step 1's stack runs alone, on the main stream) and drain are inside it.
     depth = model.encoder.lookahead_depth
-    groups = model.encoder.lookahead_groups if not wl["arch"] else 1          # batches per grouped program run (ResNet stacks)
+    groups = model.encoder.lookahead_groups                                    # batches per grouped program run
     n_streams = model.encoder.lookahead_streams or max(1, depth // groups)
     nb = depth + 1
     batches = [images] + [synth_batch(torch, wl["batch"], wl["vocab"], wl["cap_len"], wl["image"], dev, 977 * (k + 1) + rank)[0]

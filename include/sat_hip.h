@@ -307,16 +307,20 @@ int64_t sat_lstm_fwd_status_offset(int B, int H);
 int sat_lstm_persist_enable(int on);
 int64_t sat_lstm_bwd_ws_bytes(int B, int H);          /* minimum */
 /* size that also lets the batched dW_ih / dX GEMMs run split-K when they would leave most CUs idle (N = packed rows), and the
- * recurrence as ONE persistent launch.  INVARIANT of the full workspace: its granule-exchange region (a region of its own behind
- * the split-K slabs) is never cleared per call -- granules carry a per-call epoch tag -- so the CALLER ZEROES THE WORKSPACE ONCE
- * before its first use, hands the same buffer to later calls, and lets nobody else write into it; a fresh un-zeroed buffer per
- * call (arbitrary old bit patterns) could, after enough calls, be read as a valid hand-off.  (The library re-zeroes a known
- * buffer by itself when its 24-bit epoch counter wraps.) */
+ * recurrence as ONE persistent launch.  Layout (ABI 16): the granule-exchange region of the persistent recurrence and its status
+ * word come FIRST, at offsets that depend on (B, H) only; the N-dependent slabs follow.  So ONE buffer sized with
+ * sat_lstm_bwd_ws_bytes_max for the longest batch serves every call (any N <= n_max).  The exchange region is never cleared per
+ * call -- granules carry a per-call epoch tag -- and the invariant "no foreign bit pattern in it" is the LIBRARY's: it clears the
+ * region the first time it sees the buffer's address (and when its 24-bit epoch counter wraps) and remembers the address; an owner
+ * that frees the buffer (or reuses the memory for something else) says so with sat_lstm_ws_release.  The caller zeroes nothing. */
 int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H);
+int64_t sat_lstm_bwd_ws_bytes_max(int n_max, int B, int In, int H);
+int sat_lstm_ws_release(void* workspace);
 /* With the FULL workspace (and the forward's envelope: H in {32,...,512}, T <= 64, ceil(B/8) * H/16 <= CUs) the backward
  * recurrence runs as ONE persistent launch too (SAT_LSTM_PERSIST_BWD=0: one launch per step).  Its STATUS WORD (uint32) sits at
- * this byte offset of the workspace: zeroed by every such call, non-zero when a bounded wait of the persistent launch ran out --
- * DG and every gradient of that call are then INVALID; read it back behind the call as for sat_lstm_fwd_status_offset. */
+ * this byte offset of the workspace (a function of B and H only): zeroed by every such call, non-zero when a bounded wait of the
+ * persistent launch ran out -- DG and every gradient of that call are then INVALID; read it back behind the call as for
+ * sat_lstm_fwd_status_offset. */
 int64_t sat_lstm_bwd_status_offset(int N, int B, int In, int H);
 int sat_lstm_bwd(const float* dHS /*[N,H]*/, const float* X, const float* w_ih, const float* w_hh,
                  const float* GA, const float* CS, const float* HP,
@@ -499,6 +503,21 @@ int sat_beam_gather_rows(const float* src, const int32_t* parent, int B, int K, 
                          sat_stream_t stream);
 int sat_beam_backtrack(const int32_t* parents, const int64_t* tokens, int T, int B, int K, int64_t* ids,
                        sat_stream_t stream);
+/* The whole decode loop of one batch as ONE call -- the 20 steps of `DecoderRNN.sample` (models.py:56-67; eval.py:99) enqueued from
+ * C instead of step by step from the host language (round 4: seven launches per step through the FFI made the beam loop host-bound,
+ * 2.44 ms per 20 steps for ~1.3 ms of GPU work).  Same kernels, same order as the step entry points: bit-identical results.
+ * lstm_w: HOST array of 4 * num_layers device pointers (w_ih, w_hh, b_ih, b_hh per layer).
+ * sat_beam_decode: beam width K <= 8 (the reference's sample_beam is a stub, model2.py:113-114); end_id < 0: none.  ids [B][K][steps]
+ *   best first, scores [B][K] (nullable).  workspace: sat_beam_decode_ws_bytes, 256-byte aligned.
+ * sat_greedy_decode: h / c [num_layers][B][H] = the initial LSTM state in, the final one out (models.py:61 hands `states` to the
+ *   LSTM); h_tmp same size, x_tmp [B][E] scratch; ids [B][ids_stride], column i = step i; workspace: sat_vocab_argmax_ws_bytes. */
+int64_t sat_beam_decode_ws_bytes(int B, int K, int E, int H, int V, int num_layers, int steps);
+int sat_beam_decode(const float* features /*[B,E]*/, const float* embed /*[V,E]*/, const float* const* lstm_w /*[host]*/, int num_layers,
+                    const float* lin_w /*[V,H]*/, const float* lin_b, int B, int K, int E, int H, int V, int steps, int64_t end_id,
+                    int64_t* ids, float* scores, void* workspace, int64_t ws_bytes, sat_stream_t stream);
+int sat_greedy_decode(const float* features, const float* embed, const float* const* lstm_w /*[host]*/, int num_layers,
+                      const float* lin_w, const float* lin_b, int B, int E, int H, int V, int steps, float* h, float* c, float* h_tmp,
+                      float* x_tmp, int64_t* ids, int64_t ids_stride, float* workspace, int64_t ws_bytes, sat_stream_t stream);
 /* The truncation rule of the reference's id -> word loop (`evaluation`, eval.py:103-109: `if word == '<end>': break`):
  * kept[b] = number of ids of row b in front of the first end_id (T when the row has none).  ids: [B] rows of T int64 with
  * `stride` elements between rows (model.sample's [B,20], or one hypothesis plane of the beam ids). */

@@ -99,6 +99,8 @@ SIGNATURES = {
     "sat_lstm_bwd_ws_bytes": (_i64, [_i, _i]),
     "sat_lstm_bwd_ws_bytes_full": (_i64, [_i, _i, _i, _i]),
     "sat_lstm_bwd_status_offset": (_i64, [_i, _i, _i, _i]),
+    "sat_lstm_bwd_ws_bytes_max": (_i64, [_i, _i, _i, _i]),
+    "sat_lstm_ws_release": (_i, [_vp]),
     "sat_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_vocab_logits_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
@@ -141,6 +143,9 @@ SIGNATURES = {
     "sat_beam_gather_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_beam_backtrack": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sat_kept_tokens": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp]),
+    "sat_beam_decode_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i, _i]),
+    "sat_beam_decode": (_i, [_vp, _vp, C.POINTER(_vp), _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "sat_greedy_decode": (_i, [_vp, _vp, C.POINTER(_vp), _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "sat_clamp_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp]),
     "sat_clamp_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "sat_step_fault_flag": (_i, [C.POINTER(_vp), _i, _vp, _vp, _vp]),

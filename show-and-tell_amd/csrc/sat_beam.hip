@@ -18,14 +18,15 @@ constexpr int RC = 12;    // 16-byte chunks of a logits row a thread keeps in re
 // a better than b: higher score, ties -> lower flat candidate index (k*V + v)
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
 
-__device__ __forceinline__ float block_reduce256(float v, bool is_max, float* sh) {
+template <int NT>
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
     v = is_max ? wave_max(v) : wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     float r = sh[0];
 #pragma unroll
-    for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+    for (int i = 1; i < NT / 64; ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];      // wave order: fixed
     return r;
 }
 
@@ -48,13 +49,20 @@ __device__ __forceinline__ void list_insert(float (&val)[KMAX], int (&idx)[KMAX]
     }
 }
 
-__global__ __launch_bounds__(256) void beam_row_kernel(const float* __restrict__ logits, long ldl,
-                                                       const float* __restrict__ scores_in,
-                                                       const int64_t* __restrict__ last_tok, long end_id, int K, int V,
-                                                       float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    __shared__ float sh[4];
-    __shared__ float s_rv[4];
-    __shared__ int s_ri[4];
+// One workgroup of NT threads per (image, hypothesis) row.  Round 5: the selection no longer keeps a sorted top-K list per thread
+// (an insert per element that beats the list's tail: 11 k instructions per wave at V = 10 000, the kernel was instruction-bound at
+// 33 us per 320 rows).  Now: a thread keeps only its single best candidate; K rounds of block arg-best; the wave that owned the
+// winner strikes it out and finds its threads' next best -- the other waves skip that.  Exactly the same result: the K best
+// candidates of the row under (score desc, flat index asc).
+template <int NT>
+__global__ __launch_bounds__(NT) void beam_row_kernel(const float* __restrict__ logits, long ldl,
+                                                      const float* __restrict__ scores_in,
+                                                      const int64_t* __restrict__ last_tok, long end_id, int K, int V,
+                                                      float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+    constexpr int NW = NT / 64, RCN = RC * 256 / NT;          // waves; 16-byte chunks of the row a thread keeps in registers
+    __shared__ float sh[NW];
+    __shared__ float s_rv[NW];
+    __shared__ int s_ri[NW];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int k = row % K;
     const float base = scores_in[row];
@@ -71,7 +79,89 @@ __global__ __launch_bounds__(256) void beam_row_kernel(const float* __restrict__
         return;
     }
     const float* x = logits + (long)row * ldl;
-    // thread-local best KMAX continuations of this row
+    const int nq = V >> 2;                                   // whole 16-byte chunks (rows are 16-byte aligned: ldl % 4 == 0)
+    if ((ldl & 3) == 0 && nq <= RCN * NT) {
+        // the row lives in registers: ONE pass over memory (every load unconditional, chunk indexes past the row clamped and
+        // ignored below: a load under a runtime condition makes the compiler branch around each one and wait for it alone)
+        f32x4 rc[RCN];
+#pragma unroll
+        for (int c = 0; c < RCN; ++c) {
+            const int q = tid + c * NT;
+            rc[c] = *(const f32x4*)(x + 4 * (q < nq ? q : nq - 1));
+        }
+        const int tail = (nq << 2) + tid;                    // V % 4 leftover elements, one per thread
+        float xt = tail < V ? x[tail] : -INFINITY;
+#pragma unroll
+        for (int c = 0; c < RCN; ++c)
+            if (tid + c * NT >= nq) rc[c] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};       // (a select on the VALUE)
+        float m = xt;
+#pragma unroll
+        for (int c = 0; c < RCN; ++c) m = fmaxf(fmaxf(fmaxf(m, rc[c][0]), fmaxf(rc[c][1], rc[c][2])), rc[c][3]);
+        m = block_reduce<NT>(m, true, sh);
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < RCN; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += expf(rc[c][e] - m);       // exp(-inf) = 0 for the padding
+        }
+        s += expf(xt - m);
+        s = block_reduce<NT>(s, false, sh);
+        const float lse = m + logf(s);
+        // candidate scores in place (the f32 expression the step-by-step oracle rounds: base + (x - lse)); -inf stays -inf
+#pragma unroll
+        for (int c = 0; c < RCN; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rc[c][e] = base + (rc[c][e] - lse);
+        xt = base + (xt - lse);
+        // this thread's best (elements in increasing index order, strict > keeps the lowest index among equals)
+        auto local_best = [&](float& bv, int& bi) {
+            bv = -INFINITY;
+            bi = INT_MAX;
+#pragma unroll
+            for (int c = 0; c < RCN; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rc[c][e] > bv) { bv = rc[c][e]; bi = k * V + 4 * (tid + c * NT) + e; }
+            if (xt > bv) { bv = xt; bi = k * V + tail; }
+        };
+        float mv;
+        int mi;
+        local_best(mv, mi);
+        for (int r = 0; r < K; ++r) {
+            float bv = mv;
+            int bi = mi;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) { s_rv[tid >> 6] = bv; s_ri[tid >> 6] = bi; }
+            __syncthreads();
+            bv = s_rv[0];
+            bi = s_ri[0];
+            int ww = 0;
+#pragma unroll
+            for (int w = 1; w < NW; ++w)
+                if (better(s_rv[w], s_ri[w], bv, bi)) { bv = s_rv[w]; bi = s_ri[w]; ww = w; }
+            if (tid == 0) { cv_out[r] = bv; ci_out[r] = bi; }
+            if (ww == (tid >> 6) && bi != INT_MAX) {         // (wave-uniform) the winner's wave: its owner strikes it out, finds its next best
+                if (mi == bi) {
+                    const int el = bi - k * V;
+                    if (el == tail) xt = -INFINITY;
+#pragma unroll
+                    for (int c = 0; c < RCN; ++c)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (4 * (tid + c * NT) + e == el) rc[c][e] = -INFINITY;
+                    local_best(mv, mi);
+                }
+            }
+        }
+        return;
+    }
+    // rows too long for the registers: thread-local sorted lists over three passes
     float val[KMAX];
     int idx[KMAX];
 #pragma unroll
@@ -79,57 +169,15 @@ __global__ __launch_bounds__(256) void beam_row_kernel(const float* __restrict__
         val[j] = -INFINITY;
         idx[j] = INT_MAX;
     }
-    const int nq = V >> 2;                                   // whole 16-byte chunks (rows are 16-byte aligned: ldl % 4 == 0)
-    if ((ldl & 3) == 0 && nq <= RC * 256) {
-        // the row lives in registers: ONE pass over memory, then max, sum and selection from registers.
-        // A thread's elements are visited in increasing index order (chunk tid, tid+256, ...; tail last).
-        f32x4 rc[RC];
-#pragma unroll
-        for (int c = 0; c < RC; ++c) {
-            const int q = tid + c * 256;
-            if (q < nq) rc[c] = *(const f32x4*)(x + 4 * q);
-        }
-        const int tail = (nq << 2) + tid;                    // V % 4 leftover elements, one per thread
-        const float xt = tail < V ? x[tail] : -INFINITY;
-        float m = xt;
-#pragma unroll
-        for (int c = 0; c < RC; ++c)
-            if (tid + c * 256 < nq) m = fmaxf(fmaxf(fmaxf(m, rc[c][0]), fmaxf(rc[c][1], rc[c][2])), rc[c][3]);
-        m = block_reduce256(m, true, sh);
-        float s = 0.0f;
-#pragma unroll
-        for (int c = 0; c < RC; ++c)
-            if (tid + c * 256 < nq) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s += expf(rc[c][e] - m);
-            }
-        if (tail < V) s += expf(xt - m);
-        s = block_reduce256(s, false, sh);
-        const float lse = m + logf(s);
-#pragma unroll
-        for (int c = 0; c < RC; ++c) {
-            const int q = tid + c * 256;
-            if (q < nq) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float cv = base + (rc[c][e] - lse);
-                    if (cv > val[KMAX - 1]) list_insert(val, idx, cv, k * V + 4 * q + e);
-                }
-            }
-        }
-        if (tail < V) {
-            const float cv = base + (xt - lse);
-            if (cv > val[KMAX - 1]) list_insert(val, idx, cv, k * V + tail);
-        }
-    } else {
+    {
         float m = -INFINITY;
-        for (int i = tid; i < V; i += 256) m = fmaxf(m, x[i]);
-        m = block_reduce256(m, true, sh);
+        for (int i = tid; i < V; i += NT) m = fmaxf(m, x[i]);
+        m = block_reduce<NT>(m, true, sh);
         float s = 0.0f;
-        for (int i = tid; i < V; i += 256) s += expf(x[i] - m);
-        s = block_reduce256(s, false, sh);
+        for (int i = tid; i < V; i += NT) s += expf(x[i] - m);
+        s = block_reduce<NT>(s, false, sh);
         const float lse = m + logf(s);
-        for (int i = tid; i < V; i += 256) {
+        for (int i = tid; i < V; i += NT) {
             const float cv = base + (x[i] - lse);
             if (cv > val[KMAX - 1]) list_insert(val, idx, cv, k * V + i);
         }
@@ -156,7 +204,7 @@ __global__ __launch_bounds__(256) void beam_row_kernel(const float* __restrict__
         bv = s_rv[0];
         bi = s_ri[0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < NW; ++w)
             if (better(s_rv[w], s_ri[w], bv, bi)) {
                 bv = s_rv[w];
                 bi = s_ri[w];
@@ -179,7 +227,8 @@ __global__ __launch_bounds__(256) void beam_row_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                         int K, int V, int* __restrict__ parent,
-                                                        int64_t* __restrict__ token, float* __restrict__ scores_out) {
+                                                        int64_t* __restrict__ token, float* __restrict__ scores_out,
+                                                        const float* __restrict__ embed, int E, float* __restrict__ x_next, long ldx) {
     const int b = blockIdx.x, lane = threadIdx.x;
     float v = -INFINITY;
     int ix = INT_MAX;
@@ -203,12 +252,70 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
             v = -INFINITY;
             ix = INT_MAX;
         }
+        const bool ok = bi != INT_MAX;                 // (bv, bi) are the same in every lane after the reduction
         if (lane == 0) {
-            const bool ok = bi != INT_MAX;
             parent[b * K + r] = ok ? bi / V : 0;
             token[b * K + r] = ok ? bi % V : 0;
             scores_out[b * K + r] = ok ? bv : -INFINITY;
         }
+        if (embed) {                                   // the next step's input row: embed(token) (models.py:64), by the whole wave
+            const float* src = embed + (long)(ok ? bi % V : 0) * E;
+            float* dst = x_next + (long)(b * K + r) * ldx;
+            for (int e = lane * 4; e < E; e += 256) *(f32x4*)(dst + e) = *(const f32x4*)(src + e);
+        }
+    }
+}
+
+// x0 row (b, k) = features[b]; scores: hypothesis 0 of every image live at 0, the others dead
+__global__ __launch_bounds__(256) void beam_init_kernel(const float* __restrict__ features, int K, int E, long total,
+                                                        float* __restrict__ x0, long ldx, float* __restrict__ scores, int R) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / E;
+        x0[row * ldx + (i - row * E)] = features[(row / K) * E + (i - row * E)];
+    }
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < R) scores[t] = (t % K) == 0 ? 0.0f : -INFINITY;
+}
+
+// the (h, c) rows of one layer re-ordered by parent in ONE launch: dst row (b, k) = src row (b, parent[b, k])
+__global__ __launch_bounds__(256) void beam_gather2_kernel(const float* __restrict__ h_src, const float* __restrict__ c_src,
+                                                           const int* __restrict__ parent, int K, int W, long total,
+                                                           float* __restrict__ h_dst, long ldh, float* __restrict__ c_dst) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < 2 * total; i += (long)gridDim.x * 256) {
+        const bool second = i >= total;
+        const long j = second ? i - total : i;
+        const long row = j / W;
+        const int col = (int)(j - row * W);
+        const long b = row / K;
+        const long from = (b * K + parent[row]) * W + col;
+        if (second) c_dst[j] = c_src[from];
+        else h_dst[row * ldh + col] = h_src[from];
+    }
+}
+
+// wide decode steps (many rows, one LSTM layer): W_cat [4H][In + H] = [W_ih | W_hh], so that the step's gates are ONE GEMM over the
+// concatenated input row [x | h]
+__global__ __launch_bounds__(256) void beam_wcat_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, int In, int H,
+                                                        long total, float* __restrict__ wcat) {
+    const int ld = In + H;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / ld;
+        const int col = (int)(i - row * ld);
+        wcat[i] = col < In ? w_ih[row * In + col] : w_hh[row * H + (col - In)];
+    }
+}
+
+// gates [R][4H] (i, f, g, o pre-activations, both biases in) -> c (in place), h_new: the LSTM cell's pointwise half (models.py:52)
+__global__ __launch_bounds__(256) void beam_lstm_point_kernel(const float* __restrict__ gates, float* __restrict__ c,
+                                                              float* __restrict__ h_new, int H, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / H;
+        const int u = (int)(i - row * H);
+        const float* g = gates + row * 4 * H;
+        const float gi = sat_sigmoid(g[u]), gf = sat_sigmoid(g[H + u]), gg = sat_tanh(g[2 * H + u]), go = sat_sigmoid(g[3 * H + u]);
+        const float cn = gf * c[i] + gi * gg;
+        c[i] = cn;
+        h_new[i] = go * sat_tanh(cn);
     }
 }
 
@@ -271,11 +378,165 @@ extern "C" int sat_beam_step(const float* logits, int64_t ldl, const float* scor
     float* cand_val = (float*)workspace;                       // [B*K rows][K]
     int* cand_idx = (int*)(cand_val + (long)B * K * K);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(beam_row_kernel, dim3(B * K), dim3(256), 0, s, logits, (long)ldl, scores_in, last_tokens,
+    hipLaunchKernelGGL(beam_row_kernel<256>, dim3(B * K), dim3(256), 0, s, logits, (long)ldl, scores_in, last_tokens,
                        (long)end_id, K, V, cand_val, cand_idx);
     SAT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, s, cand_val, cand_idx, K, V, parent, token, scores_out);
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, s, cand_val, cand_idx, K, V, parent, token, scores_out,
+                       (const float*)nullptr, 0, (float*)nullptr, 0L);
     SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+// ---- the whole beam decode of one batch as ONE call (eval.py:99's `model.sample` loop, models.py:56-67, widened to a beam; the
+//      reference's own sample_beam is a stub, model2.py:113-114).  Round 4 drove the 20 steps from Python: seven launches per step
+//      through ctypes, 2.44 ms per 20 steps of which the GPU was busy ~1.3 ms -- the loop was host-bound.  Here the host enqueues
+//      5 launches per step (one LSTM layer) from C with no Python in between: LSTM step, exact-f32 vocab projection, per-row
+//      log-softmax + top-K, per-image merge (which also gathers the next step's embedding rows), ONE (h, c) re-ordering launch per
+//      layer.  Same kernels, same order, same arithmetic as the step-by-step entry points: bit-identical ids and scores. ----
+static int64_t al256(int64_t n) { return (n + 255) / 256 * 256; }
+
+extern "C" int64_t sat_beam_decode_ws_bytes(int B, int K, int E, int H, int V, int num_layers, int steps) {
+    if (B <= 0 || K <= 0 || K > KMAX || E <= 0 || H <= 0 || V <= 0 || num_layers < 1 || steps < 1) return 0;
+    const int64_t R = (int64_t)B * K, ldl = (V + 3) / 4 * 4;
+    // (+ the wide path's buffers: two [R][E + H] input rows, W_cat [4H][E + H], gates [R][4H])
+    return al256(4 * (int64_t)num_layers * R * H * 4) + al256(R * ldl * 4) + 2 * al256(R * 4) + al256(sat_beam_step_ws_bytes(B, K)) +
+           al256((int64_t)steps * R * 4) + al256((int64_t)steps * R * 8) + 2 * al256(R * E * 4) +
+           2 * al256(R * (int64_t)(E + H) * 4) + al256(4 * (int64_t)H * (E + H) * 4) + al256(R * 4 * (int64_t)H * 4);
+}
+
+extern "C" int sat_beam_decode(const float* features, const float* embed, const float* const* lstm_w, int num_layers,
+                               const float* lin_w, const float* lin_b, int B, int K, int E, int H, int V, int steps,
+                               int64_t end_id, int64_t* ids, float* scores_out, void* workspace, int64_t ws_bytes,
+                               sat_stream_t stream) {
+    if (!features || !embed || !lstm_w || !lin_w || !lin_b || !ids || !workspace) return SAT_ERR_ARG;
+    const int64_t need = sat_beam_decode_ws_bytes(B, K, E, H, V, num_layers, steps);
+    if (need <= 0) return SAT_ERR_ARG;
+    if ((E & 3) || (long)K * V > INT_MAX - 1) return SAT_ERR_UNSUPPORTED;
+    if (ws_bytes < need || (((uintptr_t)workspace) & 255)) return SAT_ERR_WORKSPACE;
+    for (int i = 0; i < 4 * num_layers; ++i)
+        if (!lstm_w[i]) return SAT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t R = (int64_t)B * K, ldl = (V + 3) / 4 * 4;
+    char* w = (char*)workspace;
+    float* hc = (float*)w;                                     // [layer][h0, h1, c0, c1][R][H]
+    w += al256(4 * (int64_t)num_layers * R * H * 4);
+    float* logits = (float*)w; w += al256(R * ldl * 4);
+    float* sc[2];
+    sc[0] = (float*)w; w += al256(R * 4);
+    sc[1] = (float*)w; w += al256(R * 4);
+    void* cand = w; w += al256(sat_beam_step_ws_bytes(B, K));
+    int32_t* parents = (int32_t*)w; w += al256((int64_t)steps * R * 4);
+    int64_t* tokens = (int64_t*)w; w += al256((int64_t)steps * R * 8);
+    float* x0 = (float*)w; w += al256(R * E * 4);
+    float* xe = (float*)w; w += al256(R * E * 4);
+    float* xh[2];
+    xh[0] = (float*)w; w += al256(R * (int64_t)(E + H) * 4);
+    xh[1] = (float*)w; w += al256(R * (int64_t)(E + H) * 4);
+    float* wcat = (float*)w; w += al256(4 * (int64_t)H * (E + H) * 4);
+    float* gates = (float*)w;
+    hipError_t e = hipMemsetAsync(hc, 0, (size_t)(4 * (int64_t)num_layers * R * H * 4), s);      // h = c = 0
+    if (e != hipSuccess) return (int)e;
+    // WIDE steps (round 5): with one LSTM layer and >= 128 rows the step's gates are ONE LDS-tiled exact-f32 MFMA GEMM over the
+    // concatenated row [x | h] (sat_gemm_f32: ~0.5 of the f32 peak) + a pointwise launch, instead of the few-rows kernel, which
+    // re-reads the 6 MB of weights once per 64-row chunk (34 -> ~17 us per step at 320 rows)
+    const bool wide = num_layers == 1 && R >= 128 && !(H & 3);
+    const long ldx = E + H;
+    if (wide) {
+        e = hipMemsetAsync(xh[0], 0, (size_t)(R * ldx * 4), s);                                  // h_{-1} = 0
+        if (e != hipSuccess) return (int)e;
+        const long total = 4L * H * ldx;
+        int grid = sat_cdiv(total, 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(beam_wcat_kernel, dim3(grid), dim3(256), 0, s, lstm_w[0], lstm_w[1], E, H, total, wcat);
+        SAT_LAUNCH_CHECK();
+    }
+    if (ldl > V) {                                             // pad columns of the logits rows: read by nobody, but keep them defined
+        e = hipMemsetAsync(logits, 0, (size_t)(R * ldl * 4), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    {
+        const long total = R * E;                              // (>= R: the scores, one per thread, are covered by the same grid)
+        int grid = sat_cdiv(total, 256);
+        if (grid > 2048) grid = 2048;
+        if ((long)grid * 256 < R) grid = sat_cdiv(R, 256);
+        hipLaunchKernelGGL(beam_init_kernel, dim3(grid), dim3(256), 0, s, features, K, E, total, wide ? xh[0] : x0, wide ? ldx : (long)E,
+                           sc[0], (int)R);
+        SAT_LAUNCH_CHECK();
+    }
+    float* cand_val = (float*)cand;
+    int* cand_idx = (int*)(cand_val + (long)B * K * K);
+    int cur_h[8] = {0}, cur_c[8] = {0};                        // which of the two buffers holds a layer's live h / c
+    if (num_layers > 8) return SAT_ERR_UNSUPPORTED;
+    const float* x = x0;
+    int si = 0, xi = 0;
+    for (int i = 0; i < steps; ++i) {
+        const float* inp = x;
+        if (wide) {
+            float* c = hc + (long)(2 + cur_c[0]) * R * H;
+            float* h_new = hc + (long)cur_h[0] * R * H;
+            SAT_TRY(sat_gemm_f32(0, 0, xh[xi], ldx, wcat, ldx, gates, 4L * H, lstm_w[2], lstm_w[3], (int)R, 4 * H, (int)ldx, stream));
+            {
+                const long total = R * H;
+                int grid = sat_cdiv(total, 256);
+                if (grid > 2048) grid = 2048;
+                hipLaunchKernelGGL(beam_lstm_point_kernel, dim3(grid), dim3(256), 0, s, gates, c, h_new, H, total);
+                SAT_LAUNCH_CHECK();
+            }
+            inp = h_new;
+        }
+        for (int l = 0; l < num_layers && !wide; ++l) {
+            float* base = hc + (long)l * 4 * R * H;
+            float* h_in = base + (long)cur_h[l] * R * H;
+            float* h_out = base + (long)(1 - cur_h[l]) * R * H;
+            float* c = base + (long)(2 + cur_c[l]) * R * H;
+            const int In = l == 0 ? E : H;
+            SAT_TRY(sat_lstm_step(inp, h_in, c, lstm_w[4 * l], lstm_w[4 * l + 1], lstm_w[4 * l + 2], lstm_w[4 * l + 3], (int)R, In, H,
+                                  h_out, stream));
+            cur_h[l] = 1 - cur_h[l];
+            inp = h_out;
+        }
+        SAT_TRY(sat_vocab_logits_fwd(inp, lin_w, lin_b, (int)R, H, V, logits, ldl, stream));
+        int32_t* par = parents + (long)i * R;
+        int64_t* tok = tokens + (long)i * R;
+        const int64_t* last = (i > 0 && end_id >= 0) ? tok - R : (const int64_t*)nullptr;
+        hipLaunchKernelGGL(beam_row_kernel<256>, dim3((unsigned)R), dim3(256), 0, s, logits, (long)ldl, sc[si], last, (long)end_id, K, V,
+                           cand_val, cand_idx);
+        SAT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, s, cand_val, cand_idx, K, V, par, tok, sc[1 - si], embed, E,
+                           wide ? xh[1 - xi] : xe, wide ? ldx : (long)E);
+        SAT_LAUNCH_CHECK();
+        si = 1 - si;
+        if (wide) {                                            // (h, c) by parent: h straight into the next input row's h half
+            const long total = R * H;
+            int grid = sat_cdiv(2 * total, 256);
+            if (grid > 2048) grid = 2048;
+            hipLaunchKernelGGL(beam_gather2_kernel, dim3(grid), dim3(256), 0, s, hc + (long)cur_h[0] * R * H, hc + (long)(2 + cur_c[0]) * R * H,
+                               par, K, H, total, xh[1 - xi] + E, ldx, hc + (long)(2 + 1 - cur_c[0]) * R * H);
+            SAT_LAUNCH_CHECK();
+            cur_c[0] = 1 - cur_c[0];
+            xi = 1 - xi;
+        } else if (K > 1) {
+            for (int l = 0; l < num_layers; ++l) {
+                float* base = hc + (long)l * 4 * R * H;
+                const long total = R * H;
+                int grid = sat_cdiv(2 * total, 256);
+                if (grid > 2048) grid = 2048;
+                hipLaunchKernelGGL(beam_gather2_kernel, dim3(grid), dim3(256), 0, s, base + (long)cur_h[l] * R * H,
+                                   base + (long)(2 + cur_c[l]) * R * H, par, K, H, total, base + (long)(1 - cur_h[l]) * R * H, (long)H,
+                                   base + (long)(2 + 1 - cur_c[l]) * R * H);
+                SAT_LAUNCH_CHECK();
+                cur_h[l] = 1 - cur_h[l];
+                cur_c[l] = 1 - cur_c[l];
+            }
+        }
+        x = xe;
+    }
+    hipLaunchKernelGGL(beam_backtrack_kernel, dim3(sat_cdiv(R, 256)), dim3(256), 0, s, parents, tokens, steps, (int)R, K, ids);
+    SAT_LAUNCH_CHECK();
+    if (scores_out) {
+        e = hipMemcpyAsync(scores_out, sc[si], (size_t)(R * 4), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
     return SAT_OK;
 }
 
@@ -298,5 +559,39 @@ extern "C" int sat_beam_backtrack(const int32_t* parents, const int64_t* tokens,
     hipLaunchKernelGGL(beam_backtrack_kernel, dim3(sat_cdiv((long)B * K, 256)), dim3(256), 0, (hipStream_t)stream, parents,
                        tokens, T, B * K, K, ids);
     SAT_LAUNCH_CHECK();
+    return SAT_OK;
+}
+
+// ---- greedy decode (models.py:56-67 `DecoderRNN.sample`) as ONE call: steps x (LSTM step per layer, vocab projection + arg-max,
+//      embedding row of the chosen id), enqueued from C.  h / c: [num_layers][B][H] initial state IN, final state OUT (updated in
+//      place; h_tmp: scratch of the same size).  ids [B][ids_stride] i64, column i = step i. ----
+extern "C" int sat_greedy_decode(const float* features, const float* embed, const float* const* lstm_w, int num_layers,
+                                 const float* lin_w, const float* lin_b, int B, int E, int H, int V, int steps, float* h, float* c,
+                                 float* h_tmp, float* x_tmp /*[B][E]*/, int64_t* ids, int64_t ids_stride, float* workspace,
+                                 int64_t ws_bytes, sat_stream_t stream) {
+    if (!features || !embed || !lstm_w || !lin_w || !lin_b || !h || !c || !h_tmp || !x_tmp || !ids || !workspace) return SAT_ERR_ARG;
+    if (B <= 0 || E <= 0 || H <= 0 || V <= 0 || num_layers < 1 || num_layers > 8 || steps < 1 || ids_stride < steps) return SAT_ERR_ARG;
+    if (ws_bytes < sat_vocab_argmax_ws_bytes(B, V)) return SAT_ERR_WORKSPACE;
+    float* hb[8][2];
+    for (int l = 0; l < num_layers; ++l) { hb[l][0] = h + (long)l * B * H; hb[l][1] = h_tmp + (long)l * B * H; }
+    int cur[8] = {0};
+    const float* x = features;
+    for (int i = 0; i < steps; ++i) {
+        const float* inp = x;
+        for (int l = 0; l < num_layers; ++l) {
+            SAT_TRY(sat_lstm_step(inp, hb[l][cur[l]], c + (long)l * B * H, lstm_w[4 * l], lstm_w[4 * l + 1], lstm_w[4 * l + 2],
+                                  lstm_w[4 * l + 3], B, l == 0 ? E : H, H, hb[l][1 - cur[l]], stream));
+            cur[l] = 1 - cur[l];
+            inp = hb[l][cur[l]];
+        }
+        SAT_TRY(sat_vocab_argmax(inp, lin_w, lin_b, B, H, V, ids + i, ids_stride, workspace, ws_bytes, stream));
+        SAT_TRY(sat_embed_rows(embed, ids + i, ids_stride, B, E, V, x_tmp, stream));
+        x = x_tmp;
+    }
+    for (int l = 0; l < num_layers; ++l)
+        if (cur[l]) {                                          // an odd number of steps: the live hidden state sits in the scratch
+            hipError_t e = hipMemcpyAsync(hb[l][0], hb[l][1], (size_t)B * H * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
     return SAT_OK;
 }

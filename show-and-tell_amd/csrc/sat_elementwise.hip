@@ -381,9 +381,13 @@ __global__ void bn_act_kernel(const T* in0, const T* __restrict__ in1, T* out,
 // out[pixel * ldo + c] = relu(in[pixel * C + c] * s[c] + t[c]): the activation of a conv lands in a channel slice of a wider
 // (concatenated) NHWC tensor -- Inception blocks (BASELINE configs[3]).  One thread per 16-byte chunk.
 template <typename T>
-__global__ void bn_relu_strided_kernel(const T* __restrict__ in, T* __restrict__ out, long ldo, const BnSrc b, double count,
+__global__ void bn_relu_strided_kernel(const T* __restrict__ in, T* __restrict__ out, long ldo, const BnSrc b_, double count,
                                        float momentum, float eps, long npix, int C) {
     constexpr int V = Vec<T>::N;
+    const long grp = blockIdx.y;                             // grouped program: npix = the pixels of ONE group's batch
+    in += grp * npix * C;
+    out += grp * npix * ldo;
+    const BnSrc b = bn_group(b_, grp, C);
     extern __shared__ __attribute__((aligned(16))) float tab[];
     const float* s = b.scale;
     const float* t = b.shift;
@@ -1084,7 +1088,9 @@ static int bn_relu_strided_launch_t(const sat_op* op, int parity, hipStream_t s)
     const long npix = (long)op->N * op->Hout * op->Wout;
     int grid = ew_grid(npix * (C / V));
     if (lds && grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(bn_relu_strided_kernel<T>, dim3(grid), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (T*)op->out, (long)op->ldc, b,
+    const int groups = op->groups > 1 ? op->groups : 1;
+    if (groups > 1 && (!op->stat_acc || (b.running_mean && b.running_var != b.running_mean + C))) return SAT_ERR_ARG;
+    hipLaunchKernelGGL(bn_relu_strided_kernel<T>, dim3(grid, groups), dim3(EW_BLOCK), lds, s, (const T*)op->in0, (T*)op->out, (long)op->ldc, b,
                        (double)op->count, op->momentum, op->eps, npix, C);
     SAT_LAUNCH_CHECK();
     return SAT_OK;

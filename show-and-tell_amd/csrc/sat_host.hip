@@ -305,7 +305,18 @@ static int fill_split(long M, long Nn, long K) {
     return (int)(ks < 1 ? 1 : (ks > 8 ? 8 : ks));
 }
 
-static int64_t lstm_bwd_exchange_offset(int N, int B, int In, int H) {
+// Layout of the FULL backward workspace (round 5: the exchange FIRST, at offsets that depend on (B, H) only, so that one buffer
+// sized for the longest batch serves every N -- with real captions N changes almost every step):
+//   [0, xb - 64)      granule exchange of the persistent backward recurrence: a region of its own, nothing else writes there;
+//   [xb - 64, xb)     the recurrence's status word          (xb = sat_lstm_persist_bwd_ws_bytes(B, H))
+//   [head, head + m)  dh_part / dc_state of the per-step form, then the split-K slabs of the batched GEMMs (m depends on N)
+// (an H the persistent recurrence does not run has no exchange: the head is then the status word alone)
+static int64_t lstm_bwd_xb(int B, int H) {
+    const int64_t xb = sat_lstm_persist_bwd_ws_bytes(B, H);
+    return xb >= 64 ? xb : 64;
+}
+static int64_t lstm_bwd_head_bytes(int B, int H) { return (lstm_bwd_xb(B, H) + 255) / 256 * 256; }
+static int64_t lstm_bwd_slab_bytes(int N, int B, int In, int H) {
     const int64_t base = sat_lstm_bwd_ws_bytes(B, H);
     const int64_t dx = (int64_t)fill_split(N, In, 4L * H) * N * In * sizeof(float);
     const int64_t dw = (int64_t)fill_split(4L * H, In, N) * 4 * H * In * sizeof(float);
@@ -315,24 +326,28 @@ static int64_t lstm_bwd_exchange_offset(int N, int B, int In, int H) {
 }
 
 // workspace that additionally lets sat_lstm_bwd run its under-filled weight/input-gradient GEMMs split-K and its recurrence as
-// ONE persistent launch.  The caller ZEROES it once before its first use and hands the SAME buffer to later calls (or zeroes a
-// new one): the exchange region carries per-call epoch tags instead of being cleared per call.
+// ONE persistent launch, for exactly N packed rows ...
 extern "C" int64_t sat_lstm_bwd_ws_bytes_full(int N, int B, int In, int H) {
-    const int64_t base = sat_lstm_bwd_ws_bytes(B, H);
-    const int64_t dx = (int64_t)fill_split(N, In, 4L * H) * N * In * sizeof(float);
-    const int64_t dw = (int64_t)fill_split(4L * H, In, N) * 4 * H * In * sizeof(float);
-    int64_t m = dx > dw ? dx : dw;
-    if (base > m) m = base;
-    // [0, m): dh_part / dc_state of the per-step form, then the split-K slabs of the batched GEMMs;
-    // [align(m), + exchange): the granule exchange of the persistent backward recurrence, a region of ITS OWN -- nothing else
-    // writes there (its tags must never meet foreign bit patterns: ADVICE r3); last 64 bytes: the recurrence's status word
-    return lstm_bwd_exchange_offset(N, B, In, H) + (sat_lstm_persist_bwd_ws_bytes(B, H) + 255) / 256 * 256 + 64;
+    return lstm_bwd_head_bytes(B, H) + lstm_bwd_slab_bytes(N, B, In, H);
+}
+// ... and for ANY N <= n_max (split-K factors are not monotonic in N: the bound takes the largest factor): size the buffer once with
+// this, hand it to every call
+extern "C" int64_t sat_lstm_bwd_ws_bytes_max(int n_max, int B, int In, int H) {
+    int64_t m = sat_lstm_bwd_ws_bytes(B, H);
+    const int64_t dx = 8LL * n_max * In * sizeof(float), dw = 8LL * 4 * H * In * sizeof(float);
+    if (dx > m) m = dx;
+    if (dw > m) m = dw;
+    return lstm_bwd_head_bytes(B, H) + (m + 255) / 256 * 256;
 }
 
-// Byte offset of the backward recurrence's STATUS WORD (uint32) in a workspace of sat_lstm_bwd_ws_bytes_full bytes: zeroed by every
-// sat_lstm_bwd call that got the full workspace, set non-zero when the persistent backward recurrence gave up waiting for its
-// group (DG and every gradient of that call are then INVALID) -- read it back like sat_lstm_fwd_status_offset's word.
-extern "C" int64_t sat_lstm_bwd_status_offset(int N, int B, int In, int H) { return sat_lstm_bwd_ws_bytes_full(N, B, In, H) - 64; }
+// Byte offset of the backward recurrence's STATUS WORD (uint32) in the full workspace -- a function of (B, H) only (N and In are
+// kept in the signature for ABI stability): zeroed by every sat_lstm_bwd call that got the full workspace, set non-zero when the
+// persistent backward recurrence gave up waiting for its group (DG and every gradient of that call are then INVALID) -- read it back
+// like sat_lstm_fwd_status_offset's word.
+extern "C" int64_t sat_lstm_bwd_status_offset(int N, int B, int In, int H) {
+    (void)N; (void)In;
+    return lstm_bwd_xb(B, H) - 64;
+}
 
 static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, const float* w_hh, const float* GA,
                          const float* CS, const float* HP, const int32_t* batch_sizes, int T, int In, int H,
@@ -349,6 +364,10 @@ static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, co
     for (int t = 0; t < T; ++t) N += batch_sizes[t];
     const int nz = lstm_bwd_split(H);
     const long slab = (long)B * H;
+    const int64_t full = sat_lstm_bwd_ws_bytes_full((int)N, B, In, H);
+    const bool roomy = ws_bytes >= full;
+    char* const ws0 = (char*)workspace;
+    if (roomy) workspace = (float*)(ws0 + lstm_bwd_head_bytes(B, H));       // the slab region sits behind the exchange + status head
     float* dc_state = workspace + nz * slab; // [B][H]  (the nz slabs in front of it: room kept for the split-K GEMMs below)
     hipError_t e = hipMemsetAsync(dc_state, 0, (size_t)slab * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
@@ -356,13 +375,11 @@ static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, co
     // workgroup can be resident and the caller brought the full workspace (its last 64 bytes = the status word); otherwise one
     // launch per step
     static const int persist_bwd = getenv("SAT_LSTM_PERSIST_BWD") ? atoi(getenv("SAT_LSTM_PERSIST_BWD")) : 1;
-    const int64_t full = sat_lstm_bwd_ws_bytes_full((int)N, B, In, H);
     bool recurrence_done = false;
-    if (ws_bytes >= full) {
-        unsigned* status = (unsigned*)((char*)workspace + (full - 64));
+    if (roomy) {
+        unsigned* status = (unsigned*)(ws0 + sat_lstm_bwd_status_offset((int)N, B, In, H));
         if (persist_bwd && sat_lstm_persist_bwd_ws_bytes(B, H) > 0 && sat_lstm_persist_ok(B, H, T, device_cu_count())) {
-            SAT_TRY(sat_lstm_persist_bwd_launch(dHS, GA, CS, w_hh, DG, batch_sizes, T, H,
-                                                (char*)workspace + lstm_bwd_exchange_offset((int)N, B, In, H), status, s));
+            SAT_TRY(sat_lstm_persist_bwd_launch(dHS, GA, CS, w_hh, DG, batch_sizes, T, H, ws0, status, s));
             recurrence_done = true;
         } else {
             e = hipMemsetAsync(status, 0, 64, s);
@@ -392,7 +409,6 @@ static int lstm_bwd_impl(const float* dHS, const float* X, const float* w_ih, co
         if (dX) SAT_TRY(sat_gemm_mixed_nt(DG, 4L * H, 0, w_ih, In, 1, dX, In, nullptr, nullptr, (int)N, In, 4 * H, mixed, mixed_bytes, s));
         return SAT_OK;
     }
-    const bool roomy = ws_bytes >= sat_lstm_bwd_ws_bytes_full((int)N, B, In, H);
     const int ks_dw = roomy ? fill_split(4L * H, In, N) : 1;
     if (ks_dw > 1) {
         SAT_TRY(sat_gemm_f32_splitk(2, 1, DG, 4L * H, X, In, workspace, In, nullptr, nullptr, 4 * H, In, (int)N, ks_dw,

@@ -44,6 +44,8 @@ struct PersistArgs {
     unsigned* err;        // sticky timeout word (zeroed per call; the CALLER reads it back: sat_lstm_fwd_status_offset)
     unsigned spin_limit;  // sweeps a workgroup waits for its group before it gives up
     int dbg_stall;        // test build only (-DSAT_TESTHOOKS, SAT_LSTM_DEBUG_STALL=1): workgroup 0 never publishes -> its group times out; always 0 in the product library
+    int xcd_map;          // 1: group = blockIdx.x % groups, member = blockIdx.x / groups -- with 8 groups the members of a group have equal blockIdx.x % 8,
+                          // i.e. share an XCD under round-robin placement (speed only, never correctness; SAT_LSTM_XCD_MAP, measured: profiles/r05_lstm_ab.txt)
     int H, T, B, members;
     int prefix[kMaxT + 1];
 };
@@ -88,7 +90,9 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int group = blockIdx.x / p.members, member = blockIdx.x - group * p.members;
+    const int ngroups = gridDim.x / p.members;
+    const int group = p.xcd_map ? (int)(blockIdx.x % ngroups) : (int)(blockIdx.x / p.members);
+    const int member = p.xcd_map ? (int)(blockIdx.x / ngroups) : (int)(blockIdx.x - group * p.members);
     const int row0 = group * kRows;                   // first batch row of this group
     const int n16 = lane & 15, kg = lane >> 4;
     const int u0 = member * kUnits + wave * 4;        // this wave's 4 hidden units
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
                 w[1] = (unsigned)__shfl_down((int)w0, 1, 64);
                 w[2] = (unsigned)__shfl_down((int)w0, 2, 64);
                 w[3] = (unsigned)__shfl_down((int)w0, 3, 64);
-                if ((lane & 3) == 0 && t + 1 < p.T && !(p.dbg_stall && blockIdx.x == 0)) {
+                if ((lane & 3) == 0 && t + 1 < p.T && !(p.dbg_stall && group == 0 && member == 0)) {
                     const __amdgpu_buffer_rsrc_t dst = xch_rsrc((const char*)p.xch + ((long)(t & 1) * groups + group) * kSlab, kSlab);
                     store16_sc1(dst, (unsigned)(erow * H + u0) * 4u, w);
                 }
@@ -251,6 +255,7 @@ struct PersistBwdArgs {
     unsigned spin_limit;
     unsigned epoch;       // call counter: tags are epoch * 128 + step + 1, so granules of an earlier call never match (no 17 MB memset)
     int dbg_stall;
+    int xcd_map;
     int H, T, B, members;
     int prefix[kMaxT + 1];
 };
@@ -265,7 +270,9 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(const PersistBwdA
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int group = blockIdx.x / p.members, member = blockIdx.x - group * p.members;
+    const int ngroups = gridDim.x / p.members;
+    const int group = p.xcd_map ? (int)(blockIdx.x % ngroups) : (int)(blockIdx.x / p.members);
+    const int member = p.xcd_map ? (int)(blockIdx.x / ngroups) : (int)(blockIdx.x - group * p.members);
     const int row0 = group * kRows;
     const int n16 = lane & 15, kg = lane >> 4;
     const int u0 = member * kUnits;
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(const PersistBwdA
                     acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], wreg[kb][tl][e], acc[tl], 0, 0, 0);
         }
         // C/D map: col = lane & 15 (unit of the destination member), row = (lane >> 4) * 4 + reg: rows 0..7 sit in lanes kg < 2
-        if (kg < 2 && !(p.dbg_stall && blockIdx.x == 0)) {
+        if (kg < 2 && !(p.dbg_stall && group == 0 && member == 0)) {
             gu64* dst0 = xch + ((long)(t & 1) * groups + group) * slab;
             const unsigned long long tag = (unsigned long long)(p.epoch * 128u + (unsigned)(t + 1)) << 32;
 #pragma unroll
@@ -477,6 +484,8 @@ int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, flo
     const char* ds = getenv("SAT_LSTM_DEBUG_STALL");
     a.dbg_stall = (ds && ds[0] == '1') ? 1 : 0;
 #endif
+    static const int xcd_map = getenv("SAT_LSTM_XCD_MAP") ? atoi(getenv("SAT_LSTM_XCD_MAP")) & 1 : 0;      // (bit 0: forward, bit 1: backward)
+    a.xcd_map = xcd_map;
     a.prefix[0] = 0;
     for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
     hipError_t e = hipMemsetAsync(workspace, 0, (size_t)need, s);
@@ -500,6 +509,18 @@ int64_t sat_lstm_persist_bwd_ws_bytes(int B, int H) {
     return 2 * groups * members * members * kRows * 16 * 8 + 64;
 }
 
+static std::mutex g_xch_mu;
+static std::unordered_map<void*, unsigned> g_xch_seen;   // exchange buffer -> generation it was last cleared in
+static unsigned g_xch_epoch = 0, g_xch_generation = 1;
+
+// the owner of a full backward workspace frees it (or hands the memory to somebody else): the next buffer at that address is
+// cleared again before its first use
+extern "C" int sat_lstm_ws_release(void* workspace) {
+    std::lock_guard<std::mutex> lk(g_xch_mu);
+    g_xch_seen.erase(workspace);
+    return SAT_OK;
+}
+
 int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* CS, const float* W, float* DG,
                                 const int32_t* batch_sizes, int T, int H, void* xch, unsigned* err, hipStream_t s) {
     const int B = batch_sizes[0];
@@ -514,23 +535,26 @@ int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* 
     const char* ds = getenv("SAT_LSTM_DEBUG_STALL");
     a.dbg_stall = (ds && ds[0] == '2') ? 1 : 0;
 #endif
+    // members of a group on equal blockIdx.x % 8 (one XCD under round-robin placement; speed only): measured at cfg 2 (round 5,
+    // profiles/r05_lstm_ab.txt, tools/micro_lstm.py, two processes each): the BACKWARD's K-split exchange of 8-byte granules gains
+    // 11 % (241.5 -> 214 us per call), the FORWARD's 4-byte self-tagged words lose 25 % (149.7 -> 187 us) -- so only here by default
+    static const int xcd_map = getenv("SAT_LSTM_XCD_MAP") ? (atoi(getenv("SAT_LSTM_XCD_MAP")) >> 1) & 1 : 1;
+    a.xcd_map = xcd_map && ((groups & (groups - 1)) == 0) && groups >= 8;
     a.prefix[0] = 0;
     for (int t = 0; t < T; ++t) a.prefix[t + 1] = a.prefix[t] + batch_sizes[t];
-    // Tags are epoch * 128 + step + 1 with a process-wide call counter, so the exchange is never cleared per call.  Invariant
-    // (sat_hip.h): the caller zeroed the buffer before its first use and nobody else writes there.  When the 24-bit counter
-    // wraps, tags of 2^24 calls ago could match again: every buffer is then cleared once, at its next use (generation check).
-    static std::mutex mu;
-    static std::unordered_map<void*, unsigned> seen;     // exchange buffer -> generation it was last known clean in
-    static unsigned epoch = 0, generation = 1;
+    // Tags are epoch * 128 + step + 1 with a process-wide call counter, so the exchange is never cleared per call.  The invariant
+    // "no foreign bit pattern in the exchange region" lives HERE, in one place (round 5): the library clears a buffer the first
+    // time it sees its address (and again when the 24-bit counter wraps: tags of 2^24 calls ago could match), remembers it, and
+    // forgets it when the owner says the memory is gone (sat_lstm_ws_release) -- callers need not zero anything.
     bool clear = false;
     {
-        std::lock_guard<std::mutex> lk(mu);
-        if (++epoch >= (1u << 24)) { epoch = 1; ++generation; }
-        a.epoch = epoch;
-        if (seen.size() > 4096) seen.clear();      // bounded; a forgotten buffer is cleared again only if the epoch has wrapped since the process began
-        auto it = seen.find(xch);
-        if (it == seen.end()) { seen.emplace(xch, generation); clear = generation > 1; }
-        else if (it->second != generation) { it->second = generation; clear = true; }
+        std::lock_guard<std::mutex> lk(g_xch_mu);
+        if (++g_xch_epoch >= (1u << 24)) { g_xch_epoch = 1; ++g_xch_generation; }
+        a.epoch = g_xch_epoch;
+        if (g_xch_seen.size() > 4096) g_xch_seen.clear();      // bounded: a forgotten buffer only costs it one clear
+        auto it = g_xch_seen.find(xch);
+        if (it == g_xch_seen.end()) { g_xch_seen.emplace(xch, g_xch_generation); clear = true; }
+        else if (it->second != g_xch_generation) { it->second = g_xch_generation; clear = true; }
     }
     hipError_t e = hipMemsetAsync(err, 0, 64, s);
     if (e != hipSuccess) return (int)e;

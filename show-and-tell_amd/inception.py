@@ -102,18 +102,30 @@ class InceptionStack(nn.Module):
     def bns(self):
         return [m.bn for m in self.modules() if isinstance(m, BasicConv2d)]
 
-    def program(self, N, H, W, dtype, training, device):
-        return InceptionProgram(self, N, H, W, dtype, training, device)
+    def program(self, N, H, W, dtype, training, device, groups=1, signatures=None):
+        return InceptionProgram(self, N, H, W, dtype, training, device, groups=groups, signatures=signatures)
 
 
 class InceptionProgram(ConvStackProgram):
     """op program of the Inception-v3 stack for one (batch, H, W, dtype, training); `run` / `run_timed` / hipGraph replay are
     the ResNet program's."""
 
-    def __init__(self, stack, N, H, W, dtype, training, device):
+    def __init__(self, stack, N, H, W, dtype, training, device, groups=1, signatures=None):
+        """groups = G > 1 (bf16): G look-ahead batches per launch, as in the ResNet program -- train mode: `sat_op.groups` = G, every
+        per-batch buffer G consecutive copies, per-group BatchNorm statistics, deferred running statistics; eval mode: the batches
+        concatenate into one program over G * N images."""
         self.N, self.H, self.W, self.dtype, self.training, self.stack = N, H, W, dtype, training, stack
-        self.groups, self._n_prep = 1, 1                   # one batch per launch; ops[0] is the image prep (ConvStackProgram.run)
-        self.keep, self.bn_list, self.stat_accs, self._want_sigs = [], [], [], {}
+        self.groups = int(groups)
+        self._n_prep = self.groups                         # ops[0 .. groups) are the image preps (ConvStackProgram.run)
+        if self.groups > 1 and dtype != L.SAT_BF16:
+            raise ValueError("grouped programs are for the bf16 stack")
+        Nb = N                                             # images per batch
+        if self.groups > 1 and not training:
+            N, G = self.groups * N, 1
+        else:
+            G = self.groups
+        GN = G * N                                         # images every per-image op (pools, image prep, the final pool) sees
+        self.keep, self.bn_list, self.stat_accs, self._want_sigs = [], [], [], dict(signatures or {})
         td = torch.bfloat16 if dtype == L.SAT_BF16 else torch.float32
         esz = 2 if dtype == L.SAT_BF16 else 4
         ch = 16 // esz
@@ -147,10 +159,10 @@ class InceptionProgram(ConvStackProgram):
                 wp[:, :wt.shape[1]] = wt
                 wt = wp
             wk = wt.permute(0, 2, 3, 1).contiguous().to(td).reshape(cv.cout, -1)
-            raw = alloc((N, ho, wo, cv.cout))
+            raw = alloc((GN, ho, wo, cv.cout))
             self.keep.append(wk)
             o = L.SatOp()
-            o.kind, o.dtype = L.OP_CONV, dtype
+            o.kind, o.dtype, o.groups = L.OP_CONV, dtype, G
             o.in0, o.w, o.out = x.data_ptr(), wk.data_ptr(), raw.data_ptr()
             o.N, o.Hin, o.Win, o.Cin, o.Hout, o.Wout, o.Cout = N, h, w, cin, ho, wo, cv.cout
             o.KH, o.KW, o.stride, o.pad = cv.kh, cv.kw, cv.stride, cv.ph
@@ -160,11 +172,11 @@ class InceptionProgram(ConvStackProgram):
             M = N * ho * wo
             tiles = lib.sat_conv_tiles_m(M)
             a = L.SatOp()
-            a.kind, a.dtype = L.OP_BN_RELU, dtype
+            a.kind, a.dtype, a.groups = L.OP_BN_RELU, dtype, G
             a.in0 = raw.data_ptr()
             a.N, a.Hout, a.Wout, a.Cout = N, ho, wo, cv.cout
             if out is None:
-                act = alloc((N, ho, wo, cv.cout))
+                act = alloc((GN, ho, wo, cv.cout))
                 a.out = act.data_ptr()
             else:
                 act = None
@@ -181,16 +193,16 @@ class InceptionProgram(ConvStackProgram):
                 a.scale0, a.shift0 = s.data_ptr(), t.data_ptr()
                 ops.extend([o, f, a])
             elif atomic:
-                acc = alloc((2, 1, 2, cv.cout), torch.int64, zero=True)
+                acc = alloc((G, 2, 2, cv.cout), torch.int64, zero=True)      # [G][2 parities][2][C]
                 self.stat_accs.append(acc)
                 if tiles <= 128:
                     o.stat_acc = acc.data_ptr()
                     ops.append(o)
                 else:                                    # many row tiles: per-tile slabs + the wide reducer into the same sums
-                    max_part[0] = max(max_part[0], tiles * 2 * cv.cout)
+                    max_part[0] = max(max_part[0], G * tiles * 2 * cv.cout)
                     o.tiles_m = tiles
                     f = L.SatOp()
-                    f.kind, f.dtype = L.OP_BN_FINALIZE, dtype
+                    f.kind, f.dtype, f.groups = L.OP_BN_FINALIZE, dtype, G
                     f.stat_acc = acc.data_ptr()
                     f.Cout, f.tiles_m, f.training = cv.cout, tiles, 1
                     part_users.extend([o, f])
@@ -221,9 +233,9 @@ class InceptionProgram(ConvStackProgram):
             o = L.SatOp()
             o.kind, o.dtype = kind, dtype
             o.in0 = x.data_ptr()
-            o.N, o.Hin, o.Win, o.Cout, o.Hout, o.Wout = N, h, w, c, ho, wo
+            o.N, o.Hin, o.Win, o.Cout, o.Hout, o.Wout = GN, h, w, c, ho, wo        # per image: the groups concatenate
             if out is None:
-                res = alloc((N, ho, wo, c))
+                res = alloc((GN, ho, wo, c))
                 o.out = res.data_ptr()
             else:
                 res = None
@@ -233,12 +245,13 @@ class InceptionProgram(ConvStackProgram):
 
         # ---- program ----
         cpad = ch
-        self.img = alloc((N, H, W, cpad), zero=True)
-        o = L.SatOp()
-        o.kind, o.dtype = L.OP_IMAGE_PREP, dtype
-        o.out = self.img.data_ptr()
-        o.N, o.Hin, o.Win, o.Hout, o.Wout, o.pad, o.Cout = N, H, W, H, W, 0, cpad
-        ops.append(o)
+        self.img = alloc((GN, H, W, cpad), zero=True)
+        for g_ in range(self.groups):                    # one image prep per batch, each into its slice
+            o = L.SatOp()
+            o.kind, o.dtype = L.OP_IMAGE_PREP, dtype
+            o.out = self.img[g_ * Nb:].data_ptr()
+            o.N, o.Hin, o.Win, o.Hout, o.Wout, o.pad, o.Cout = Nb, H, W, H, W, 0, cpad
+            ops.append(o)
         x, h, w = self.img, H, W
         for name in ("Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3"):
             x, h, w = basic(getattr(stack, name), x, h, w)
@@ -252,7 +265,7 @@ class InceptionProgram(ConvStackProgram):
                 ho, wo = (h - 3) // 2 + 1, (w - 3) // 2 + 1
             else:
                 ho, wo = h, w
-            y = alloc((N, ho, wo, cout))
+            y = alloc((GN, ho, wo, cout))
             off = 0
 
             def chain(names, src, hh, ww, width):
@@ -300,13 +313,13 @@ class InceptionProgram(ConvStackProgram):
                 chain(["branch_pool"], ap, h, w, 192)
             assert off == cout, (name, off, cout)
             x, h, w = y, ho, wo
-        self.pooled = alloc((N, stack.feature_dim), torch.float32)
+        self.pooled = alloc((GN, stack.feature_dim), torch.float32)
         apo = L.SatOp()
         apo.kind, apo.dtype = L.OP_AVGPOOL, dtype
         apo.in0, apo.out = x.data_ptr(), self.pooled.data_ptr()
-        apo.N, apo.Hin, apo.Win, apo.Cout = N, h, w, stack.feature_dim
+        apo.N, apo.Hin, apo.Win, apo.Cout = GN, h, w, stack.feature_dim
         ops.append(apo)
-        self.final_map = (x, N, h, w, stack.feature_dim)
+        self.final_map = (x, GN, h, w, stack.feature_dim)
         if max_part[0]:
             self.partial = alloc((max_part[0],), torch.float32)
             for o_ in part_users:
@@ -317,6 +330,8 @@ class InceptionProgram(ConvStackProgram):
         self._use_graph = os.environ.get("SAT_GRAPH", "1") != "0" and torch.device(device).type == "cuda"
         self._runs, self._graphs = [0, 0], [None, None]
         self._running_items = None
+        if self.groups > 1 and training:
+            self.defer_running_stats()
         # per-geometry kernel selection, as on the ResNet path: the tuner's three fastest variants per geometry, the final choice by
         # timing whole-program passes (ConvStackProgram._autotune; no activation buffer needs re-randomising: the tuner only times)
         self._autotune(device, (), alloc)

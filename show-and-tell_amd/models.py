@@ -120,7 +120,7 @@ class EncoderCNN(nn.Module):
         # (`ConvStackProgram(groups=G)`: every launch covers G batches, per-batch BatchNorm statistics, results bit-identical per
         # batch) -- half the launch boundaries and twice the workgroups per launch of the frozen stack.  1 = one program per batch.
         env_g = os.environ.get("SAT_LOOKAHEAD_GROUPS")
-        self.lookahead_groups = max(1, int(env_g)) if env_g else (1 if isinstance(arch, str) else self.LOOKAHEAD_GROUPS)
+        self.lookahead_groups = max(1, int(env_g)) if env_g else self.LOOKAHEAD_GROUPS
         env = os.environ.get("SAT_LOOKAHEAD_DEPTH")
         self.lookahead_depth = int(env) if env else self.LOOKAHEAD_DEPTH.get(arch if isinstance(arch, str) else "",
                                                                               3 * self.lookahead_groups)
@@ -181,23 +181,23 @@ class EncoderCNN(nn.Module):
                 if any(e["prog"] is self._programs[old] for e in self._inflight):
                     break                                   # never evict a program with a batch in flight
                 del self._programs[old]
-            make = getattr(self.resnet, "program", None)
-            if make is not None:
-                prog = make(N, H, W, dt, self.training, images.device)
+            make = getattr(self.resnet, "program", None)           # a stack with its own op program (Inception-v3)
+            # Every program of one (shape, mode, weights) runs its convs on kernel variants of the SAME BatchNorm statistics
+            # signature (tile shape / summation order), so a batch gets bit-identical features whichever program runs it.  The
+            # first program built tunes freely and leads; with the grouped look-ahead on that should be a grouped one (the
+            # tile shapes that win at `lookahead_groups` batches per launch are not the ones that win at one), so build it
+            # first when an ungrouped program is asked for
+            lead = key[:7]
+            grouped_la = dt == L.SAT_BF16 and self.lookahead_depth > 0 and self.lookahead_groups > 1
+            if lead not in self._lead_sigs and groups == 1 and grouped_la:
+                self._program(images, instance="g0", groups=self.lookahead_groups)
+            if make is not None:                         # a stack with its own op program (Inception-v3)
+                prog = make(N, H, W, dt, self.training, images.device, groups=groups, signatures=self._lead_sigs.get(lead))
             else:
-                # Every program of one (shape, mode, weights) runs its convs on kernel variants of the SAME BatchNorm statistics
-                # signature (tile shape / summation order), so a batch gets bit-identical features whichever program runs it.  The
-                # first program built tunes freely and leads; with the grouped look-ahead on that should be a grouped one (the
-                # tile shapes that win at `lookahead_groups` batches per launch are not the ones that win at one), so build it
-                # first when an ungrouped program is asked for
-                lead = key[:7]
-                grouped_la = dt == L.SAT_BF16 and self.lookahead_depth > 0 and self.lookahead_groups > 1
-                if lead not in self._lead_sigs and groups == 1 and grouped_la:
-                    self._program(images, instance="g0", groups=self.lookahead_groups)
                 prog = ConvStackProgram(self.resnet, N, H, W, dt, self.training, images.device, groups=groups,
                                         signatures=self._lead_sigs.get(lead))
-                if lead not in self._lead_sigs:
-                    self._lead_sigs[lead] = prog.signatures()
+            if lead not in self._lead_sigs:
+                self._lead_sigs[lead] = prog.signatures()
             self._programs[key] = prog
             if instance is not None:
                 prog.defer_running_stats()
@@ -207,7 +207,7 @@ class EncoderCNN(nn.Module):
     # stacks in flight.  Measured on MI355X at batch 64, per stack: 5.68 ms alone, 4.40 with two in flight, 4.33 with three (with
     # 8 hardware queues; 4.86 with HIP's default 4, where the third stream shares a queue)
     # whole ResNet-152 step: 5.25 ms at depth 2, 5.10 at depth 3, 5.38 at depth 4; Inception-v3 299x299: 5.68 at 2, 5.98 at 3
-    LOOKAHEAD_DEPTH = {"inception_v3": 2}
+    LOOKAHEAD_DEPTH = {"inception_v3": 4}      # (two grouped runs of two batches in flight; round 4: two single stacks)
     LOOKAHEAD_GROUPS = 2
 
     # Look-ahead RUN SLOTS: at most `lookahead_depth // lookahead_groups` op-program runs are in flight (3 by default: more than
@@ -279,7 +279,7 @@ class EncoderCNN(nn.Module):
         when it is the very next one or the list is shorter than the look-ahead window (the end of the data).  Returns the
         number of batches started."""
         ims = [im for im in images_list if im is not None and im.dim() == 4]
-        G = self.lookahead_groups if (self.compute_dtype == "bf16" and not hasattr(self.resnet, "program")) else 1
+        G = self.lookahead_groups if self.compute_dtype == "bf16" else 1
         started = 0
         new = [im for im in ims if not self._is_in_flight(im)]
         if G > 1:
@@ -315,7 +315,7 @@ class EncoderCNN(nn.Module):
         eager then captured).  Touches no model state: look-ahead instances keep their running-statistics updates deferred, and
         nothing here applies them."""
         L.require_gpu(images, "images")
-        G = self.lookahead_groups if (self.compute_dtype == "bf16" and not hasattr(self.resnet, "program")) else 1
+        G = self.lookahead_groups if self.compute_dtype == "bf16" else 1
         progs = []
         with torch.no_grad():
             if G > 1:
@@ -403,16 +403,17 @@ _WS_CACHE = {}
 
 
 def _persistent_ws(dev, nbytes, tag):
-    """A ZEROED uint8 workspace that the same (device, stream, size, role) gets again on every call: the persistent backward
-    recurrence tags its exchange granules per call instead of clearing 17 MB per step, which needs a buffer that was zero before
-    its first use and that nobody else writes (include/sat_hip.h, sat_lstm_bwd_ws_bytes_full) -- a fresh `torch.empty` per call
-    holds arbitrary old bits."""
+    """A uint8 workspace that the same (device, stream, size, role) gets again on every call: the persistent backward recurrence tags
+    its exchange granules per call instead of clearing 17 MB per step.  The invariant behind that -- no foreign bit pattern in the
+    exchange region -- is the LIBRARY's (include/sat_hip.h, sat_lstm_bwd_ws_bytes_full: it clears a buffer the first time it sees
+    its address); all this side owes it is `sat_lstm_ws_release` when a buffer goes away."""
     key = (str(dev), int(nbytes), tag, torch.cuda.current_stream(dev).cuda_stream)
     ws = _WS_CACHE.get(key)
     if ws is None:
         if len(_WS_CACHE) >= 16:
-            _WS_CACHE.pop(next(iter(_WS_CACHE)))
-        ws = _WS_CACHE[key] = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+            old = _WS_CACHE.pop(next(iter(_WS_CACHE)))
+            L.load().sat_lstm_ws_release(old.data_ptr())
+        ws = _WS_CACHE[key] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
     return ws
 
 
@@ -583,10 +584,10 @@ def decoder_backward_tapes(lib, dlogits, tapes, embed_w, lstm_layers, lin_w, pi,
         GA, CS, HP = tapes["layers"][l]
         DG = torch.empty(N, 4 * H, device=dev)
         dX = torch.empty(N, In, device=dev)
-        # the FULL workspace (split-K weight-gradient GEMMs + the persistent backward recurrence): it must be zero before its
-        # first use and ours alone (sat_hip.h)
-        wsb = lib.sat_lstm_bwd_ws_bytes_full(N, B, In, H)
-        ws = lstm_ws[l][1] if lstm_ws is not None else _persistent_ws(dev, wsb, ("lstm_bwd", l))
+        # the FULL workspace (split-K weight-gradient GEMMs + the persistent backward recurrence), sized for any N <= B * T so that
+        # batches of other lengths reuse it (its exchange region and status word sit at (B, H)-only offsets)
+        ws = lstm_ws[l][1] if lstm_ws is not None else _persistent_ws(dev, lib.sat_lstm_bwd_ws_bytes_max(B * T, B, In, H), ("lstm_bwd", l))
+        wsb = ws.numel()
         if mixed_ws is not None:
             L.check(lib.sat_lstm_bwd_bf16(L.ptr(dH), L.ptr(tapes["X"][l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(GA), L.ptr(CS),
                                           L.ptr(HP), pi.bs_c, T, In, H, L.ptr(DG), L.ptr(grads_out[("w_ih", l)]),
@@ -707,29 +708,25 @@ class DecoderRNN(nn.Module):
         H, V, E = self.hidden_size, self.vocab_size, self.embed_size
         st = L.stream()
         h0, c0 = self._initial_states(states, B, dev)
-        h = [h0[l].clone() for l in range(self.num_layers)]
-        h2 = [torch.empty(B, H, device=dev) for _ in range(self.num_layers)]
-        c = [c0[l].clone() for l in range(self.num_layers)]
+        h, c = h0.clone().contiguous(), c0.clone().contiguous()         # [num_layers, B, H]: state in, state out
+        h_tmp, xe = torch.empty_like(h), torch.empty(B, E, device=dev)
         ids = torch.empty(B, 20, dtype=torch.int64, device=dev)
         wsb = lib.sat_vocab_argmax_ws_bytes(B, V)
-        ws = torch.empty(wsb // 4, device=dev)
-        x = features
-        xe = torch.empty(B, E, device=dev)
-        for i in range(20):
-            inp = x
-            for l in range(self.num_layers):
-                w_ih, w_hh, b_ih, b_hh = self.lstm.layer(l)
-                L.check(lib.sat_lstm_step(L.ptr(inp), L.ptr(h[l]), L.ptr(c[l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih),
-                                          L.ptr(b_hh), B, w_ih.shape[1], H, L.ptr(h2[l]), st), "sat_lstm_step")
-                h[l], h2[l] = h2[l], h[l]
-                inp = h[l]
-            col = ids[:, i]
-            L.check(lib.sat_vocab_argmax(L.ptr(inp), L.ptr(self.linear.weight), L.ptr(self.linear.bias), B, H, V,
-                                         col.data_ptr(), ids.stride(0), L.ptr(ws), wsb, st), "sat_vocab_argmax")
-            L.check(lib.sat_embed_rows(L.ptr(self.embed.weight), col.data_ptr(), ids.stride(0), B, E, V, L.ptr(xe), st),
-                    "sat_embed_rows")
-            x = xe
+        ws = torch.empty(max(wsb // 4, 4), device=dev)
+        # the 20 steps (LSTM step, vocab projection + arg-max, embedding row) are enqueued by ONE library call: the loop was
+        # host-bound when every launch came through ctypes (round 4: 0.72 ms per 20 steps at batch 64)
+        L.check(lib.sat_greedy_decode(L.ptr(features), L.ptr(self.embed.weight), self._lstm_ptrs(), self.num_layers,
+                                      L.ptr(self.linear.weight), L.ptr(self.linear.bias), B, E, H, V, 20, L.ptr(h), L.ptr(c),
+                                      L.ptr(h_tmp), L.ptr(xe), ids.data_ptr(), ids.stride(0), L.ptr(ws), wsb, st), "sat_greedy_decode")
         return ids.squeeze()                # models.py:67: [20] at batch 1
+
+    def _lstm_ptrs(self):
+        """HOST array of the LSTM's device pointers, (w_ih, w_hh, b_ih, b_hh) per layer: the `lstm_w` argument of the decode calls"""
+        import ctypes as _C
+        ptrs = []
+        for l in range(self.num_layers):
+            ptrs += [t.data_ptr() for t in self.lstm.layer(l)]
+        return (_C.c_void_p * len(ptrs))(*ptrs)
 
     def _initial_states(self, states, B, dev):
         """The LSTM state `sample` starts from (models.py:56,61 hands `states` to nn.LSTM) as two f32 [num_layers, B, H]
@@ -771,48 +768,18 @@ class DecoderRNN(nn.Module):
         if K < 1 or K > 8:
             raise ValueError("beam_size must be in 1..8")
         H, V, E = self.hidden_size, self.vocab_size, self.embed_size
-        st, R = L.stream(), B * K
-        h = [torch.zeros(R, H, device=dev) for _ in range(self.num_layers)]
-        c = [torch.zeros(R, H, device=dev) for _ in range(self.num_layers)]
-        h2 = [torch.empty(R, H, device=dev) for _ in range(self.num_layers)]
-        c2 = [torch.empty(R, H, device=dev) for _ in range(self.num_layers)]
-        ldl = (V + 3) // 4 * 4
-        logits = torch.zeros(R, ldl, device=dev)
-        scores = torch.full((B, K), float("-inf"), device=dev)
-        scores[:, 0] = 0.0                       # step 0: K identical rows per image, only hypothesis 0 is live
-        scores2 = torch.empty(B, K, device=dev)
-        bws = torch.empty(lib.sat_beam_step_ws_bytes(B, K), dtype=torch.uint8, device=dev)
-        parents = torch.empty(steps, R, dtype=torch.int32, device=dev)
-        tokens = torch.empty(steps, R, dtype=torch.int64, device=dev)
-        x = features.repeat_interleave(K, 0).contiguous()
-        xe = torch.empty(R, E, device=dev)
+        st = L.stream()
         eid = -1 if end_id is None else int(end_id)
-        for i in range(steps):
-            inp = x
-            for l in range(self.num_layers):
-                w_ih, w_hh, b_ih, b_hh = self.lstm.layer(l)
-                L.check(lib.sat_lstm_step(L.ptr(inp), L.ptr(h[l]), L.ptr(c[l]), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih),
-                                          L.ptr(b_hh), R, w_ih.shape[1], H, L.ptr(h2[l]), st), "sat_lstm_step")
-                h[l], h2[l] = h2[l], h[l]
-                inp = h[l]
-            L.check(lib.sat_vocab_logits_fwd(L.ptr(inp), L.ptr(self.linear.weight), L.ptr(self.linear.bias), R, H, V,
-                                             L.ptr(logits), ldl, st), "sat_vocab_logits_fwd")
-            last = tokens[i - 1].data_ptr() if (i > 0 and eid >= 0) else None
-            L.check(lib.sat_beam_step(L.ptr(logits), ldl, L.ptr(scores), last, eid, B, K, V, parents[i].data_ptr(),
-                                      tokens[i].data_ptr(), L.ptr(scores2), L.ptr(bws), bws.numel(), st), "sat_beam_step")
-            scores, scores2 = scores2, scores
-            if K > 1:
-                for l in range(self.num_layers):
-                    L.check(lib.sat_beam_gather_rows(L.ptr(h[l]), parents[i].data_ptr(), B, K, H, L.ptr(h2[l]), st),
-                            "sat_beam_gather_rows")
-                    L.check(lib.sat_beam_gather_rows(L.ptr(c[l]), parents[i].data_ptr(), B, K, H, L.ptr(c2[l]), st),
-                            "sat_beam_gather_rows")
-                    h[l], h2[l], c[l], c2[l] = h2[l], h[l], c2[l], c[l]
-            L.check(lib.sat_embed_rows(L.ptr(self.embed.weight), tokens[i].data_ptr(), 1, R, E, V, L.ptr(xe), st),
-                    "sat_embed_rows")
-            x = xe
+        wsb = lib.sat_beam_decode_ws_bytes(B, K, E, H, V, self.num_layers, steps)
+        ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
         ids = torch.empty(B, K, steps, dtype=torch.int64, device=dev)
-        L.check(lib.sat_beam_backtrack(L.ptr(parents), L.ptr(tokens), steps, B, K, L.ptr(ids), st), "sat_beam_backtrack")
+        scores = torch.empty(B, K, device=dev)
+        # every step (LSTM step, exact-f32 vocab projection, per-row log-softmax + top-K, per-image merge that also gathers the next
+        # input's embedding rows, one (h, c) re-ordering launch) is enqueued by ONE library call (sat_beam_decode)
+        L.check(lib.sat_beam_decode(L.ptr(features), L.ptr(self.embed.weight), self._lstm_ptrs(), self.num_layers,
+                                    L.ptr(self.linear.weight), L.ptr(self.linear.bias), B, K, E, H, V, int(steps), eid,
+                                    ids.data_ptr(), L.ptr(scores), ws.data_ptr() + off, wsb, st), "sat_beam_decode")
         if return_all:
             return ids, scores
         return ids[:, 0].contiguous()

@@ -105,6 +105,13 @@ class TrainStep:
         self._fault_sticky = torch.zeros(1, device=self.flat.params.device)
         self.fault_slot = self.flat.grads[self.flat.loss_slot + 1:self.flat.loss_slot + 2]
 
+    def __del__(self):
+        try:                                     # the library remembers a backward workspace by address: tell it the memory is gone
+            for _, bws in getattr(self, "_lstm_ws", []):
+                self.lib.sat_lstm_ws_release(bws.data_ptr())
+        except Exception:
+            pass
+
     # -- encoder look-ahead ---------------------------------------------------------------------------
     def prefetch_encoder(self, images):
         """Start the frozen conv stack of a LATER batch on a side stream (`EncoderCNN.prefetch`: up to three batches' stacks in
@@ -178,23 +185,33 @@ class TrainStep:
                 xhat=torch.empty(B, E, device=dev), rstd=torch.empty(E, device=dev),
                 head_ws=torch.empty(max(wsb // 4, B * E), device=dev), d_feat=torch.empty(B, E, device=dev),
                 pooled=torch.empty(B, F, device=dev))
-            # LSTM workspaces this engine owns for good: zeroed once (the backward's exchange region is tagged per call, never
-            # cleared: sat_hip.h), their status words folded into the step's fault flag below
-            bufs["lstm_ws"], words = [], []
+        # LSTM workspaces this engine owns for good, keyed by (B, caption width) -- NOT by N, which changes with almost every batch
+        # of real captions: sized for the longest batch of that width (sat_lstm_bwd_ws_bytes_max), the exchange region and the
+        # status words at offsets that depend on (B, H) only; their status words are folded into the step's fault flag below
+        wkey = (B, int(captions.shape[1]))
+        if getattr(self, "_lstm_ws_key", None) != wkey:
+            for _, old in getattr(self, "_lstm_ws", []):
+                lib.sat_lstm_ws_release(old.data_ptr())          # (the library forgets the address: a later buffer there is cleared again)
+            self._lstm_ws, words = [], []
+            n_max = B * (int(captions.shape[1]) - 1)
             for l in range(dec.num_layers):
                 In = E if l == 0 else dec.hidden_size
-                fb, bb = lib.sat_lstm_fwd_ws_bytes(B, dec.hidden_size), lib.sat_lstm_bwd_ws_bytes_full(N, B, In, dec.hidden_size)
+                fb, bb = lib.sat_lstm_fwd_ws_bytes(B, dec.hidden_size), lib.sat_lstm_bwd_ws_bytes_max(n_max, B, In, dec.hidden_size)
                 fws = torch.zeros(max(fb, 16), dtype=torch.uint8, device=dev)
-                bws = torch.zeros(bb, dtype=torch.uint8, device=dev)
-                bufs["lstm_ws"].append((fws, bws))
+                bws = torch.empty(bb, dtype=torch.uint8, device=dev)
+                self._lstm_ws.append((fws, bws))
                 fo = lib.sat_lstm_fwd_status_offset(B, dec.hidden_size)
                 if fo >= 0 and fb > 0:
                     words.append(fws.data_ptr() + fo)
-                words.append(bws.data_ptr() + lib.sat_lstm_bwd_status_offset(N, B, In, dec.hidden_size))
+                so = lib.sat_lstm_bwd_status_offset(N, B, In, dec.hidden_size)
+                bws[so:so + 64].zero_()                          # (read by the fault flag even when the call below never runs persistently)
+                words.append(bws.data_ptr() + so)
             if len(words) > 8:
                 raise ValueError("at most 4 LSTM layers (8 status words per step)")
             import ctypes as _C
-            bufs["fault_words"] = ((_C.c_void_p * len(words))(*words), len(words))
+            self._fault_words = ((_C.c_void_p * len(words))(*words), len(words))
+            self._lstm_ws_key = wkey
+        bufs["lstm_ws"], bufs["fault_words"] = self._lstm_ws, self._fault_words
         # targets = pack(captions[:,1:], lengths-1)                           train.py:135
         L.check(lib.sat_pack_targets(captions.data_ptr(), captions.stride(0), L.ptr(pi.prefix_dev), pi.T, N,
                                      L.ptr(bufs["targets"]), st), "sat_pack_targets")

@@ -252,6 +252,7 @@ def test_program_builds_and_their_tuning_passes_leave_the_model_untouched(tmp_pa
     import json
     tune = tmp_path / "tune.json"
     monkeypatch.setenv("SAT_TUNE_FILE", str(tune))
+    monkeypatch.setenv("SAT_AUTOTUNE", "1")               # timing-based tuning is opt-in since round 5 (tune.py): this test is about it
     torch.manual_seed(3)
     arch = dict(layers=(1, 2, 1, 1), width=64)            # wide enough for the weights-in-registers kernels (Cin % 64, Cout % 128)
     enc = sat.EncoderCNN(32, arch=arch, compute_dtype="bf16").cuda().train()
