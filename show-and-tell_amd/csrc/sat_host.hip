@@ -194,8 +194,9 @@ extern "C" int sat_fc_bn1d_bwd(const float* dy, const float* pooled, const float
 // ------------------------------------------------------------------------------------------------------
 // LSTM layer over a packed batch
 bool sat_lstm_persist_ok(int B, int H, int T, int n_cu);          // sat_lstm_persist.hip
+int sat_lstm_persist_rows(int B, int H, int T, int n_cu);
 int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, float* HP, const int32_t* batch_sizes, int T,
-                            int H, void* workspace, int64_t ws_bytes, hipStream_t s);
+                            int H, int rows, void* workspace, int64_t ws_bytes, hipStream_t s);
 int64_t sat_lstm_persist_bwd_ws_bytes(int B, int H);
 int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* CS, const float* W, float* DG,
                                 const int32_t* batch_sizes, int T, int H, void* xch, unsigned* err, hipStream_t s);
@@ -235,8 +236,8 @@ static int lstm_fwd_impl(const float* X, const float* w_ih, const float* w_hh, c
     // the recurrence: ONE persistent launch (W_hh in registers, per-group hidden-state exchange) when every workgroup
     // can be resident and the caller brought the exchange workspace; otherwise one launch per step
     static const int persist_env = getenv("SAT_LSTM_PERSIST") ? atoi(getenv("SAT_LSTM_PERSIST")) : 1;
-    if (persist_env && workspace && ws_bytes >= sat_lstm_fwd_ws_bytes(B, H) && sat_lstm_persist_ok(B, H, T, device_cu_count()))
-        return sat_lstm_persist_launch(GA, w_hh, CS, HS, HP, batch_sizes, T, H, workspace, ws_bytes, s);
+    const int prow = (persist_env && workspace && ws_bytes >= sat_lstm_fwd_ws_bytes(B, H)) ? sat_lstm_persist_rows(B, H, T, device_cu_count()) : 0;
+    if (prow) return sat_lstm_persist_launch(GA, w_hh, CS, HS, HP, batch_sizes, T, H, prow, workspace, ws_bytes, s);
     // one launch per step: the status word the caller reads back (sat_lstm_fwd_status_offset) reports a clean run
     const int64_t soff = sat_lstm_fwd_status_offset(B, H);
     if (workspace && soff >= 0 && ws_bytes >= soff + 64) {

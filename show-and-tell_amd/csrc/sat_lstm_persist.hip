@@ -80,8 +80,12 @@ __device__ __forceinline__ float untag_h(unsigned w) {
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int NKB>      // H = 16 * NKB, NKB even
+// KR = batch rows per group: 8 (half of every 16-row MFMA tile is padding, twice the groups), or 16 -- round 5: a full tile, half the
+// workgroups; what lets H = 1024 (64 members per group: 4 groups x 64 = 256 workgroups at batch 64, W_hh slice = 256 registers per
+// lane across VGPRs + AGPRs, one wave per SIMD) run persistently at all
+template <int NKB, int KR>      // H = 16 * NKB, NKB even
 __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) {
+    constexpr int kRows = KR;
     constexpr int H = 16 * NKB;
     constexpr int HROW = H + 4;                       // LDS row stride in floats: rows land 16 B apart in the bank row
     __shared__ __attribute__((aligned(16))) float h_lds[kRows * HROW];
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
     if (tid == 0) s_abort = 0;
     __syncthreads();
 
-    // epilogue ownership: lanes 0..31 of each wave own (row = lane>>2, unit = u0 + (lane&3)); c lives in a register
+    // epilogue ownership: lanes 0 .. 4 KR - 1 of each wave own (row = lane>>2, unit = u0 + (lane&3)); c lives in a register
     const int erow = lane >> 2, eu = u0 + (lane & 3);
     float c_reg = 0.0f;
     constexpr unsigned kSlab = kRows * H * 4;                           // bytes per (parity, group): [8 rows][H] words
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
 
         // ---- the epilogue's own operands, fetched under the MFMAs: x-gates of (row, unit) ----
         float xg[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool own = lane < 32 && erow < active;
+        const bool own = lane < 4 * kRows && erow < active;
         const long prow = (long)p.prefix[t] + row0 + erow;               // packed row of (t, batch row)
         if (own) {
 #pragma unroll
@@ -190,15 +194,15 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(const PersistArgs p) 
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], wreg[kb + 1][e], acc1, 0, 0, 0);
             }
         }
-        // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg -> rows 0..7 sit in lanes with kg < 2
-        if (kg < 2) {
+        // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg -> rows 0..KR-1 sit in lanes with 4 kg < KR
+        if (kg * 4 < kRows) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) c_lds[wave][kg * 4 + e][n16] = acc0[e] + acc1[e];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // wave-local hand-off through LDS
         __builtin_amdgcn_wave_barrier();
 
-        if (lane < 32) {
+        if (lane < 4 * kRows) {
             float g4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) g4[g] = c_lds[wave][erow][g * 4 + (lane & 3)] + xg[g];
@@ -435,11 +439,12 @@ __global__ __launch_bounds__(256) void lstm_persist_bwd_kernel(const PersistBwdA
 
 bool sat_lstm_persist_has(int H);
 
-// workspace: the granule exchange (2 parities) + the error word, in one block that is zeroed per call
+// workspace: the exchange (2 parities) + the error word, in one block that is zeroed per call.  Sized for 16-row groups (>= what
+// 8-row groups need): the rows per group are chosen at launch (sat_lstm_persist_rows)
 extern "C" int64_t sat_lstm_fwd_ws_bytes(int B, int H) {
     if (H < 16 || (H % 16)) return 0;
-    const int64_t groups = (B + kRows - 1) / kRows, members = H / kUnits;
-    return 2 * groups * members * kRows * kUnits * 4 + 64;
+    const int64_t rows = (B + 15) / 16 * 16;
+    return 2 * rows * H * 4 + 64;
 }
 
 // Byte offset of the recurrence's STATUS WORD (u32) inside the sat_lstm_fwd workspace: 0 after a clean run, non-zero when a
@@ -459,7 +464,21 @@ extern "C" int sat_lstm_persist_enable(int on) {
     return prev;
 }
 
-// can the persistent kernel run this layer?  (all workgroups must be co-resident: one per CU)
+// rows per group of the persistent FORWARD recurrence for this layer, 0 = it cannot run (all workgroups must be co-resident: one per
+// CU): 8 where ceil(B / 8) * H / 16 workgroups fit, else 16 (H = 1024 at batch 64).  SAT_LSTM_ROWS=16 prefers 16 wherever it fits
+// (half the workgroups: profiles/r05_lstm_ab.txt).
+bool sat_lstm_persist_has16(int H);
+int sat_lstm_persist_rows(int B, int H, int T, int n_cu) {
+    if (!g_persist_enabled || T > kMaxT || T < 1 || H < 16 || (H % 16)) return 0;
+    static const int prefer16 = getenv("SAT_LSTM_ROWS") ? atoi(getenv("SAT_LSTM_ROWS")) == 16 : 0;
+    const int members = H / kUnits;
+    const bool fit8 = sat_lstm_persist_has(H) && ((B + 7) / 8) * members <= n_cu;
+    const bool fit16 = sat_lstm_persist_has16(H) && ((B + 15) / 16) * members <= n_cu;
+    if (fit16 && (prefer16 || !fit8)) return 16;
+    return fit8 ? 8 : 0;
+}
+
+// can the persistent BACKWARD kernel run this layer?  (8-row groups only; all workgroups co-resident)
 bool sat_lstm_persist_ok(int B, int H, int T, int n_cu) {
     if (!g_persist_enabled) return false;
     if (!sat_lstm_persist_has(H) || T > kMaxT || T < 1) return false;
@@ -468,9 +487,10 @@ bool sat_lstm_persist_ok(int B, int H, int T, int n_cu) {
 }
 
 int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, float* HP, const int32_t* batch_sizes, int T,
-                            int H, void* workspace, int64_t ws_bytes, hipStream_t s) {
+                            int H, int rows, void* workspace, int64_t ws_bytes, hipStream_t s) {
     const int B = batch_sizes[0];
-    const int groups = (B + kRows - 1) / kRows, members = H / kUnits;
+    if (rows != 8 && rows != 16) return SAT_ERR_ARG;
+    const int groups = (B + rows - 1) / rows, members = H / kUnits;
     const int64_t need = sat_lstm_fwd_ws_bytes(B, H);
     if (!workspace || ws_bytes < need) return SAT_ERR_WORKSPACE;
     PersistArgs a = {};
@@ -492,11 +512,20 @@ int sat_lstm_persist_launch(float* GA, const float* W, float* CS, float* HS, flo
     if (e != hipSuccess) return (int)e;
     // (all workgroups must be resident together; the only other kernels of this library that spin are this one's own instances)
     const dim3 grid(groups * members), block(256);
-    switch (H / 16) {
-#define SAT_PERSIST_CASE(n) case n: hipLaunchKernelGGL((lstm_persist_kernel<n>), grid, block, 0, s, a); break;
-        SAT_PERSIST_CASE(2) SAT_PERSIST_CASE(4) SAT_PERSIST_CASE(6) SAT_PERSIST_CASE(8) SAT_PERSIST_CASE(16) SAT_PERSIST_CASE(32)
+    if (rows == 16) {
+        switch (H / 16) {
+#define SAT_PERSIST_CASE(n) case n: hipLaunchKernelGGL((lstm_persist_kernel<n, 16>), grid, block, 0, s, a); break;
+            SAT_PERSIST_CASE(16) SAT_PERSIST_CASE(32) SAT_PERSIST_CASE(64)
 #undef SAT_PERSIST_CASE
-        default: return SAT_ERR_UNSUPPORTED;
+            default: return SAT_ERR_UNSUPPORTED;
+        }
+    } else {
+        switch (H / 16) {
+#define SAT_PERSIST_CASE(n) case n: hipLaunchKernelGGL((lstm_persist_kernel<n, 8>), grid, block, 0, s, a); break;
+            SAT_PERSIST_CASE(2) SAT_PERSIST_CASE(4) SAT_PERSIST_CASE(6) SAT_PERSIST_CASE(8) SAT_PERSIST_CASE(16) SAT_PERSIST_CASE(32)
+#undef SAT_PERSIST_CASE
+            default: return SAT_ERR_UNSUPPORTED;
+        }
     }
     SAT_LAUNCH_CHECK();
     return SAT_OK;
@@ -575,4 +604,7 @@ int sat_lstm_persist_bwd_launch(const float* dHS, const float* GA, const float* 
 
 bool sat_lstm_persist_has(int H) {
     switch (H / 16) { case 2: case 4: case 6: case 8: case 16: case 32: return (H % 16) == 0; default: return false; }
+}
+bool sat_lstm_persist_has16(int H) {
+    switch (H / 16) { case 16: case 32: case 64: return (H % 16) == 0; default: return false; }
 }

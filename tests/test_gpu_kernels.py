@@ -1109,11 +1109,14 @@ def test_embed_concat_bwd_beyond_the_default_lds_limit(lib):
 
 
 @pytest.mark.parametrize("B,T,In,H,ragged", [(64, 19, 256, 512, False), (64, 19, 64, 512, True), (13, 7, 32, 64, True),
-                                             (8, 5, 32, 32, False), (40, 12, 96, 256, True), (3, 9, 32, 128, True)])
+                                             (8, 5, 32, 32, False), (40, 12, 96, 256, True), (3, 9, 32, 128, True),
+                                             (64, 19, 512, 1024, False), (64, 12, 1024, 1024, True), (21, 6, 64, 1024, True)])
 def test_lstm_fwd_persistent_equals_per_step_launches(lib, B, T, In, H, ragged, monkeypatch):
     """sat_lstm_fwd with the exchange workspace (ONE persistent launch: W_hh in registers, granule hand-off per group)
     against the same entry point without it (one launch per step): every tape bit-identical (same MFMA, same K order per
-    output element is NOT guaranteed -- the per-step kernel splits K over 8 waves -- so: 1e-6), and against fp64"""
+    output element is NOT guaranteed -- the per-step kernel splits K over 8 waves -- so: 1e-6), and against fp64.
+    H = 1024 (the reference's default hidden size, config.py:28; BASELINE configs[3]): 16-row groups, 4 groups x 64 members at
+    batch 64, the W_hh slice across VGPRs + AGPRs (round 5)."""
     g = torch.Generator().manual_seed(B * 7 + T + H)
     lengths = sorted([int(x) for x in torch.randint(1, T + 1, (B,), generator=g)], reverse=True) if ragged else [T] * B
     lengths[0] = T
@@ -1285,6 +1288,20 @@ def test_fixed_point_statistics_hold_for_small_magnitude_channels(lib):
     # mean: absolute error <= 1.2e-7 per tile sum / 128 rows; variance: relative to (var + eps), which is what the normalisation sees
     assert (got_m - mean).abs().max().item() < 2e-6, (got_m - mean).abs().max()
     assert (((got_v - unb).abs()) / (unb + 1e-5)).max().item() < 2e-3
+
+
+def test_lstm_fwd_16_row_groups_at_hidden_512_in_a_fresh_process():
+    """SAT_LSTM_ROWS=16 (read once per process): the cfg-2 layer on 4 groups x 32 members = 128 workgroups -- full 16-row MFMA tiles,
+    half the CUs -- must equal the per-step launches like the default 8-row form does"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SAT_LSTM_ROWS="16")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
+                        "test_lstm_fwd_persistent_equals_per_step_launches and (512 or 256)"], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_persistent_lstm_timeout_is_reported_not_swallowed(hooks_lib, monkeypatch):
