@@ -431,7 +431,7 @@ def selftest_launch(torch, rank, world, fail_rank=-1):
         dist.destroy_process_group()
 
 
-def attach_traffic(out):
+def attach_traffic(out, TRAFFIC_FILE=TRAFFIC_FILE):
     # HBM bytes per conv launch come from separate rocprofv3 --pmc passes (tools/run_gpu_pmc.sh -> profiles/): only a
     # measurement taken on THIS library build is quoted -- a file older than libsat_hip.so describes other kernels
     if not os.path.exists(TRAFFIC_FILE):
@@ -618,7 +618,7 @@ def main():
         if args.workload == "train":
             attach_traffic(out)
         else:
-            out["roofline"]["traffic_note"] = "null: the PMC traffic passes of this round were taken on the headline workload (profiles/r05_pmc_traffic.json)"
+            attach_traffic(out, os.path.join(ROOT, "profiles", "r05_cfg3_pmc_traffic.json"))      # the same passes on configs[3]
         if world == 1 and args.lookahead and not args.no_f32_mode:
             # the same K steps with strictly sequential steps (what --no-lookahead times), for comparison in the same process
             def seq_steps(n):

@@ -62,6 +62,11 @@ def collate_on_device(images, flat_captions, lengths, image_ids=None):
     return out_im, caps, [lengths[i] for i in order], ids
 
 
+class _Upcoming(list):
+    """the list `DevicePrefetcher.upcoming_images()` returns; `.last`: the data ends inside it (`EncoderCNN.prefetch_many`)"""
+    last = None
+
+
 class DevicePrefetcher:
     """Wraps an iterable of (images, captions, lengths, ...) host batches: yields the same tuples with the two tensors
     resident on `device`; the copies of the next `depth` batches run on a side HIP stream while the caller works on the
@@ -70,13 +75,17 @@ class DevicePrefetcher:
     that follow, in order -- what `TrainStep.step(..., next_images=...)` / `EncoderCNN.prefetch` want for the encoder
     look-ahead; the very same tensor objects are yielded later."""
 
-    def __init__(self, batches, device, depth=1):
+    def __init__(self, batches, device, depth=None):
+        """depth: batches staged ahead of the one being consumed; None = 6, the encoder's default look-ahead window
+        (`EncoderCNN.lookahead_depth`: a smaller depth still works -- `upcoming_images()` tells the look-ahead whether the data
+        ends inside the list -- but leaves run slots of the look-ahead empty)"""
         self.batches, self.device = batches, torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DevicePrefetcher copies to the MI355X; got device %s" % (device,))
         self.stream = torch.cuda.Stream(self.device)
-        self.depth = max(1, int(depth))
+        self.depth = max(1, int(depth if depth is not None else 6))
         self._queue = []          # [(staged batch tuple, copy-done event)]
+        self._done = False        # the wrapped iterable is exhausted: everything that will ever come is staged
 
     def _stage(self, batch):
         images, captions = batch[0], batch[1]
@@ -94,7 +103,8 @@ class DevicePrefetcher:
         up by copies of batches it will only consume later; it waits for a batch's copy when `__iter__` yields that
         batch.  Hand such tensors to nothing but the look-ahead.  wait=True: the current stream waits for every staged copy
         first, so the tensors are safe for ANY use on it."""
-        out = []
+        out = _Upcoming()
+        out.last = self._done                              # the data ends inside this list: a batch without a partner will not get one
         cur = torch.cuda.current_stream(self.device) if wait else None
         for staged, ev in self._queue:
             if wait:
@@ -107,13 +117,13 @@ class DevicePrefetcher:
     def __iter__(self):
         it = iter(self.batches)
         self._queue = []
-        done = False
+        self._done = False
         while True:
-            while not done and len(self._queue) < self.depth + 1:      # the batch to yield + `depth` copies in flight
+            while not self._done and len(self._queue) < self.depth + 1:      # the batch to yield + `depth` copies in flight
                 try:
                     self._queue.append(self._stage(next(it)))
                 except StopIteration:
-                    done = True
+                    self._done = True
             if not self._queue:
                 return
             ready, ev = self._queue.pop(0)

@@ -233,7 +233,9 @@ class EncoderCNN(nn.Module):
         return None
 
     def _is_in_flight(self, images):
-        return any(im is images for e in self._inflight for im in e["images"])
+        # (a tensor already consumed from a group that is only partly taken is NOT in flight any more: a staging buffer refilled
+        # and handed in again must start a new run instead of silently returning False -- ADVICE r4)
+        return any(im is images and not e["taken"][g] for e in self._inflight for g, im in enumerate(e["images"]))
 
     def _launch(self, ims, slot, groups):
         dev = ims[0].device
@@ -272,12 +274,17 @@ class EncoderCNN(nn.Module):
         self._launch([images], slot, 1)
         return True
 
-    def prefetch_many(self, images_list):
-        """`prefetch` for the next few batches IN ORDER.  With `lookahead_groups` = G > 1 (ResNet, bf16, train mode) G batches
-        that are not in flight yet start together as ONE grouped program (every launch of the stack covers G batches; each
-        batch's statistics and features are bit for bit those of its own ungrouped run); a batch left over is started alone
-        when it is the very next one or the list is shorter than the look-ahead window (the end of the data).  Returns the
-        number of batches started."""
+    def prefetch_many(self, images_list, last=None):
+        """`prefetch` for the next few batches IN ORDER.  With `lookahead_groups` = G > 1 (bf16) G batches that are not in flight
+        yet start together as ONE grouped program (every launch of the stack covers G batches; each batch's statistics and
+        features are bit for bit those of its own ungrouped run); a batch left over is started alone when it is the very next
+        one or at the END OF THE DATA (no partner will come).  `last`: True / False says explicitly whether the list reaches the
+        end of the data (`DevicePrefetcher.upcoming_images()` sets it on the list it returns); None infers it from a list shorter
+        than the look-ahead window -- right for callers that always hand in `lookahead_depth` batches when they have them
+        (`bench.py`), wrong for a prefetcher of smaller depth, which would start a single per step and never a group.
+        Returns the number of batches started."""
+        if last is None:
+            last = getattr(images_list, "last", None)
         ims = [im for im in images_list if im is not None and im.dim() == 4]
         G = self.lookahead_groups if self.compute_dtype == "bf16" else 1
         started = 0
@@ -298,7 +305,7 @@ class EncoderCNN(nn.Module):
             # a batch left without a partner starts alone when it is the very next one (it must not wait: one slot beyond the
             # regular ones is its), or when the caller's list is shorter than the look-ahead window -- the end of the data: no
             # partner will come, and started now its stack runs beside the last groups instead of alone behind them
-            tail = len(ims) < self.lookahead_depth
+            tail = bool(last) if last is not None else len(ims) < self.lookahead_depth
             for im in new:
                 if im is ims[0]:
                     started += 1 if self.prefetch(im, _extra=True) else 0

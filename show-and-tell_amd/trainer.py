@@ -126,6 +126,7 @@ class TrainStep:
         batch frees is available to them)."""
         enc = self.model.encoder
         nxt = None
+        last = getattr(next_images, "last", None)      # (DevicePrefetcher.upcoming_images() says whether the data ends inside the list)
         if next_images is not None:
             nxt = list(next_images) if isinstance(next_images, (list, tuple)) else [next_images]
         hit = enc._take_prefetched(images)
@@ -134,10 +135,10 @@ class TrainStep:
             out.copy_(prog.pooled_of(g))
             prog.apply_running_stats(g)         # batch order = consumption order
             if nxt:
-                enc.prefetch_many(nxt)
+                enc.prefetch_many(nxt, last=last)
             return out
         if nxt:
-            enc.prefetch_many(nxt)
+            enc.prefetch_many(nxt, last=last)
         out.copy_(enc._pooled_raw(images))
         return out
 

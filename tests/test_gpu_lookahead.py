@@ -53,6 +53,40 @@ def test_lookahead_is_bitwise_identical_to_sequential(groups, depth):
         assert grouped_runs >= 2, grouped_runs          # the grouped path really ran (not only single prefetches)
 
 
+def test_a_prefetcher_shallower_than_the_window_still_runs_grouped_programs():
+    """`prefetch_many` inferred "end of the data" from a list shorter than the look-ahead window, so a `DevicePrefetcher`
+    of depth 3 under a window of 6 started one single per step and never a group.  The prefetcher now says explicitly whether the data
+    ends inside the list it hands over (`upcoming_images().last`): grouped runs in steady state, singles only at the real end -- and
+    the losses equal the sequential run bit for bit."""
+    def run(lookahead):
+        torch.manual_seed(5)
+        model = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().train()
+        if not lookahead:
+            model.encoder.lookahead_depth = 0
+        ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+        g = torch.Generator().manual_seed(11)
+        caps = torch.randint(1, 120, (8, 9), generator=g)
+        lengths = [9, 9, 8, 7, 6, 5, 4, 3]
+        host = [(torch.rand(8, 3, 64, 64, generator=g), caps, lengths) for _ in range(9)]
+        pf = sat.DevicePrefetcher(host, "cuda", depth=3)
+        losses, grouped, singles = [], 0, 0
+        for im, cp, ln in pf:
+            up = pf.upcoming_images() if lookahead else None
+            before = {id(e) for e in model.encoder._inflight}
+            losses.append(ts.step(im, cp, ln, next_images=up or None))
+            for e in model.encoder._inflight:
+                if id(e) not in before:
+                    grouped += len(e["images"]) > 1
+                    singles += len(e["images"]) == 1
+        torch.cuda.synchronize()
+        ts.check_ids()
+        return torch.cat(losses).cpu(), grouped, singles
+    seq, _, _ = run(False)
+    la, grouped, singles = run(True)
+    assert torch.equal(seq, la)
+    assert grouped >= 3 and singles <= 3, (grouped, singles)
+
+
 def test_lookahead_of_a_different_tensor_is_discarded():
     torch.manual_seed(5)
     model = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().train()

@@ -56,11 +56,13 @@ with torch.no_grad():
 
     im299 = torch.randn(64, 3, 299, 299, device=dev)
     model = sat.ShowAndTell(512, 1024, 10000, 2, arch="inception_v3", compute_dtype="bf16").to(dev).train()
-    model.encoder._program(im299)
+    model.encoder._program(im299)                        # grouped lead, the ungrouped program within its signatures ...
+    model.encoder.build_lookahead(im299)                 # ... and the look-ahead instances (grouped FOLLOWERS: keys with ",s<signature>")
     for _ in range(8):
         model.encoder(im299)
     model.eval()
     model.encoder._program(im299)
+    model.encoder.build_lookahead(im299)
     note("inception_v3 train + eval: done")
     del model
     torch.cuda.empty_cache()

@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 
-CONV_KERNELS = ('conv_glds_kernel', 'conv_xp_kernel', 'conv_pr_kernel', 'conv_stem_kernel', 'conv_pw_kernel', 'conv_aw_kernel')
+CONV_KERNELS = ('conv_glds_kernel', 'conv_xp_kernel', 'conv_pr_kernel', 'conv_stem_kernel', 'conv_pw_kernel', 'conv_aw_kernel', 'conv_ap_kernel')
 
 
 def cls(n):

@@ -65,7 +65,7 @@ def main():
     out["sequential_training_step"] = {"kernels": step, "bytes_corrected": tot_s}
     c = prog.get("conv (all kernels)")
     if c:
-        out["kernel"] = "conv_glds_kernel + conv_xp_kernel + conv_pw_kernel + conv_aw_kernel + conv_pr_kernel + conv_stem_kernel: every conv launch of one pass of the grouped look-ahead program"
+        out["kernel"] = "conv_glds_kernel + conv_xp_kernel + conv_pw_kernel + conv_aw_kernel + conv_ap_kernel + conv_pr_kernel + conv_stem_kernel: every conv launch of one pass of the grouped look-ahead program"
         out["launches"] = c["launches"]
         out["hbm_bytes_per_launch_corrected"] = c["bytes_per_launch_corrected"]
     print(json.dumps(out, indent=1))

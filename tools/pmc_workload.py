@@ -15,10 +15,11 @@ import bench  # noqa: E402
 sat = importlib.import_module("show-and-tell_amd")
 L = sat._lib
 lib = L.load()
-wl = bench.WORKLOADS["train"]
+wl = bench.WORKLOADS[os.environ.get("SAT_PMC_WORKLOAD", "train")]          # "inception": BASELINE configs[3]
 dev = torch.device("cuda", 0)
 torch.manual_seed(123)
-model = sat.ShowAndTell(wl["embed"], wl["hidden"], wl["vocab"], wl["layers"], compute_dtype="bf16").to(dev).train()
+model = sat.ShowAndTell(wl["embed"], wl["hidden"], wl["vocab"], wl["layers"], compute_dtype="bf16",
+                        **({"arch": wl["arch"]} if wl["arch"] else {})).to(dev).train()
 ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
 images, caps, lengths = bench.synth_batch(torch, wl["batch"], wl["vocab"], wl["cap_len"], wl["image"], dev, 123)
 G = model.encoder.lookahead_groups

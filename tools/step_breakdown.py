@@ -25,6 +25,12 @@ def short(n):
     m = re.search(r'conv_aw_kernel<([^>]*)>', n)       # 1x1 convs, weights straight into registers
     if m:
         return 'conv<aw:' + m.group(1).replace(' ', '') + '>'
+    m = re.search(r'conv_ap_kernel<([^>]*)>', n)       # expansion 1x1 convs, weights resident in registers, persistent over row tiles
+    if m:
+        return 'conv<ap:' + m.group(1).replace(' ', '') + '>'
+    for k in ('gram_kernel', 'gram_cov', 'bn_from_gram', 'gemm_bf16_nt'):      # bn3 from the Gram matrix of conv3's input (sat_gram.hip)
+        if k in n:
+            return k
     if 'bn_act_kernel' in n:
         return 'bn_add' if ('_Accum, bool' in n or 'Lb1' in n) else 'bn_relu'
     for k in ['bn_finalize', 'maxpool', 'avgpool', 'image_prep', 'lstm_persist', 'lstm_bwd_step', 'skinny', 'gemm_kernel', 'lstm_bwd_point', 'ce_rows',
