@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 16
+#define SAT_ABI_VERSION 17
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -170,8 +170,17 @@ typedef struct sat_op {
      * and SAT_OP_AVGPOOL are per image: give them N = G * batch.  0 / 1 = ungrouped. */
     int32_t groups;
     int64_t ldc;
+    /* SAT_OP_CONV with flags bit 3 (SAT_CONV_IN_RESIDUAL; bf16, 1x1 / stride 1 on a dense NHWC tensor, w_packed, Cin a multiple of 128
+     * in [256, 2048], Cout of 128): this conv ALSO finishes the bottleneck in front of it.  Its operand is
+     *     y = relu(bn(in0) + in1)        (bn = the input BatchNorm of scale0 / shift0 or stat_acc1 / gamma1 / ...; in1 shaped like in0)
+     * built on its way to LDS -- bit for bit what SAT_OP_BN_ADD_RELU writes -- and y is written to out1 (shaped like in0, per group like
+     * in0) as well: the normalise + add + ReLU launch between conv3 of one bottleneck and conv1 of the next disappears
+     * (models.py:27, train-mode BatchNorm).  out1 may alias in0 when Cout == 128 (or == 256 and the eight-wave variant runs it: the
+     * library checks); it must not alias in1. */
+    void* out1;
 } sat_op;
 #define SAT_CONV_PADW 2
+#define SAT_CONV_IN_RESIDUAL 8
 #define SAT_CONV_GROUP_TABLE 4   /* SAT_OP_CONV flags: scale1 / shift1 are PER GROUP, [G][2][Cout] apart (the table SAT_OP_BN_FROM_GRAM writes), and
                                   * in1 (the residual) is per group like `out`: lets a grouped train-mode program run conv3 with the
                                   * inference epilogue */

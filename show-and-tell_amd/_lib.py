@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -19,6 +19,7 @@ OP_MAXPOOL3S2, OP_AVGPOOL3 = 10, 11
 OP_GRAM, OP_GRAM_COV, OP_GEMM_BF16_NT, OP_BN_FROM_GRAM = 12, 13, 14, 15
 CONV_PADW = 2
 CONV_GROUP_TABLE = 4
+CONV_IN_RESIDUAL = 8
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -53,7 +54,7 @@ class SatOp(C.Structure):
         ("stat_acc", _vp), ("stat_acc1", _vp), ("gamma1", _vp), ("beta1", _vp),
         ("running_mean1", _vp), ("running_var1", _vp), ("w_packed", _vp),
         ("reserved1", C.c_int32 * 2),
-        ("pad_w", C.c_int32), ("groups", C.c_int32), ("ldc", C.c_int64),
+        ("pad_w", C.c_int32), ("groups", C.c_int32), ("ldc", C.c_int64), ("out1", C.c_void_p),
     ]
 
 

@@ -7,7 +7,10 @@ FLAGS="${SAT_EXTRA_FLAGS} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-
 mkdir -p build
 pids=()
 for f in sat_gemm sat_gemm_bf16 sat_conv_glds sat_lstm_persist sat_skinny sat_elementwise sat_attend sat_beam sat_gram sat_host; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ sat_common.h -nt build/$f.o ] || [ sat_internal.h -nt build/$f.o ] || [ sat_conv_xp.inc -nt build/$f.o ] || [ sat_conv_pr.inc -nt build/$f.o ] || [ sat_conv_stem.inc -nt build/$f.o ] || [ sat_conv_pw.inc -nt build/$f.o ] || [ sat_conv_aw.inc -nt build/$f.o ] || [ ../../include/sat_hip.h -nt build/$f.o ]; then
+  stale=0
+  [ -f build/$f.o ] || stale=1
+  for d in $f.hip sat_common.h sat_internal.h ../../include/sat_hip.h sat_conv_*.inc; do [ $d -nt build/$f.o ] && stale=1; done
+  if [ $stale = 1 ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi

@@ -80,6 +80,10 @@ struct ConvArgs {
     // instruction sequence of the ungrouped launch on its batch (same tiles, same summation order, own statistics)
     long gs_a, gs_c, gs_partial, gs_acc, gs_in_acc, gs_in_run;
     long gs_out_tab;         // SAT_CONV_GROUP_TABLE: out_scale / out_shift move by this many floats per group (the table SAT_OP_BN_FROM_GRAM writes), else 0
+    // SAT_CONV_IN_RESIDUAL (conv_ay_kernel): the operand is relu(bn(A) + in_res), built on its way to LDS and written to Y as well
+    // (the previous bottleneck's normalise + add + ReLU inside this bottleneck's conv1); both shaped like A, group stride gs_a
+    const bf16_t* in_res;
+    bf16_t* Y;
 };
 // fixed-point scale of the atomic statistics is SAT_STAT_SCALE (sat_internal.h)
 constexpr double kStatScale = SAT_STAT_SCALE;
@@ -129,6 +133,7 @@ __device__ __forceinline__ ConvArgs group_args(const ConvArgs& q) {
         p.A += g * q.gs_a;
         p.C += g * q.gs_c;
         if (p.residual) p.residual += g * q.gs_c;
+        if (p.in_res) { p.in_res += g * q.gs_a; p.Y += g * q.gs_a; }
         if (p.out_scale) { p.out_scale += g * q.gs_out_tab; p.out_shift += g * q.gs_out_tab; }
         if (p.stat_partial) p.stat_partial += g * q.gs_partial;
         if (p.acc) p.acc += g * q.gs_acc;
@@ -615,7 +620,7 @@ int launch_glds(ConvArgs& a, int groups, hipStream_t s) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows).
 // LDS = S * (BM/8 + BN/8) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem, pw, aw, ap; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel; pw: conv_pw_kernel; aw: conv_aw_kernel
+struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem, pw, aw, ap, ay; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel; pw: conv_pw_kernel; aw: conv_aw_kernel
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128}, {128, 3, 8, 0, 0, 128}, {128, 2, 8, 0, 0, 128}, {64, 4, 8, 0, 0, 128}, {64, 3, 8, 0, 0, 128},
     {64, 2, 8, 0, 0, 128}, {128, 4, 4, 0, 0, 128}, {128, 2, 4, 0, 0, 128}, {64, 3, 4, 0, 0, 128}, {64, 2, 4, 0, 0, 128},
@@ -631,6 +636,8 @@ constexpr Variant kVariants[] = {
     {128, 3, 4, 0, 0, 128, 0, 0, 0, 0, 1},                                                                               // 1x1: activations through registers into LDS, weights straight into registers (sat_conv_aw.inc)
     {256, 3, 8, 0, 0, 128, 0, 0, 0, 0, 2},                                                                               // ... eight waves, 256-column tiles: the activations staged once per row tile
     {128, 2, 4, 0, 0, 128, 0, 0, 0, 0, 0, 1},                                                                            // expansion 1x1 (K = 256): weights resident in registers, the workgroup persistent over row tiles (sat_conv_ap.inc)
+    {128, 2, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 1},                                                                         // conv1 that also finishes the previous bottleneck: operand = relu(bn3(c3) + y), written out as it goes (sat_conv_ay.inc)
+    {256, 2, 8, 0, 0, 128, 0, 0, 0, 0, 0, 0, 2},                                                                         // ... eight waves, 256-column tiles
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
@@ -641,6 +648,7 @@ constexpr int kVariantPr = 29;
 #include "sat_conv_pw.inc"
 #include "sat_conv_aw.inc"
 #include "sat_conv_ap.inc"
+#include "sat_conv_ay.inc"
 
 int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
     switch (v) {
@@ -679,6 +687,8 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 32: return launch_aw<4>(a, groups, s);
         case 33: return launch_aw<8>(a, groups, s);
         case 34: return launch_ap(a, groups, s);
+        case 35: return launch_ay<4>(a, groups, s);
+        case 36: return launch_ay<8>(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -696,7 +706,7 @@ bool signature_matches(int v, int want);
 int stat_signature(int v) {
     const Variant& k = kVariants[v];
     if (k.ap) return 6000;          // (a lane's 64 rows of a tile, the tiles of a worker in order, then the two halves)
-    if (k.aw) return 5000;          // (a lane's 64 rows, then the two halves: the same for the four- and the eight-wave form)
+    if (k.aw || k.ay) return 5000;          // (a lane's 64 rows, then the two halves: the same for the four- and the eight-wave form)
     if (k.pw) return 4000;
     if (k.stem) return 3000;
     if (k.pr) return 2000;
@@ -728,6 +738,11 @@ ConvArgs make_args(const sat_op* op) {
     }
     a.out_scale = op->scale1; a.out_shift = op->shift1;        // inference epilogue: affine (+ residual) (+ ReLU)
     a.residual = (const bf16_t*)op->in1;
+    if (op->flags & SAT_CONV_IN_RESIDUAL) {     // in1 belongs to the INPUT side: operand = relu(bn(in0) + in1), also written to out1
+        a.residual = nullptr;
+        a.in_res = (const bf16_t*)op->in1;
+        a.Y = (bf16_t*)op->out1;
+    }
     a.out_relu = op->flags & 1;
     a.M = op->N * op->Hout * op->Wout; a.N = op->Cout; a.K = op->KH * op->KW * op->Cin;
     a.ldb = a.K; a.ldc = (op->ldc >= op->Cout) ? op->ldc : op->Cout;
@@ -753,6 +768,8 @@ int op_groups(const sat_op* op) { return op->groups > 1 ? op->groups : 1; }
 bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
+    if (k.ay) return ay_ok(a, k.ay == 2 ? 8 : 4);
+    if (a.in_res) return false;                                      // only conv_ay_kernel builds its operand from two tensors
     if (k.ap) return ap_ok(a);
     if (k.aw) return aw_ok(a, k.aw == 2 ? 8 : 4);
     if (k.pw) return pw_ok(a);
@@ -770,6 +787,7 @@ bool variant_ok(int v, const ConvArgs& a) {
 int heuristic_variant(const ConvArgs& a) {
     // 128x128 with a deep ring when it still leaves >= 2 tiles per CU and K is long enough to use the ring;
     // otherwise 128x64 with a shallower ring (more workgroups per CU to overlap prologue/epilogue phases)
+    if (a.in_res) return ay_ok(a, 4) ? 35 : 36;           // the operand built from the raw conv3 tensor and the residual: conv_ay_kernel
     if (a.in_affine && !a.linear) return kVariantPr;      // 3x3 with a fused input BatchNorm: the LDS-resident patch (the builder fuses bn1 only where it can run)
     if (stem_ok(a)) return 30;                            // the op program's stem layout: the persistent stem kernel
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
@@ -786,8 +804,12 @@ int prepare_args(const sat_op* op, int parity, ConvArgs& a) {
     if ((a.out_scale != nullptr) != (a.out_shift != nullptr)) return SAT_ERR_ARG;
     if (a.residual && (!a.out_scale || (const void*)a.residual == (const void*)a.C)) return SAT_ERR_ARG;
     if (a.out_scale && (a.stat_partial || a.acc)) return SAT_ERR_ARG;     // batch statistics and a fixed affine exclude each other
+    if (op->flags & SAT_CONV_IN_RESIDUAL) {
+        if (!a.in_res || !a.Y || !a.in_affine || (((uintptr_t)a.in_res | (uintptr_t)a.Y) & 15)) return SAT_ERR_ARG;
+        if (!ay_ok(a, 4) && !ay_ok(a, 8)) return SAT_ERR_UNSUPPORTED;
+    }
     if (a.in_affine) {
-        if (a.Cin > 512 || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;
+        if ((a.Cin > 512 && !a.in_res) || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;
         if (a.in_acc) {
             if (!a.in_gamma || !a.in_beta || a.in_count < 1) return SAT_ERR_ARG;
             long long* base = (long long*)op->stat_acc1;       // [2 parities][2][Cin]
@@ -850,7 +872,7 @@ static int tune_one(const sat_op* op, int groups, int want_sig, int reps, float*
     if (a.in_affine) {           // ... nor derive from / clear the live accumulators: the neutral table stands in
         a.in_acc = nullptr; a.in_acc_clear = nullptr; a.in_running_mean = nullptr; a.in_running_var = nullptr;
         a.in_scale = scratch; a.in_shift = scratch + kTuneTab;
-        if (a.Cin > 512 || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;
+        if ((a.Cin > 512 && !a.in_res) || a.Cin > kTuneTab || (a.Cin % 64) || (a.KH * a.KW > 32)) return SAT_ERR_UNSUPPORTED;
     }
     std::vector<std::pair<float, int>> timed;
     int rc = SAT_OK;

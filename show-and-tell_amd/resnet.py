@@ -423,6 +423,22 @@ class ConvStackProgram:
         # the next block-output buffer, which the normalise+add pass then transforms in place -- a bottleneck touches two large
         # buffers instead of three, so a stack's live set in layer 3 drops from ~90 to ~65 MB (+0.7 % under look-ahead)
         inplace = training and dtype == L.SAT_BF16
+        # bf16 training, OPT-IN (SAT_DEFER_BN3=1): bn3 + residual add + ReLU of bottleneck k DEFERRED into conv1 of bottleneck k + 1
+        # (conv_ay_kernel, SAT_CONV_IN_RESIDUAL): that conv builds its operand relu(bn3(c3_k) + y_{k-1}) on the way to LDS and writes
+        # y_k out as it goes -- the normalise + add launch and conv1's re-read of the tensor it wrote disappear (bit-identical
+        # results, tests/test_gpu_conv_ay.py).  Eligible: a bottleneck without projection followed by another one in the same layer
+        # whose conv1 the kernel runs (planes a multiple of 128: layers 2-4), and not already fused through the Gram statistics.
+        # MEASURED (round 5, interleaved on one box, profiles/r05_defer_ab.txt): per layer-3 bottleneck 24 + 38 us -> 39.5 us in
+        # sequence (the pass's bytes now stream at the HBM rate under conv1's MFMAs), 8 % fewer bytes per pass, the encoder pipeline
+        # ALONE 2.96 -> 2.87 ms per batch -- and the training step unchanged to 1 % slower (3.41 -> 3.42-3.46 ms): under the
+        # look-ahead the light normalise + add launches already ran beside the other stacks' convs for free, while the fused conv1
+        # holds a conv workgroup's registers and LDS for 15 us longer -- what the step pays for is conv workgroup-time.  Hence opt-in.
+        # SAT_DEFER_INPLACE=1: y_k overwrites the raw conv3 tensor (two large buffers per bottleneck instead of three; only where
+        # one column tile covers conv1's Cout)
+        defer_bn3 = training and dtype == L.SAT_BF16 and os.environ.get("SAT_DEFER_BN3", "0") == "1"
+        defer_inplace = os.environ.get("SAT_DEFER_INPLACE", "0") == "1"
+        self.deferred_blocks = 0
+        pending = None                                   # (raw conv3 tensor, bn3 scale / shift handles) of the bottleneck in front
         blocks_geo = list(zip(stack.blocks(), geo))
         for bi, (blk, (h, w_, h2, w2, inpl, planes, stride)) in enumerate(blocks_geo):
             tm1 = lib.sat_conv_tiles_m(N * h * w_)
@@ -446,7 +462,17 @@ class ConvStackProgram:
                 fused(blk.conv3, blk.bn3, self.a2, ynext, h2, w2, h2, w2, N * h2 * w2, True, resid)
                 y, ynext = ynext, y
                 continue
-            ops.append(std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_))
+            if pending is not None:
+                # this conv1 also finishes the bottleneck in front: operand = relu(bn3(c3) + y), written to the other y buffer
+                c3_prev, s3p, t3p = pending
+                pending = None
+                cv1 = fused_input_bn(std_conv(blk.conv1, c3_prev, self.c1, N, h, w_, h, w_), s3p, t3p)
+                cv1.in1, cv1.out1, cv1.flags = y.data_ptr(), ynext.data_ptr(), cv1.flags | L.CONV_IN_RESIDUAL
+                ops.append(cv1)
+                y, ynext = ynext, y
+                self.deferred_blocks += 1
+            else:
+                ops.append(std_conv(blk.conv1, y, self.c1, N, h, w_, h, w_))
             f, s1, t1 = fin_op(blk.bn1, planes, N * h * w_, tm1)
             add(f)
             pr_geom = (h2 == h and w2 == w_ and planes % 64 == 0 and 128 <= planes <= 512 and w_ <= 31)
@@ -461,6 +487,13 @@ class ConvStackProgram:
             f, s2, t2 = fin_op(blk.bn2, planes, N * h2 * w2, tm2)
             add(f)
             c3buf = ynext if inplace else self.c3
+            nxt = blocks_geo[bi + 1] if bi + 1 < len(blocks_geo) else None
+            defer = (defer_bn3 and blk.downsample is None and nxt is not None and nxt[0].downsample is None and nxt[1][6] == 1 and
+                     nxt[1][5] == planes and nxt[1][4] == planes * 4 and planes % 128 == 0 and planes * 4 <= 2048)
+            if defer:
+                # (in place only where ONE column tile of the consuming conv1 covers its Cout = planes: 128, or 256 with the
+                # eight-wave variant -- the library refuses the aliasing otherwise)
+                c3buf = ynext if (defer_inplace and planes <= 256) else self.c3
             if (gram_bn3 and blk.downsample is None and stride == 1 and inpl == planes * 4 and planes % 128 == 0 and planes <= gram_pmax
                     and bnref.get(s2.data_ptr()) is not None):
                 # bn3's batch statistics from the Gram matrix of conv3's input, then conv3 with bn3 + residual + ReLU in its epilogue
@@ -498,6 +531,8 @@ class ConvStackProgram:
                 self.gram_blocks += 1
                 y, ynext = ynext, y
                 continue
+            if defer and bnref.get(s2.data_ptr()) is None:
+                defer = False
             if fuse_in_bn and planes <= 512 and planes % 64 == 0:
                 # conv3 reads the RAW c2 and applies bn2 + ReLU to its A operand in LDS: a2 never exists in HBM
                 ops.append(fused_input_bn(std_conv(blk.conv3, self.c2, c3buf, N, h2, w2, h2, w2), s2, t2))
@@ -507,6 +542,9 @@ class ConvStackProgram:
                 ops.append(std_conv(blk.conv3, a2buf, c3buf, N, h2, w2, h2, w2))
             f, s3, t3 = fin_op(blk.bn3, planes * 4, N * h2 * w2, tm2)
             add(f)
+            if defer and bnref.get(s3.data_ptr()) is not None:
+                pending = (c3buf, s3, t3)                # y stays y_{k-1}: the next conv1 adds it and writes y_k into ynext
+                continue
             if blk.downsample is not None:
                 ops.append(std_conv(blk.downsample[0], y, self.cd, N, h, w_, h2, w2))
                 f, sd, td_ = fin_op(blk.downsample[1], planes * 4, N * h2 * w2, tm2)

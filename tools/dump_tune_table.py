@@ -41,18 +41,28 @@ def note(msg):
 
 with torch.no_grad():
     images = torch.randn(64, 3, 224, 224, device=dev)
-    model = sat.ShowAndTell(256, 512, 10000, 1, compute_dtype="bf16").to(dev).train()
-    model.encoder._program(images)                       # grouped lead first, then the ungrouped program within its signatures
-    model.encoder.build_lookahead(images)
-    note("resnet152 train: done")
-    for _ in range(8):                                   # running statistics that match the data before the eval-mode programs run
-        model.encoder(images)
-    model.eval()
-    model.encoder._program(images)
-    model.encoder.build_lookahead(images)
-    note("resnet152 eval: done")
-    del model
-    torch.cuda.empty_cache()
+    # the default program form, then the opt-in one (SAT_DEFER_BN3=1: bn3 + add + ReLU inside the next conv1, conv_ay_kernel): its
+    # conv1 geometries carry their own keys
+    for env in ({}, {"SAT_DEFER_BN3": "1"}):
+        os.environ.update(env)
+        model = sat.ShowAndTell(256, 512, 10000, 1, compute_dtype="bf16").to(dev).train()
+        model.encoder._program(images)                   # grouped lead first, then the ungrouped program within its signatures
+        model.encoder.build_lookahead(images)
+        note("resnet152 train %s: done" % (env or ""))
+        for k in env:
+            del os.environ[k]
+        if env:
+            del model
+            torch.cuda.empty_cache()
+            continue
+        for _ in range(8):                               # running statistics that match the data before the eval-mode programs run
+            model.encoder(images)
+        model.eval()
+        model.encoder._program(images)
+        model.encoder.build_lookahead(images)
+        note("resnet152 eval: done")
+        del model
+        torch.cuda.empty_cache()
 
     im299 = torch.randn(64, 3, 299, 299, device=dev)
     model = sat.ShowAndTell(512, 1024, 10000, 2, arch="inception_v3", compute_dtype="bf16").to(dev).train()
