@@ -18,6 +18,31 @@ constexpr int RC = 12;    // 16-byte chunks of a logits row a thread keeps in re
 // a better than b: higher score, ties -> lower flat candidate index (k*V + v)
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
 
+// wave-wide arg-best of (value, index) under `better`, the result in every lane: four DPP row rotations (8, 4, 2, 1: an all-reduce
+// inside each row of 16 lanes -- the operation is commutative and idempotent) and the four row results by readlane
+template <int CTRL>
+__device__ __forceinline__ void argbest_step(float& v, int& i) {
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xf, 0xf, false);
+    if (better(ov, oi, v, i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void wave_argbest(float& v, int& i) {
+    argbest_step<0x128>(v, i);      // row_ror:8
+    argbest_step<0x124>(v, i);      // row_ror:4
+    argbest_step<0x122>(v, i);      // row_ror:2
+    argbest_step<0x121>(v, i);      // row_ror:1
+    float bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    int bi = __builtin_amdgcn_readlane(i, 0);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        const float qv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * q));
+        const int qi = __builtin_amdgcn_readlane(i, 16 * q);
+        if (better(qv, qi, bv, bi)) { bv = qv; bi = qi; }
+    }
+    v = bv;
+    i = bi;
+}
+
 template <int NT>
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
     v = is_max ? wave_max(v) : wave_sum(v);
@@ -63,6 +88,8 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(const float* __restrict__ 
     __shared__ float sh[NW];
     __shared__ float s_rv[NW];
     __shared__ int s_ri[NW];
+    __shared__ float s_cv[NW * KMAX];
+    __shared__ int s_ci[NW * KMAX];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int k = row % K;
     const float base = scores_in[row];
@@ -98,13 +125,17 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < RCN; ++c) m = fmaxf(fmaxf(fmaxf(m, rc[c][0]), fmaxf(rc[c][1], rc[c][2])), rc[c][3]);
         m = block_reduce<NT>(m, true, sh);
+        // exp(x - m) as ONE fma and ONE v_exp_f32 per element (2^(x log2e - m log2e); 1 ulp, arguments <= 0, exp(-inf) = 0 for the
+        // padding): libm's expf is ~8 instructions per element with its range fix-ups, and this loop is a third of the kernel's
+        // instructions
+        const float ml = m * 1.44269504088896340736f;
         float s = 0.0f;
 #pragma unroll
         for (int c = 0; c < RCN; ++c) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s += expf(rc[c][e] - m);       // exp(-inf) = 0 for the padding
+            for (int e = 0; e < 4; ++e) s += __builtin_amdgcn_exp2f(__builtin_fmaf(rc[c][e], 1.44269504088896340736f, -ml));
         }
-        s += expf(xt - m);
+        s += __builtin_amdgcn_exp2f(__builtin_fmaf(xt, 1.44269504088896340736f, -ml));
         s = block_reduce<NT>(s, false, sh);
         const float lse = m + logf(s);
         // candidate scores in place (the f32 expression the step-by-step oracle rounds: base + (x - lse)); -inf stays -inf
@@ -113,50 +144,74 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 4; ++e) rc[c][e] = base + (rc[c][e] - lse);
         xt = base + (xt - lse);
-        // this thread's best (elements in increasing index order, strict > keeps the lowest index among equals)
-        auto local_best = [&](float& bv, int& bi) {
+        // this thread's best TWO (elements in increasing index order: strict > keeps the lower index among equals in front)
+        float v1 = -INFINITY, v2 = -INFINITY;
+        int i1 = INT_MAX, i2 = INT_MAX;
+        auto offer = [&](float xv, int xi) {
+            const bool a = xv > v1, b2 = xv > v2;
+            v2 = a ? v1 : (b2 ? xv : v2);
+            i2 = a ? i1 : (b2 ? xi : i2);
+            v1 = a ? xv : v1;
+            i1 = a ? xi : i1;
+        };
+#pragma unroll
+        for (int c = 0; c < RCN; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) offer(rc[c][e], k * V + 4 * (tid + c * NT) + e);
+        offer(xt, k * V + tail);
+        if (v1 == -INFINITY) i1 = INT_MAX;                   // (padding / -inf logits are no candidates)
+        if (v2 == -INFINITY) i2 = INT_MAX;
+        // the best element of this thread that comes AFTER (pv, pi) in the order (score desc, index asc): the rare third pop
+        auto local_next = [&](float pv, int pi, float& bv, int& bi) {
             bv = -INFINITY;
             bi = INT_MAX;
+            auto see = [&](float xv, int xi) {
+                const bool after = xv < pv || (xv == pv && xi > pi);
+                if (after && xv > bv) { bv = xv; bi = xi; }
+            };
 #pragma unroll
             for (int c = 0; c < RCN; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (rc[c][e] > bv) { bv = rc[c][e]; bi = k * V + 4 * (tid + c * NT) + e; }
-            if (xt > bv) { bv = xt; bi = k * V + tail; }
+                for (int e = 0; e < 4; ++e) see(rc[c][e], k * V + 4 * (tid + c * NT) + e);
+            see(xt, k * V + tail);
         };
-        float mv;
-        int mi;
-        local_best(mv, mi);
+        // Selection without block barriers in the rounds (round 5, second form): every WAVE extracts the K best of its own quarter of
+        // the row -- K rounds of a wave-wide arg-best over the threads' current heads on DPP row rotations + four readlanes (no LDS
+        // crossbar, no barrier); the owner lane pops its head (its second best is at hand; a third pop rescans, rarely) -- then ONE
+        // barrier and wave 0 picks the K best of the NW * K survivors the same way.  The union of the waves' lists contains the row's
+        // K best, and every comparison uses (score desc, flat index asc): the result is exactly the one of block-wide rounds.
+        const int lane = tid & 63, wave = tid >> 6;
+        int pops = 0;
         for (int r = 0; r < K; ++r) {
-            float bv = mv;
-            int bi = mi;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-            }
-            __syncthreads();
-            if ((tid & 63) == 0) { s_rv[tid >> 6] = bv; s_ri[tid >> 6] = bi; }
-            __syncthreads();
-            bv = s_rv[0];
-            bi = s_ri[0];
-            int ww = 0;
-#pragma unroll
-            for (int w = 1; w < NW; ++w)
-                if (better(s_rv[w], s_ri[w], bv, bi)) { bv = s_rv[w]; bi = s_ri[w]; ww = w; }
-            if (tid == 0) { cv_out[r] = bv; ci_out[r] = bi; }
-            if (ww == (tid >> 6) && bi != INT_MAX) {         // (wave-uniform) the winner's wave: its owner strikes it out, finds its next best
-                if (mi == bi) {
-                    const int el = bi - k * V;
-                    if (el == tail) xt = -INFINITY;
-#pragma unroll
-                    for (int c = 0; c < RCN; ++c)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (4 * (tid + c * NT) + e == el) rc[c][e] = -INFINITY;
-                    local_best(mv, mi);
+            float bv = v1;
+            int bi = i1;
+            wave_argbest(bv, bi);
+            if (lane == 0) { s_cv[wave * KMAX + r] = bv; s_ci[wave * KMAX + r] = bi; }
+            if (i1 == bi && bi != INT_MAX) {                 // the owner lane (candidate indexes are unique)
+                if (pops == 0) {
+                    v1 = v2;
+                    i1 = i2;
+                } else {
+                    float nv;
+                    int ni;
+                    local_next(bv, bi, nv, ni);
+                    v1 = nv;
+                    i1 = ni;
                 }
+                ++pops;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const bool has = lane < NW * K;
+            float cv = has ? s_cv[(lane / K) * KMAX + lane % K] : -INFINITY;
+            int ci = has ? s_ci[(lane / K) * KMAX + lane % K] : INT_MAX;
+            for (int r = 0; r < K; ++r) {
+                float bv = cv;
+                int bi = ci;
+                wave_argbest(bv, bi);
+                if (lane == 0) { cv_out[r] = bv; ci_out[r] = bi; }
+                if (ci == bi) { cv = -INFINITY; ci = INT_MAX; }
             }
         }
         return;
@@ -225,43 +280,60 @@ __global__ __launch_bounds__(NT) void beam_row_kernel(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
-                                                        int K, int V, int* __restrict__ parent,
-                                                        int64_t* __restrict__ token, float* __restrict__ scores_out,
-                                                        const float* __restrict__ embed, int E, float* __restrict__ x_next, long ldx) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    float v = -INFINITY;
-    int ix = INT_MAX;
-    if (lane < K * K) {
-        v = cand_val[(long)b * K * K + lane];
-        ix = cand_idx[(long)b * K * K + lane];
-    }
-    for (int r = 0; r < K; ++r) {
-        float bv = v;
-        int bi = ix;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (better(ov, oi, bv, bi)) {
-                bv = ov;
-                bi = oi;
+// One workgroup of 256 threads per image: wave 0 merges (K rounds of a wave-wide arg-best over the image's K * K row candidates), then
+// -- one barrier -- all four waves move the rows of the next step: embedding row of the chosen token and, in the wide decode path, the
+// (h, c) rows of the hypothesis it extends, every row by its own wave with all its loads in flight at once (the copies used to sit
+// inside the merge rounds, one dependent round trip per hypothesis: 6.2 + 4.8 us per step as two launches, 8.0 as one wave)
+__global__ __launch_bounds__(256) void beam_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                         int K, int V, int* __restrict__ parent,
+                                                         int64_t* __restrict__ token, float* __restrict__ scores_out,
+                                                         const float* __restrict__ embed, int E, float* __restrict__ x_next, long ldx,
+                                                         const float* __restrict__ h_src, const float* __restrict__ c_src, int H,
+                                                         float* __restrict__ h_dst, long ldh, float* __restrict__ c_dst) {
+    __shared__ int s_par[KMAX], s_tok[KMAX];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        float v = -INFINITY;
+        int ix = INT_MAX;
+        if (lane < K * K) {
+            v = cand_val[(long)b * K * K + lane];
+            ix = cand_idx[(long)b * K * K + lane];
+        }
+        for (int r = 0; r < K; ++r) {
+            float bv = v;
+            int bi = ix;
+            wave_argbest(bv, bi);                          // (bv, bi) are the same in every lane after the reduction
+            if (ix == bi && bi != INT_MAX) {             // the winner leaves the pool
+                v = -INFINITY;
+                ix = INT_MAX;
+            }
+            const bool ok = bi != INT_MAX;
+            const int par = ok ? bi / V : 0, tok = ok ? bi % V : 0;
+            if (lane == 0) {
+                parent[b * K + r] = par;
+                token[b * K + r] = tok;
+                scores_out[b * K + r] = ok ? bv : -INFINITY;
+                s_par[r] = par;
+                s_tok[r] = tok;
             }
         }
-        if (ix == bi && bi != INT_MAX) {             // the winner leaves the pool
-            v = -INFINITY;
-            ix = INT_MAX;
+    }
+    if (!embed && !h_src) return;                          // (uniform)
+    __syncthreads();
+    for (int r = wave; r < K; r += 4) {
+        const int par = s_par[r], tok = s_tok[r];
+        const long to = (long)(b * K + r);
+        if (embed) {                                       // the next step's input row: embed(token) (models.py:64)
+            const float* src = embed + (long)tok * E;
+            for (int e = lane * 4; e < E; e += 256) *(f32x4*)(x_next + to * ldx + e) = *(const f32x4*)(src + e);
         }
-        const bool ok = bi != INT_MAX;                 // (bv, bi) are the same in every lane after the reduction
-        if (lane == 0) {
-            parent[b * K + r] = ok ? bi / V : 0;
-            token[b * K + r] = ok ? bi % V : 0;
-            scores_out[b * K + r] = ok ? bv : -INFINITY;
-        }
-        if (embed) {                                   // the next step's input row: embed(token) (models.py:64), by the whole wave
-            const float* src = embed + (long)(ok ? bi % V : 0) * E;
-            float* dst = x_next + (long)(b * K + r) * ldx;
-            for (int e = lane * 4; e < E; e += 256) *(f32x4*)(dst + e) = *(const f32x4*)(src + e);
+        if (h_src) {                                       // ... and the LSTM state of the hypothesis it extends
+            const long from = (long)(b * K + par) * H;
+            for (int e = lane * 4; e < H; e += 256) {
+                const f32x4 hv = *(const f32x4*)(h_src + from + e), cv = *(const f32x4*)(c_src + from + e);
+                *(f32x4*)(h_dst + to * ldh + e) = hv;
+                *(f32x4*)(c_dst + to * H + e) = cv;
+            }
         }
     }
 }
@@ -306,13 +378,19 @@ __global__ __launch_bounds__(256) void beam_wcat_kernel(const float* __restrict_
 }
 
 // gates [R][4H] (i, f, g, o pre-activations, both biases in) -> c (in place), h_new: the LSTM cell's pointwise half (models.py:52)
+// (nslab > 1: the gates arrive as K-split partial sums, slab z `slab` floats further on; summed here in slab order)
 __global__ __launch_bounds__(256) void beam_lstm_point_kernel(const float* __restrict__ gates, float* __restrict__ c,
-                                                              float* __restrict__ h_new, int H, long total) {
+                                                              float* __restrict__ h_new, int H, long total, int nslab, long slab) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long row = i / H;
         const int u = (int)(i - row * H);
         const float* g = gates + row * 4 * H;
-        const float gi = sat_sigmoid(g[u]), gf = sat_sigmoid(g[H + u]), gg = sat_tanh(g[2 * H + u]), go = sat_sigmoid(g[3 * H + u]);
+        float a0 = g[u], a1 = g[H + u], a2 = g[2 * H + u], a3 = g[3 * H + u];
+        for (int z = 1; z < nslab; ++z) {
+            const float* gz = g + z * slab;
+            a0 += gz[u]; a1 += gz[H + u]; a2 += gz[2 * H + u]; a3 += gz[3 * H + u];
+        }
+        const float gi = sat_sigmoid(a0), gf = sat_sigmoid(a1), gg = sat_tanh(a2), go = sat_sigmoid(a3);
         const float cn = gf * c[i] + gi * gg;
         c[i] = cn;
         h_new[i] = go * sat_tanh(cn);
@@ -381,8 +459,9 @@ extern "C" int sat_beam_step(const float* logits, int64_t ldl, const float* scor
     hipLaunchKernelGGL(beam_row_kernel<256>, dim3(B * K), dim3(256), 0, s, logits, (long)ldl, scores_in, last_tokens,
                        (long)end_id, K, V, cand_val, cand_idx);
     SAT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, s, cand_val, cand_idx, K, V, parent, token, scores_out,
-                       (const float*)nullptr, 0, (float*)nullptr, 0L);
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(256), 0, s, cand_val, cand_idx, K, V, parent, token, scores_out,
+                       (const float*)nullptr, 0, (float*)nullptr, 0L, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0L,
+                       (float*)nullptr);
     SAT_LAUNCH_CHECK();
     return SAT_OK;
 }
@@ -394,6 +473,7 @@ extern "C" int sat_beam_step(const float* logits, int64_t ldl, const float* scor
 //      log-softmax + top-K, per-image merge (which also gathers the next step's embedding rows), ONE (h, c) re-ordering launch per
 //      layer.  Same kernels, same order, same arithmetic as the step-by-step entry points: bit-identical ids and scores. ----
 static int64_t al256(int64_t n) { return (n + 255) / 256 * 256; }
+constexpr int kBeamKSplitMax = 8;      // K-split slices of the wide LSTM step's gate GEMM (the workspace holds that many [R][4H] slabs)
 
 extern "C" int64_t sat_beam_decode_ws_bytes(int B, int K, int E, int H, int V, int num_layers, int steps) {
     if (B <= 0 || K <= 0 || K > KMAX || E <= 0 || H <= 0 || V <= 0 || num_layers < 1 || steps < 1) return 0;
@@ -401,7 +481,7 @@ extern "C" int64_t sat_beam_decode_ws_bytes(int B, int K, int E, int H, int V, i
     // (+ the wide path's buffers: two [R][E + H] input rows, W_cat [4H][E + H], gates [R][4H])
     return al256(4 * (int64_t)num_layers * R * H * 4) + al256(R * ldl * 4) + 2 * al256(R * 4) + al256(sat_beam_step_ws_bytes(B, K)) +
            al256((int64_t)steps * R * 4) + al256((int64_t)steps * R * 8) + 2 * al256(R * E * 4) +
-           2 * al256(R * (int64_t)(E + H) * 4) + al256(4 * (int64_t)H * (E + H) * 4) + al256(R * 4 * (int64_t)H * 4);
+           2 * al256(R * (int64_t)(E + H) * 4) + al256(4 * (int64_t)H * (E + H) * 4) + al256(kBeamKSplitMax * R * 4 * (int64_t)H * 4);
 }
 
 extern "C" int sat_beam_decode(const float* features, const float* embed, const float* const* lstm_w, int num_layers,
@@ -441,6 +521,20 @@ extern "C" int sat_beam_decode(const float* features, const float* embed, const 
     // re-reads the 6 MB of weights once per 64-row chunk (34 -> ~17 us per step at 320 rows)
     const bool wide = num_layers == 1 && R >= 128 && !(H & 3);
     const long ldx = E + H;
+    // the gate GEMM of a step is small ([R][E + H] x [E + H][4H]: 160 tiles of 64 x 64 at 320 rows): its K axis is dealt over enough
+    // slices to fill the chip's ~512 workgroup slots, the pointwise launch sums the slices in order (measured at 320 rows, 20 steps:
+    // 1 slice 1.82 ms, 2 1.76, 3 1.685, 4 1.73, 6 1.75, 8 1.85 -- profiles/r05_decode_loop.txt); SAT_BEAM_KSPLIT overrides
+    static const int ks_env = [] { const char* e = getenv("SAT_BEAM_KSPLIT"); return e ? atoi(e) : 0; }();
+    int ksplit = 1;
+    if (wide) {
+        const long tiles = (long)sat_cdiv((int)R, 64) * sat_cdiv(4 * H, 64);
+        ksplit = (int)(512 / (tiles > 0 ? tiles : 1));
+        const int nk = sat_cdiv((int)ldx, 32);                 // K-steps of the f32 kernel
+        if (ksplit > nk / 4) ksplit = nk / 4;
+        if (ksplit > kBeamKSplitMax) ksplit = kBeamKSplitMax;
+        if (ksplit < 1) ksplit = 1;
+        if (ks_env >= 1 && ks_env <= kBeamKSplitMax) ksplit = ks_env;
+    }
     if (wide) {
         e = hipMemsetAsync(xh[0], 0, (size_t)(R * ldx * 4), s);                                  // h_{-1} = 0
         if (e != hipSuccess) return (int)e;
@@ -474,12 +568,13 @@ extern "C" int sat_beam_decode(const float* features, const float* embed, const 
         if (wide) {
             float* c = hc + (long)(2 + cur_c[0]) * R * H;
             float* h_new = hc + (long)cur_h[0] * R * H;
-            SAT_TRY(sat_gemm_f32(0, 0, xh[xi], ldx, wcat, ldx, gates, 4L * H, lstm_w[2], lstm_w[3], (int)R, 4 * H, (int)ldx, stream));
+            SAT_TRY(sat_gemm_f32_splitk(0, 0, xh[xi], ldx, wcat, ldx, gates, 4L * H, lstm_w[2], lstm_w[3], (int)R, 4 * H, (int)ldx, ksplit,
+                                        R * 4L * H, stream));
             {
                 const long total = R * H;
                 int grid = sat_cdiv(total, 256);
                 if (grid > 2048) grid = 2048;
-                hipLaunchKernelGGL(beam_lstm_point_kernel, dim3(grid), dim3(256), 0, s, gates, c, h_new, H, total);
+                hipLaunchKernelGGL(beam_lstm_point_kernel, dim3(grid), dim3(256), 0, s, gates, c, h_new, H, total, ksplit, R * 4L * H);
                 SAT_LAUNCH_CHECK();
             }
             inp = h_new;
@@ -502,20 +597,23 @@ extern "C" int sat_beam_decode(const float* features, const float* embed, const 
         hipLaunchKernelGGL(beam_row_kernel<256>, dim3((unsigned)R), dim3(256), 0, s, logits, (long)ldl, sc[si], last, (long)end_id, K, V,
                            cand_val, cand_idx);
         SAT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, s, cand_val, cand_idx, K, V, par, tok, sc[1 - si], embed, E,
-                           wide ? xh[1 - xi] : xe, wide ? ldx : (long)E);
-        SAT_LAUNCH_CHECK();
-        si = 1 - si;
-        if (wide) {                                            // (h, c) by parent: h straight into the next input row's h half
-            const long total = R * H;
-            int grid = sat_cdiv(2 * total, 256);
-            if (grid > 2048) grid = 2048;
-            hipLaunchKernelGGL(beam_gather2_kernel, dim3(grid), dim3(256), 0, s, hc + (long)cur_h[0] * R * H, hc + (long)(2 + cur_c[0]) * R * H,
-                               par, K, H, total, xh[1 - xi] + E, ldx, hc + (long)(2 + 1 - cur_c[0]) * R * H);
+        if (wide) {
+            // ... the merge wave also moves (h, c) by parent: h straight into the next input row's h half (one launch fewer per step)
+            hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(256), 0, s, cand_val, cand_idx, K, V, par, tok, sc[1 - si], embed, E,
+                               xh[1 - xi], ldx, (const float*)(hc + (long)cur_h[0] * R * H), (const float*)(hc + (long)(2 + cur_c[0]) * R * H), H,
+                               xh[1 - xi] + E, ldx, hc + (long)(2 + 1 - cur_c[0]) * R * H);
             SAT_LAUNCH_CHECK();
+            si = 1 - si;
             cur_c[0] = 1 - cur_c[0];
             xi = 1 - xi;
-        } else if (K > 1) {
+            x = xe;
+            continue;
+        }
+        hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(256), 0, s, cand_val, cand_idx, K, V, par, tok, sc[1 - si], embed, E, xe, (long)E,
+                           (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, 0L, (float*)nullptr);
+        SAT_LAUNCH_CHECK();
+        si = 1 - si;
+        if (K > 1) {
             for (int l = 0; l < num_layers; ++l) {
                 float* base = hc + (long)l * 4 * R * H;
                 const long total = R * H;

@@ -120,7 +120,8 @@ class EncoderCNN(nn.Module):
         # (`ConvStackProgram(groups=G)`: every launch covers G batches, per-batch BatchNorm statistics, results bit-identical per
         # batch) -- half the launch boundaries and twice the workgroups per launch of the frozen stack.  1 = one program per batch.
         env_g = os.environ.get("SAT_LOOKAHEAD_GROUPS")
-        self.lookahead_groups = max(1, int(env_g)) if env_g else self.LOOKAHEAD_GROUPS
+        arch_name = arch if isinstance(arch, str) else ""
+        self.lookahead_groups = max(1, int(env_g)) if env_g else self.LOOKAHEAD_GROUPS_BY_ARCH.get(arch_name, self.LOOKAHEAD_GROUPS)
         env = os.environ.get("SAT_LOOKAHEAD_DEPTH")
         self.lookahead_depth = int(env) if env else self.LOOKAHEAD_DEPTH.get(arch if isinstance(arch, str) else "",
                                                                               3 * self.lookahead_groups)
@@ -207,8 +208,14 @@ class EncoderCNN(nn.Module):
     # stacks in flight.  Measured on MI355X at batch 64, per stack: 5.68 ms alone, 4.40 with two in flight, 4.33 with three (with
     # 8 hardware queues; 4.86 with HIP's default 4, where the third stream shares a queue)
     # whole ResNet-152 step: 5.25 ms at depth 2, 5.10 at depth 3, 5.38 at depth 4; Inception-v3 299x299: 5.68 at 2, 5.98 at 3
-    LOOKAHEAD_DEPTH = {"inception_v3": 4}      # (two grouped runs of two batches in flight; round 4: two single stacks)
+    # Inception-v3 (configs[3]): THREE batches per launch, two runs in flight -- its launches are smaller than ResNet-152's (94 convs, many
+    # on 17 x 17 and 8 x 8 maps), so they gain more from a third batch per launch, and its step is bound by the decoder (two LSTM layers
+    # of hidden 1024), which leaves the Infinity Cache room for six batches of activations (round 5, one box, interleaved,
+    # tools/run_gpu_inception_g.sh: G = 2 / depth 4 14152 img/s, conv launches 0.132 of peak; G = 3 / depth 6 14368, 0.143; G = 4 / depth 8
+    # 14097, 0.150; G = 4 / depth 4 12622)
+    LOOKAHEAD_DEPTH = {"inception_v3": 6}
     LOOKAHEAD_GROUPS = 2
+    LOOKAHEAD_GROUPS_BY_ARCH = {"inception_v3": 3}
 
     # Look-ahead RUN SLOTS: at most `lookahead_depth // lookahead_groups` op-program runs are in flight (3 by default: more than
     # three side streams beside the main one cost a hardware queue), each on its slot's side stream; a slot holds a

@@ -202,30 +202,32 @@ def test_cfg4_train_step_inception_encoder_two_layer_lstm_vs_oracle():
 
 @pytest.mark.timeout(600)
 def test_inception_grouped_lookahead_is_bitwise_the_sequential_run():
-    """BASELINE configs[3] under the look-ahead: two batches through ONE grouped Inception program run (sat_op.groups = 2: every conv,
-    statistics reducer and normalise+ReLU launch -- the channel-slice ones included -- covers both batches, the pools and the image
-    prep see 2 x N images) against each batch's own ungrouped run: pooled features and every BatchNorm's running statistics bit for
-    bit (models.py:27 with BatchNorm2d in train mode; per-batch statistics).  Then the eval-mode form (the batches concatenate)."""
+    """BASELINE configs[3] under the look-ahead: three batches (the Inception default since round 5) through ONE grouped Inception
+    program run (sat_op.groups = 3: every conv, statistics reducer and normalise+ReLU launch -- the channel-slice ones included -- covers
+    all of them, the pools and the image prep see 3 x N images) against each batch's own ungrouped run: pooled features and every
+    BatchNorm's running statistics bit for bit (models.py:27 with BatchNorm2d in train mode; per-batch statistics).  Then the eval-mode
+    form (the batches concatenate)."""
     enc, _, _ = _encoder("bf16", seed=12)
     enc.train()
     g = torch.Generator().manual_seed(13)
-    a, b = torch.randn(4, 3, 299, 299, generator=g).cuda(), torch.randn(4, 3, 299, 299, generator=g).cuda()
-    assert enc.lookahead_groups == 2
+    a, b, c = (torch.randn(4, 3, 299, 299, generator=g).cuda() for _ in range(3))
+    assert enc.lookahead_groups == 3 and enc.lookahead_depth == 6
     with torch.no_grad():
-        assert enc.prefetch_many([a, b]) == 2
-        assert enc._inflight[0]["prog"].groups == 2
-        pa, pb = enc.pooled_features(a).clone(), enc.pooled_features(b).clone()
+        assert enc.prefetch_many([a, b, c]) == 3
+        assert enc._inflight[0]["prog"].groups == 3
+        pa, pb, pc = (enc.pooled_features(x).clone() for x in (a, b, c))
     sd = {k: v.clone() for k, v in enc.state_dict().items()}
     enc2, _, _ = _encoder("bf16", seed=12)
     enc2.train()
     with torch.no_grad():
-        qa, qb = enc2.pooled_features(a).clone(), enc2.pooled_features(b).clone()
-    assert torch.isfinite(pa).all() and torch.equal(pa, qa) and torch.equal(pb, qb)
+        qa, qb, qc = (enc2.pooled_features(x).clone() for x in (a, b, c))
+    assert torch.isfinite(pa).all() and torch.equal(pa, qa) and torch.equal(pb, qb) and torch.equal(pc, qc)
     for k, v in enc2.state_dict().items():
         assert torch.equal(v, sd[k]), k
     enc.eval(), enc2.eval()
     with torch.no_grad():
-        assert enc.prefetch_many([a, b]) == 2
-        ea, eb_ = enc.pooled_features(a).clone(), enc.pooled_features(b).clone()
-        fa, fb = enc2.pooled_features(a).clone(), enc2.pooled_features(b).clone()
+        assert enc.prefetch_many([a, b, c]) == 3
+        ea, eb_, ec = (enc.pooled_features(x).clone() for x in (a, b, c))
+        fa, fb, fc = (enc2.pooled_features(x).clone() for x in (a, b, c))
+    assert torch.equal(ec, fc)
     assert torch.equal(ea, fa) and torch.equal(eb_, fb)
