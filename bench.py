@@ -21,7 +21,6 @@ batch is fixed.  Prints ONE JSON line on rank 0 (contract in the task statement)
 """
 import argparse
 import importlib
-import contextlib
 import json
 import os
 import socket
@@ -565,18 +564,11 @@ def main():
     batches = [images] + [synth_batch(torch, wl["batch"], wl["vocab"], wl["cap_len"], wl["image"], dev, 977 * (k + 1) + rank)[0]
                           for k in range(nb - 1)]
 
-    # (experiment knob: SAT_MAIN_STREAM_PRIORITY=-1 runs the steps on a high-priority stream instead of the default one)
-    prio = os.environ.get("SAT_MAIN_STREAM_PRIORITY")
-    main_stream = torch.cuda.Stream(device=dev, priority=int(prio)) if prio else None
-
     def run_steps(n):
         out = None
-        if main_stream is not None:
-            main_stream.wait_stream(torch.cuda.current_stream(dev))
-        with (torch.cuda.stream(main_stream) if main_stream is not None else contextlib.nullcontext()):
-            for i in range(n):
-                nxt = [batches[j % nb] for j in range(i + 1, i + 1 + depth) if j < n] if args.lookahead else None
-                out = dp.step((batches[i % nb], caps, lengths), global_tokens, next_images=nxt or None)
+        for i in range(n):
+            nxt = [batches[j % nb] for j in range(i + 1, i + 1 + depth) if j < n] if args.lookahead else None
+            out = dp.step((batches[i % nb], caps, lengths), global_tokens, next_images=nxt or None)
         return out
 
     if args.lookahead:

@@ -326,10 +326,6 @@ template <int AMODE, int BMODE>
 int launch_f32_auto(GemmArgs& a, hipStream_t s) {
     // fill the 256 CUs: fall to smaller tiles when the big ones leave most of the chip idle
     const int ks = a.ksplit < 1 ? 1 : a.ksplit;
-    static const int force = [] { const char* e = getenv("SAT_GEMM_F32_TILE"); return e ? atoi(e) : 0; }();      // experiment knob
-    if (force == 64) return launch<float, 64, 64, AMODE, BMODE>(a, s);
-    if (force == 12864) return launch<float, 128, 64, AMODE, BMODE>(a, s);
-    if (force == 128) return launch<float, 128, 128, AMODE, BMODE>(a, s);
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128) * ks;
     const long t12864 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 64) * ks;
     if (t128 >= 384) return launch<float, 128, 128, AMODE, BMODE>(a, s);
