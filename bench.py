@@ -375,7 +375,9 @@ def lstm_roofline(torch, sat, wl, reps=30):
 
 
 def vocab_step_roofline(torch, sat, wl, rows, reps=30):
-    """The decode loop's dominant kernel: the vocab projection of ONE step over `rows` hypotheses (exact-f32 MFMA)."""
+    """The decode loop's dominant kernel: the vocab projection of ONE step over `rows` hypotheses -- the kernel the loop runs: with
+    >= 128 rows (beam decode) the three-way bf16 split on the bf16 pipe (sat_gemm_f32x3: six bf16 products per f32 product), with
+    fewer (greedy) the exact-f32 MFMA GEMM."""
     L = sat._lib
     lib = L.load()
     H, V = wl["hidden"], wl["vocab"]
@@ -385,9 +387,16 @@ def vocab_step_roofline(torch, sat, wl, rows, reps=30):
     b = torch.zeros(V, device="cuda")
     out = torch.zeros(rows, ldl, device="cuda")
     st = L.stream()
+    x3 = rows >= 128 and os.environ.get("SAT_BEAM_X3", "1") != "0" and lib.sat_gemm_f32x3_packed_bytes(V, H) > 0 and V % 4 == 0
+    if x3:
+        packed = torch.empty(lib.sat_gemm_f32x3_packed_bytes(V, H), dtype=torch.uint8, device="cuda")
+        L.check(lib.sat_gemm_f32x3_pack(w.data_ptr(), V, H, packed.data_ptr(), st), "sat_gemm_f32x3_pack")
 
-    def fn():
-        L.check(lib.sat_vocab_logits_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), rows, H, V, out.data_ptr(), ldl, st), "sat_vocab_logits_fwd")
+        def fn():
+            L.check(lib.sat_gemm_f32x3(x.data_ptr(), H, packed.data_ptr(), b.data_ptr(), out.data_ptr(), ldl, rows, V, H, st), "sat_gemm_f32x3")
+    else:
+        def fn():
+            L.check(lib.sat_vocab_logits_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), rows, H, V, out.data_ptr(), ldl, st), "sat_vocab_logits_fwd")
 
     for _ in range(3):
         fn()
@@ -399,8 +408,17 @@ def vocab_step_roofline(torch, sat, wl, rows, reps=30):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
-    gf = 2.0 * rows * H * V / 1e9
+    gf = 2.0 * rows * H * V / 1e9                         # the f32 product's flops
     nbytes = 4.0 * (V * H + rows * H + rows * V)
+    if x3:
+        nbytes = 6.0 * V * H + 4.0 * (rows * H + rows * V)      # three bf16 copies of the weights
+        return {"kernel": "sat_gemm_f32x3 of one decode step: [%d x %d] x [%d x %d]^T, f32 accuracy from a three-way bf16 split of both operands "
+                          "(6 bf16 MFMA products per f32 product, hi*hi and the corrections in separate f32 accumulators)" % (rows, H, V, H),
+                "bound": "mfma", "achieved": round(6.0 * gf / (us * 1e-6) / 1e3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(6.0 * gf / (us * 1e-6) / 1e3 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(us, 2),
+                "executed_bf16_gflop_per_launch": round(6.0 * gf, 3), "algorithmic_gflop_per_launch": round(gf, 3),
+                "f32_product_tflops": round(gf / (us * 1e-6) / 1e3, 2), "f32_product_frac_of_f32_mfma_peak": round(gf / (us * 1e-6) / 1e3 / PEAK_F32_TFLOPS, 4),
+                "algorithmic_bytes_per_launch": int(nbytes), "gbytes_per_s": round(nbytes / (us * 1e-6) / 1e9, 1)}
     return {"kernel": "sat_vocab_logits_fwd of one decode step: [%d x %d] x [%d x %d]^T, exact-f32 MFMA" % (rows, H, V, H),
             "bound": "mfma", "achieved": round(gf / (us * 1e-6) / 1e3, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(gf / (us * 1e-6) / 1e3 / PEAK_F32_TFLOPS, 4), "avg_launch_us": round(us, 2),

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SAT_ABI_VERSION 17
+#define SAT_ABI_VERSION 18
 
 #define SAT_OK 0
 #define SAT_ERR_ARG 1001
@@ -390,6 +390,16 @@ int sat_vocab_ce_fwd(const float* Hs /*[N,H]*/, const float* w /*[V,H]*/, const 
 int sat_vocab_ce_bwd(const float* dlogits /*[N,ldl]*/, int64_t ldl, const float* Hs, const float* w, int N, int H, int V,
                      float* dw, float* db, float* dHs, float* workspace, int64_t ws_bytes, sat_stream_t stream);
 int64_t sat_vocab_ce_bwd_ws_bytes(int N, int H, int V);
+/* f32 GEMM on the bf16 matrix pipe by a three-way bf16 split of both operands (hi + mid + lo, six products, hi*hi and the corrections
+ * in separate f32 accumulators): the accuracy of an f32 GEMM -- not its bit pattern -- at 6 / 16 of the f32 pipe's cost.  For weights
+ * that stay fixed over many calls (the vocab projection of the beam decode loop, models.py:53 / :63): sat_gemm_f32x3_pack splits W
+ * [N][K] f32 once into its fragment-ordered copy (sat_gemm_f32x3_packed_bytes(N, K) bytes; 0 = shape not supported: K % 128 == 0,
+ * K >= 256), sat_gemm_f32x3 computes C[M][ldc] = A[M][lda] * W^T + bias (N % 4 == 0, lda % 4 == 0, ldc % 4 == 0). */
+int64_t sat_gemm_f32x3_packed_bytes(int N, int K);
+int sat_gemm_f32x3_pack(const float* W, int N, int K, void* packed, sat_stream_t stream);
+int sat_gemm_f32x3(const float* A, int64_t lda, const void* packed, const float* bias, float* C, int64_t ldc, int M, int N, int K,
+                   sat_stream_t stream);
+
 /* split-K variant of sat_gemm_f32: K-steps dealt to ksplit slices, slice z writes C + z*slab_stride (bias in slice 0);
  * sat_sum_slabs_f32 adds the slices in fixed order. */
 int sat_gemm_f32_splitk(int amode, int bmode, const float* A, int64_t lda, const float* B, int64_t ldb,

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAT_LIB") or os.path.join(_HERE, "libsat_hip.so")    # SAT_LIB: A/B another build of the same ABI
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 SAT_F32, SAT_BF16 = 0, 1
 OP_IMAGE_PREP, OP_CONV, OP_BN_FINALIZE, OP_BN_RELU, OP_BN_ADD_RELU, OP_BN_RELU_MAXPOOL, OP_AVGPOOL = 1, 2, 3, 4, 5, 6, 7
 
@@ -115,6 +115,9 @@ SIGNATURES = {
     "sat_vocab_ce_bwd": (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sat_vocab_ce_bwd_ws_bytes": (_i64, [_i, _i, _i]),
     "sat_gemm_f32_splitk": (_i, [_i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i64, _vp]),
+    "sat_gemm_f32x3_packed_bytes": (_i64, [_i, _i]),
+    "sat_gemm_f32x3_pack": (_i, [_vp, _i, _i, _vp, _vp]),
+    "sat_gemm_f32x3": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "sat_sum_slabs_f32": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
     "sat_skinny_gemm_f32": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
     "sat_skinny_gemm_ws_bytes": (_i64, [_i, _i, _i]),

@@ -479,7 +479,9 @@ extern "C" int64_t sat_beam_decode_ws_bytes(int B, int K, int E, int H, int V, i
     if (B <= 0 || K <= 0 || K > KMAX || E <= 0 || H <= 0 || V <= 0 || num_layers < 1 || steps < 1) return 0;
     const int64_t R = (int64_t)B * K, ldl = (V + 3) / 4 * 4;
     // (+ the wide path's buffers: two [R][E + H] input rows, W_cat [4H][E + H], gates [R][4H])
-    return al256(4 * (int64_t)num_layers * R * H * 4) + al256(R * ldl * 4) + 2 * al256(R * 4) + al256(sat_beam_step_ws_bytes(B, K)) +
+    // (+ the vocab projection's weights split three ways for the bf16 pipe, when the wide path runs it: sat_gemm_f32x3)
+    return al256(sat_gemm_f32x3_packed_bytes(V, H)) +
+           al256(4 * (int64_t)num_layers * R * H * 4) + al256(R * ldl * 4) + 2 * al256(R * 4) + al256(sat_beam_step_ws_bytes(B, K)) +
            al256((int64_t)steps * R * 4) + al256((int64_t)steps * R * 8) + 2 * al256(R * E * 4) +
            2 * al256(R * (int64_t)(E + H) * 4) + al256(4 * (int64_t)H * (E + H) * 4) + al256(kBeamKSplitMax * R * 4 * (int64_t)H * 4);
 }
@@ -513,7 +515,8 @@ extern "C" int sat_beam_decode(const float* features, const float* embed, const 
     xh[0] = (float*)w; w += al256(R * (int64_t)(E + H) * 4);
     xh[1] = (float*)w; w += al256(R * (int64_t)(E + H) * 4);
     float* wcat = (float*)w; w += al256(4 * (int64_t)H * (E + H) * 4);
-    float* gates = (float*)w;
+    float* gates = (float*)w; w += al256(kBeamKSplitMax * R * 4 * (int64_t)H * 4);
+    void* lin_split = w;                                       // [V128][H] x 3 bf16, fragment ordered (sat_gemm_f32x3_pack)
     hipError_t e = hipMemsetAsync(hc, 0, (size_t)(4 * (int64_t)num_layers * R * H * 4), s);      // h = c = 0
     if (e != hipSuccess) return (int)e;
     // WIDE steps (round 5): with one LSTM layer and >= 128 rows the step's gates are ONE LDS-tiled exact-f32 MFMA GEMM over the
@@ -535,6 +538,12 @@ extern "C" int sat_beam_decode(const float* features, const float* embed, const 
         if (ksplit < 1) ksplit = 1;
         if (ks_env >= 1 && ks_env <= kBeamKSplitMax) ksplit = ks_env;
     }
+    // WIDE projection (round 5): with >= 128 rows the vocab projection -- half of a step on the exact-f32 pipe -- runs on the bf16
+    // pipe from a three-way split of both operands (sat_gemm_x3.hip: f32 accuracy, not the f32 pipe's bit pattern; the weights are
+    // split once per call).  SAT_BEAM_X3=0: the exact-f32 pipe
+    static const bool x3_env = [] { const char* v = getenv("SAT_BEAM_X3"); return !(v && v[0] == '0'); }();
+    const bool x3 = wide && x3_env && sat_gemm_f32x3_packed_bytes(V, H) > 0 && !(V & 3);
+    if (x3) SAT_TRY(sat_gemm_f32x3_pack(lin_w, V, H, lin_split, stream));
     if (wide) {
         e = hipMemsetAsync(xh[0], 0, (size_t)(R * ldx * 4), s);                                  // h_{-1} = 0
         if (e != hipSuccess) return (int)e;
@@ -590,7 +599,8 @@ extern "C" int sat_beam_decode(const float* features, const float* embed, const 
             cur_h[l] = 1 - cur_h[l];
             inp = h_out;
         }
-        SAT_TRY(sat_vocab_logits_fwd(inp, lin_w, lin_b, (int)R, H, V, logits, ldl, stream));
+        if (x3) SAT_TRY(sat_gemm_f32x3(inp, H, lin_split, lin_b, logits, ldl, (int)R, V, H, stream));
+        else SAT_TRY(sat_vocab_logits_fwd(inp, lin_w, lin_b, (int)R, H, V, logits, ldl, stream));
         int32_t* par = parents + (long)i * R;
         int64_t* tok = tokens + (long)i * R;
         const int64_t* last = (i > 0 && end_id >= 0) ? tok - R : (const int64_t*)nullptr;

@@ -204,6 +204,32 @@ def test_beam_search_matches_oracle(golden_dir, name, K, end_id):
     assert torch.equal(best, ids[:, 0])
 
 
+def test_wide_beam_decode_matches_oracle():
+    """the WIDE decode path (>= 128 hypothesis rows, one LSTM layer: the gate GEMM over [x | h] dealt over K slices, the vocab
+    projection on the bf16 pipe from a three-way split of both operands -- sat_gemm_x3.hip -- the merge launch moving (h, c)) against
+    the CPU oracle: ids bit-exact, scores to 1e-4; then once more in a fresh process on the exact-f32 pipe (SAT_BEAM_X3=0)"""
+    gen = torch.Generator().manual_seed(99)
+    E, H, V, B, K = 64, 256, 1000, 32, 5
+    params = OD.init_decoder_params(E, H, V, 1, generator=gen)
+    params["linear.weight"] = params["linear.weight"] * 6.0      # a trained projection separates its logits: no 1e-6 ties
+    feats = torch.randn(B, E, generator=gen)
+    dec = sat.DecoderRNN(E, H, V, 1)
+    dec.load_state_dict(params)
+    dec.cuda().eval()
+    ref_ids, ref_scores = OD.beam_search(params, feats, K, 1, end_id=2)
+    ids, scores = dec.sample_beam(feats.cuda(), beam_size=K, end_id=2, return_all=True)
+    assert np.array_equal(ids.cpu().numpy(), ref_ids.numpy())
+    np.testing.assert_allclose(scores.cpu().numpy(), ref_scores.numpy(), rtol=0, atol=1e-4)
+    if os.environ.get("SAT_BEAM_X3") != "0":
+        import subprocess
+        import sys
+        here = os.path.abspath(__file__)
+        r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k", "test_wide_beam_decode_matches_oracle"],
+                           env=dict(os.environ, SAT_BEAM_X3="0"), capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(here)))
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_beam_step_ties_dead_and_finished_hypotheses():
     """sat_beam_step on hand-made logits: exact ties resolve to the lower k*V+v, -inf hypotheses never win,
     a finished hypothesis continues only with end_id at unchanged score"""
