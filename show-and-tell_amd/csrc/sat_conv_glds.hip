@@ -620,7 +620,7 @@ int launch_glds(ConvArgs& a, int groups, hipStream_t s) {
 
 // kernel variants: (tile width, ring stages, waves, wave specialisation, fragment prefetch, tile rows).
 // LDS = S * (BM/8 + BN/8) KB (+ the table) decides workgroups per CU.
-struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem, pw, aw, ap, ay; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel; pw: conv_pw_kernel; aw: conv_aw_kernel
+struct Variant { int bn, s, nw, spec, pf, bm, xp, pr, stem, pw, aw, ap, ay, rs; };  // xp: conv_xp_kernel with xp column tiles per workgroup; pr: conv_pr_kernel; stem: conv_stem_kernel; pw: conv_pw_kernel; aw: conv_aw_kernel
 constexpr Variant kVariants[] = {
     {128, 4, 8, 0, 0, 128}, {128, 3, 8, 0, 0, 128}, {128, 2, 8, 0, 0, 128}, {64, 4, 8, 0, 0, 128}, {64, 3, 8, 0, 0, 128},
     {64, 2, 8, 0, 0, 128}, {128, 4, 4, 0, 0, 128}, {128, 2, 4, 0, 0, 128}, {64, 3, 4, 0, 0, 128}, {64, 2, 4, 0, 0, 128},
@@ -638,6 +638,7 @@ constexpr Variant kVariants[] = {
     {128, 2, 4, 0, 0, 128, 0, 0, 0, 0, 0, 1},                                                                            // expansion 1x1 (K = 256): weights resident in registers, the workgroup persistent over row tiles (sat_conv_ap.inc)
     {128, 2, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 1},                                                                         // conv1 that also finishes the previous bottleneck: operand = relu(bn3(c3) + y), written out as it goes (sat_conv_ay.inc)
     {256, 2, 8, 0, 0, 128, 0, 0, 0, 0, 0, 0, 2},                                                                         // ... eight waves, 256-column tiles
+    {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 1},                                                                       // 3x3 / stride 1 over 32 channels on large maps (Inception stem): weights in registers, whole input rows in LDS (sat_conv_rs.inc)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
@@ -649,6 +650,7 @@ constexpr int kVariantPr = 29;
 #include "sat_conv_aw.inc"
 #include "sat_conv_ap.inc"
 #include "sat_conv_ay.inc"
+#include "sat_conv_rs.inc"
 
 int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
     switch (v) {
@@ -689,6 +691,7 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 34: return launch_ap(a, groups, s);
         case 35: return launch_ay<4>(a, groups, s);
         case 36: return launch_ay<8>(a, groups, s);
+        case 37: return launch_rs(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -705,6 +708,7 @@ bool signature_matches(int v, int want);
 
 int stat_signature(int v) {
     const Variant& k = kVariants[v];
+    if (k.rs) return 7000;          // (a wave's 32 rows, then the four waves in order)
     if (k.ap) return 6000;          // (a lane's 64 rows of a tile, the tiles of a worker in order, then the two halves)
     if (k.aw || k.ay) return 5000;          // (a lane's 64 rows, then the two halves: the same for the four- and the eight-wave form)
     if (k.pw) return 4000;
@@ -769,7 +773,8 @@ bool variant_ok(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const Variant& k = kVariants[v];
     if (k.ay) return ay_ok(a, k.ay == 2 ? 8 : 4);
-    if (a.in_res) return false;                                      // only conv_ay_kernel builds its operand from two tensors
+    if (a.in_res) return false;
+    if (k.rs) return rs_ok(a);                                      // only conv_ay_kernel builds its operand from two tensors
     if (k.ap) return ap_ok(a);
     if (k.aw) return aw_ok(a, k.aw == 2 ? 8 : 4);
     if (k.pw) return pw_ok(a);
@@ -790,6 +795,7 @@ int heuristic_variant(const ConvArgs& a) {
     if (a.in_res) return ay_ok(a, 4) ? 35 : 36;           // the operand built from the raw conv3 tensor and the residual: conv_ay_kernel
     if (a.in_affine && !a.linear) return kVariantPr;      // 3x3 with a fused input BatchNorm: the LDS-resident patch (the builder fuses bn1 only where it can run)
     if (stem_ok(a)) return 30;                            // the op program's stem layout: the persistent stem kernel
+    if (rs_ok(a)) return 37;                              // 3x3 over 32 channels on a large map (Inception stem): whole input rows in LDS
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const int nk = sat_cdiv(a.K, 64);
     if (a.N > 64 && t128 >= 512) return nk <= 4 ? 2 : 0;

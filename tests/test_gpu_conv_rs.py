@@ -1,0 +1,102 @@
+"""GPU: conv_rs_kernel (variant 38, csrc/sat_conv_rs.inc) -- the 3 x 3 / stride 1 convs over 32 channels of the Inception-v3 stem
+(Conv2d_2a_3x3: 32 -> 32 without padding, Conv2d_2b_3x3: 32 -> 64 with padding 1; BASELINE configs[3]) with the weights in registers and
+whole input rows in LDS -- against the ring kernel (variant 1: same MFMA, same K order, so the output tensor is BITWISE equal; the column
+sums to rounding) and the f64 definition: the stem's own map sizes at a small batch, maps whose rows are barely 128 pixels wide, tiles that
+straddle two rows and two images, a ragged last tile, statistics as slabs / integer atomics / none, grouped."""
+import ctypes as C
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_kernels import _conv_op, cu, st, sync
+
+pytestmark = pytest.mark.gpu
+sat = importlib.import_module("show-and-tell_amd")
+L = sat._lib
+RS = 38
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    return L.load()
+
+
+@pytest.mark.parametrize("mode", ["slab", "atomic", "none"])
+@pytest.mark.parametrize("N,H,W,Cout,pad", [(2, 149, 149, 32, 0), (2, 147, 147, 64, 1), (1, 5, 131, 32, 0), (3, 4, 128, 64, 1), (1, 3, 300, 64, 0)])
+def test_conv_rs_is_bit_identical_to_the_ring_kernel(lib, N, H, W, Cout, pad, mode):
+    Cin = 32
+    g = torch.Generator().manual_seed(N * 13 + W + Cout)
+    x = (torch.randn(N, Cin, H, W, generator=g) * 1.5 + 0.2).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, 1, pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+
+    def run(v):
+        o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, pad, stats=(mode == "slab"))
+        o.variant = v
+        extra = {}
+        if mode == "atomic":
+            extra["acc"] = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc = extra["acc"].data_ptr()
+        ops = (L.SatOp * 1)(o)
+        L.check(lib.sat_run_ops_parity(ops, 1, 0, st()))
+        sync()
+        return keep, extra
+
+    want, wx = run(1)
+    got, gx = run(RS)
+    assert torch.isfinite(got[2].float()).all()
+    assert torch.equal(got[2], want[2])
+    assert (got[2].float().cpu().double() - ref).abs().max().item() < 3e-2 + 4e-3 * ref.abs().max().item()
+    if mode == "slab":
+        torch.testing.assert_close(got[3].sum(0), want[3].sum(0), rtol=1e-4, atol=2e-2)
+        acc_f = got[2].float().cpu().double()
+        torch.testing.assert_close(got[3].sum(0)[0].cpu().double(), ref.sum(0), rtol=1e-3, atol=1e-5 * ref.shape[0] + 2e-2)
+        del acc_f
+    elif mode == "atomic":
+        torch.testing.assert_close(gx["acc"].double() / 2 ** 22, wx["acc"].double() / 2 ** 22, rtol=1e-4, atol=2e-2)
+        assert int(gx["acc"][1].abs().sum()) == 0
+
+
+def test_conv_rs_is_the_default_for_its_geometry_and_runs_grouped(lib):
+    """no table entry: sat_conv_default_variant names it; two groups in one launch = each group's own launch, bit for bit"""
+    N, H, W, Cin, Cout = 2, 6, 140, 32, 64
+    g = torch.Generator().manual_seed(5)
+    xs = [(torch.randn(N, H, W, Cin, generator=g) + 0.1).bfloat16() for _ in range(2)]
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / 17.0).bfloat16()
+    o, keep, _ = _conv_op(L.SAT_BF16, xs[0].float(), w.float(), 1, 1, stats=False)
+    assert lib.sat_conv_default_variant(C.byref(o), -1) == RS
+    assert lib.sat_conv_variant_signature(RS) == 7000
+    outs = []
+    for x in xs:
+        o1, k1, _ = _conv_op(L.SAT_BF16, x.float(), w.float(), 1, 1, stats=False)
+        acc = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+        o1.stat_acc, o1.variant = acc.data_ptr(), RS
+        L.check(lib.sat_run_ops_parity(C.pointer(o1), 1, 0, st()))
+        sync()
+        outs.append((k1[2].clone(), acc.clone()))
+    xg = cu(torch.stack(xs))
+    og, kg, _ = _conv_op(L.SAT_BF16, xs[0].float(), w.float(), 1, 1, stats=False)
+    outg = torch.full((2, N * H * W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    accg = torch.zeros(2, 2, 2, Cout, dtype=torch.int64, device="cuda")
+    og.in0, og.out, og.stat_acc, og.groups, og.variant = xg.data_ptr(), outg.data_ptr(), accg.data_ptr(), 2, RS
+    L.check(lib.sat_run_ops_parity(C.pointer(og), 1, 0, st()))
+    sync()
+    for q in range(2):
+        assert torch.equal(outg[q], outs[q][0]) and torch.equal(accg[q], outs[q][1])
+
+
+def test_conv_rs_refuses_other_geometries(lib):
+    g = torch.Generator().manual_seed(6)
+    for (H, W, Cin, Cout, stride, pad) in [(8, 100, 32, 32, 1, 0), (8, 140, 64, 32, 1, 0), (8, 140, 32, 128, 1, 1), (9, 141, 32, 32, 2, 0)]:
+        x = torch.randn(1, H, W, Cin, generator=g)
+        w = torch.randn(Cout, 3, 3, Cin, generator=g)
+        o, keep, _ = _conv_op(L.SAT_BF16, x, w, stride, pad, stats=False)
+        assert lib.sat_conv_default_variant(C.byref(o), -1) != RS
+        o.variant = RS                                    # asked for anyway: the launch falls back on a variant that runs it
+        L.check(lib.sat_run_ops_parity(C.pointer(o), 1, 0, st()))
+        sync()
+        ref = F.conv2d(x.bfloat16().double().permute(0, 3, 1, 2), w.bfloat16().double().permute(0, 3, 1, 2), None, stride, pad)
+        assert (keep[2].float().cpu().double() - ref.permute(0, 2, 3, 1).reshape(-1, Cout)).abs().max().item() < 0.5

@@ -2,7 +2,7 @@
 """Timeline of ONE timed region of bench.py's training loop (cfg 2, look-ahead): when every conv-stack program starts and ends on
 its side stream, when the main stream gets each batch's pooled features and when each step's decoder work ends -- HIP events, times in
 ms from the region's start.  Shows where a 20-step region (the contract's) spends its fill and drain.
-    python tools/step_timeline.py [steps]"""
+    python tools/step_timeline.py [steps] [inception]"""
 import importlib
 import os
 import sys
@@ -14,13 +14,15 @@ sat = importlib.import_module("show-and-tell_amd")
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 torch.manual_seed(123)
 dev = torch.device("cuda", 0)
-model = sat.ShowAndTell(256, 512, 10000, 1, compute_dtype="bf16").to(dev).train()
+INC = len(sys.argv) > 2 and sys.argv[2].startswith("inc")          # BASELINE configs[3]: Inception-v3 299 x 299 + L = 2 / H = 1024
+model = (sat.ShowAndTell(512, 1024, 10000, 2, arch="inception_v3", compute_dtype="bf16") if INC else
+         sat.ShowAndTell(256, 512, 10000, 1, compute_dtype="bf16")).to(dev).train()
 ts = sat.TrainStep(model, lr=1e-3)
 enc = model.encoder
 g = torch.Generator().manual_seed(5)
 depth = enc.lookahead_depth
 nb = depth + 1
-batches = [torch.randn(64, 3, 224, 224, generator=g).to(dev) for _ in range(nb)]
+batches = [torch.randn(64, 3, 299 if INC else 224, 299 if INC else 224, generator=g).to(dev) for _ in range(nb)]
 lengths = [20] * 64
 caps = torch.randint(3, 10000, (64, 20), generator=g).to(dev)
 enc.build_lookahead(batches[0])
