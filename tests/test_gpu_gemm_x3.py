@@ -40,7 +40,8 @@ def _run(lib, a, w, bias, ldc=None):
 
 
 @pytest.mark.parametrize("M,N,K,scale", [(320, 10000, 512, 1.0), (130, 1000, 256, 1.0), (64, 128, 1024, 1.0), (257, 636, 384, 1.0),
-                                         (5, 12, 256, 1.0), (200, 516, 512, 1e12), (200, 516, 512, 1e-12)])
+                                         (5, 12, 256, 1.0), (200, 516, 512, 1e12), (200, 516, 512, 1e-12),
+                                         (256, 32768, 256, 1.0)])       # (the last one: >= 512 tiles of 128 rows -> the one-workgroup-per-CU form)
 def test_gemm_f32x3_has_the_accuracy_of_an_f32_gemm(lib, M, N, K, scale):
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * 2.0) * scale      # wide dynamic range per element
