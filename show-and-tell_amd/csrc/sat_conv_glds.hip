@@ -639,6 +639,7 @@ constexpr Variant kVariants[] = {
     {128, 2, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 1},                                                                         // conv1 that also finishes the previous bottleneck: operand = relu(bn3(c3) + y), written out as it goes (sat_conv_ay.inc)
     {256, 2, 8, 0, 0, 128, 0, 0, 0, 0, 0, 0, 2},                                                                         // ... eight waves, 256-column tiles
     {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 1},                                                                       // 3x3 / stride 1 over 32 channels on large maps (Inception stem): weights in registers, whole input rows in LDS (sat_conv_rs.inc)
+    {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 2},                                                                       // ... 64 -> 64 channels on 56 x 56 maps (ResNet layer 1): two output rows per step, statistics per workgroup
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
@@ -692,6 +693,7 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 35: return launch_ay<4>(a, groups, s);
         case 36: return launch_ay<8>(a, groups, s);
         case 37: return launch_rs(a, groups, s);
+        case 38: return launch_rs64(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -708,7 +710,7 @@ bool signature_matches(int v, int want);
 
 int stat_signature(int v) {
     const Variant& k = kVariants[v];
-    if (k.rs) return 7000;          // (a wave's 32 rows, then the four waves in order)
+    if (k.rs) return k.rs == 2 ? 7001 : 7000;       // (a wave's pixels of a row, then the four waves in order / of a workgroup's whole run of steps)
     if (k.ap) return 6000;          // (a lane's 64 rows of a tile, the tiles of a worker in order, then the two halves)
     if (k.aw || k.ay) return 5000;          // (a lane's 64 rows, then the two halves: the same for the four- and the eight-wave form)
     if (k.pw) return 4000;
@@ -774,7 +776,7 @@ bool variant_ok(int v, const ConvArgs& a) {
     const Variant& k = kVariants[v];
     if (k.ay) return ay_ok(a, k.ay == 2 ? 8 : 4);
     if (a.in_res) return false;
-    if (k.rs) return rs_ok(a);                                      // only conv_ay_kernel builds its operand from two tensors
+    if (k.rs) return k.rs == 2 ? rs64_ok(a) : rs_ok(a);                                      // only conv_ay_kernel builds its operand from two tensors
     if (k.ap) return ap_ok(a);
     if (k.aw) return aw_ok(a, k.aw == 2 ? 8 : 4);
     if (k.pw) return pw_ok(a);
@@ -796,6 +798,7 @@ int heuristic_variant(const ConvArgs& a) {
     if (a.in_affine && !a.linear) return kVariantPr;      // 3x3 with a fused input BatchNorm: the LDS-resident patch (the builder fuses bn1 only where it can run)
     if (stem_ok(a)) return 30;                            // the op program's stem layout: the persistent stem kernel
     if (rs_ok(a)) return 37;                              // 3x3 over 32 channels on a large map (Inception stem): whole input rows in LDS
+    if (rs64_ok(a)) return 38;                            // 3x3 64 -> 64 on ~56-pixel rows (ResNet layer 1): the same, two output rows per step
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const int nk = sat_cdiv(a.K, 64);
     if (a.N > 64 && t128 >= 512) return nk <= 4 ? 2 : 0;

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 sat = importlib.import_module("show-and-tell_amd")
 L = sat._lib
 RS = 38
+RS64 = 39
 
 
 @pytest.fixture(scope="module")
@@ -100,3 +101,67 @@ def test_conv_rs_refuses_other_geometries(lib):
         sync()
         ref = F.conv2d(x.bfloat16().double().permute(0, 3, 1, 2), w.bfloat16().double().permute(0, 3, 1, 2), None, stride, pad)
         assert (keep[2].float().cpu().double() - ref.permute(0, 2, 3, 1).reshape(-1, Cout)).abs().max().item() < 0.5
+
+
+@pytest.mark.parametrize("mode", ["slab", "atomic", "none"])
+@pytest.mark.parametrize("N,H,W", [(4, 56, 56), (3, 8, 50), (1, 2, 64), (9, 6, 49)])
+def test_conv_rs64_is_bit_identical_to_the_ring_kernel(lib, N, H, W, mode):
+    """conv_rs64_kernel (variant 39): conv2 of ResNet's layer 1 -- 3 x 3 / padding 1, 64 -> 64 channels, two output rows per step, the
+    column sums per workgroup"""
+    Cin = Cout = 64
+    g = torch.Generator().manual_seed(N * 7 + W)
+    x = (torch.randn(N, Cin, H, W, generator=g) * 1.5 + 0.2).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 24.0).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).reshape(-1, Cout)
+
+    def run(v):
+        o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 1, 1, stats=(mode == "slab"))
+        o.variant = v
+        extra = {}
+        if mode == "atomic":
+            extra["acc"] = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc = extra["acc"].data_ptr()
+        ops = (L.SatOp * 1)(o)
+        L.check(lib.sat_run_ops_parity(ops, 1, 0, st()))
+        sync()
+        return keep, extra
+
+    want, wx = run(1)
+    got, gx = run(RS64)
+    slabs_ok = mode != "slab" or lib.sat_conv_tiles_m(N * H * W) >= min(N * H // 2, 512)
+    if not slabs_ok:
+        pytest.skip("fewer statistics slabs than workgroups: the library falls back on another variant")
+    assert torch.isfinite(got[2].float()).all()
+    assert torch.equal(got[2], want[2])
+    assert (got[2].float().cpu().double() - ref).abs().max().item() < 3e-2 + 4e-3 * ref.abs().max().item()
+    if mode == "slab":
+        assert torch.isfinite(got[3]).all()
+        torch.testing.assert_close(got[3].sum(0), want[3].sum(0), rtol=1e-4, atol=3e-2)
+    elif mode == "atomic":
+        torch.testing.assert_close(gx["acc"].double() / 2 ** 22, wx["acc"].double() / 2 ** 22, rtol=1e-4, atol=3e-2)
+
+
+def test_conv_rs64_default_signature_and_groups(lib):
+    N, H, W, C_ = 3, 4, 56, 64
+    g = torch.Generator().manual_seed(15)
+    xs = [(torch.randn(N, H, W, C_, generator=g) + 0.1).bfloat16() for _ in range(2)]
+    w = (torch.randn(C_, 3, 3, C_, generator=g) / 24.0).bfloat16()
+    o, keep, _ = _conv_op(L.SAT_BF16, xs[0].float(), w.float(), 1, 1, stats=False)
+    assert lib.sat_conv_default_variant(C.byref(o), -1) == RS64 and lib.sat_conv_variant_signature(RS64) == 7001
+    outs = []
+    for x in xs:
+        o1, k1, _ = _conv_op(L.SAT_BF16, x.float(), w.float(), 1, 1, stats=False)
+        acc = torch.zeros(2, 2, C_, dtype=torch.int64, device="cuda")
+        o1.stat_acc, o1.variant = acc.data_ptr(), RS64
+        L.check(lib.sat_run_ops_parity(C.pointer(o1), 1, 0, st()))
+        sync()
+        outs.append((k1[2].clone(), acc.clone()))
+    xg = cu(torch.stack(xs))
+    og, kg, _ = _conv_op(L.SAT_BF16, xs[0].float(), w.float(), 1, 1, stats=False)
+    outg = torch.full((2, N * H * W, C_), float("nan"), device="cuda", dtype=torch.bfloat16)
+    accg = torch.zeros(2, 2, 2, C_, dtype=torch.int64, device="cuda")
+    og.in0, og.out, og.stat_acc, og.groups, og.variant = xg.data_ptr(), outg.data_ptr(), accg.data_ptr(), 2, RS64
+    L.check(lib.sat_run_ops_parity(C.pointer(og), 1, 0, st()))
+    sync()
+    for q in range(2):
+        assert torch.equal(outg[q], outs[q][0]) and torch.equal(accg[q], outs[q][1])
