@@ -640,6 +640,7 @@ constexpr Variant kVariants[] = {
     {256, 2, 8, 0, 0, 128, 0, 0, 0, 0, 0, 0, 2},                                                                         // ... eight waves, 256-column tiles
     {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 1},                                                                       // 3x3 / stride 1 over 32 channels on large maps (Inception stem): weights in registers, whole input rows in LDS (sat_conv_rs.inc)
     {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 2},                                                                       // ... 64 -> 64 channels on 56 x 56 maps (ResNet layer 1): two output rows per step, statistics per workgroup
+    {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 3},                                                                       // ... 3 x 3 / stride 2 over the image's padded 8 channels -> 32 (the first conv of the Inception stem)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
@@ -694,6 +695,7 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 36: return launch_ay<8>(a, groups, s);
         case 37: return launch_rs(a, groups, s);
         case 38: return launch_rs64(a, groups, s);
+        case 39: return launch_rs8(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -776,7 +778,7 @@ bool variant_ok(int v, const ConvArgs& a) {
     const Variant& k = kVariants[v];
     if (k.ay) return ay_ok(a, k.ay == 2 ? 8 : 4);
     if (a.in_res) return false;
-    if (k.rs) return k.rs == 2 ? rs64_ok(a) : rs_ok(a);                                      // only conv_ay_kernel builds its operand from two tensors
+    if (k.rs) return k.rs == 2 ? rs64_ok(a) : (k.rs == 3 ? rs8_ok(a) : rs_ok(a));                                      // only conv_ay_kernel builds its operand from two tensors
     if (k.ap) return ap_ok(a);
     if (k.aw) return aw_ok(a, k.aw == 2 ? 8 : 4);
     if (k.pw) return pw_ok(a);
@@ -798,6 +800,7 @@ int heuristic_variant(const ConvArgs& a) {
     if (a.in_affine && !a.linear) return kVariantPr;      // 3x3 with a fused input BatchNorm: the LDS-resident patch (the builder fuses bn1 only where it can run)
     if (stem_ok(a)) return 30;                            // the op program's stem layout: the persistent stem kernel
     if (rs_ok(a)) return 37;                              // 3x3 over 32 channels on a large map (Inception stem): whole input rows in LDS
+    if (rs8_ok(a)) return 39;                             // ... the stem's first conv (stride 2 over the padded image)
     if (rs64_ok(a)) return 38;                            // 3x3 64 -> 64 on ~56-pixel rows (ResNet layer 1): the same, two output rows per step
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);
     const int nk = sat_cdiv(a.K, 64);

@@ -17,6 +17,7 @@ sat = importlib.import_module("show-and-tell_amd")
 L = sat._lib
 RS = 38
 RS64 = 39
+RS8 = 40
 
 
 @pytest.fixture(scope="module")
@@ -165,3 +166,40 @@ def test_conv_rs64_default_signature_and_groups(lib):
     sync()
     for q in range(2):
         assert torch.equal(outg[q], outs[q][0]) and torch.equal(accg[q], outs[q][1])
+
+
+@pytest.mark.parametrize("mode", ["slab", "atomic", "none"])
+@pytest.mark.parametrize("N,H,W", [(2, 299, 299), (3, 9, 261), (1, 3, 321), (5, 21, 259)])
+def test_conv_rs8_is_bit_identical_to_the_ring_kernel(lib, N, H, W, mode):
+    """conv_rs8_kernel (variant 40): the first conv of the Inception stem -- 3 x 3 / stride 2 over the image's 3 channels padded to 8 -> 32"""
+    Cin, Cout = 8, 32
+    g = torch.Generator().manual_seed(N * 5 + W)
+    x = (torch.randn(N, Cin, H, W, generator=g) * 1.5 + 0.2).bfloat16().float()
+    x[:, 3:] = 0.0
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 5.0).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, 2, 0).permute(0, 2, 3, 1).reshape(-1, Cout)
+
+    def run(v):
+        o, keep, _ = _conv_op(L.SAT_BF16, x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), 2, 0, stats=(mode == "slab"))
+        o.variant = v
+        extra = {}
+        if mode == "atomic":
+            extra["acc"] = torch.zeros(2, 2, Cout, dtype=torch.int64, device="cuda")
+            o.stat_acc = extra["acc"].data_ptr()
+        ops = (L.SatOp * 1)(o)
+        if v == RS8:
+            assert lib.sat_conv_default_variant(C.byref(o), -1) == RS8
+        L.check(lib.sat_run_ops_parity(ops, 1, 0, st()))
+        sync()
+        return keep, extra
+
+    want, wx = run(1)
+    got, gx = run(RS8)
+    assert torch.isfinite(got[2].float()).all()
+    assert torch.equal(got[2], want[2])
+    assert (got[2].float().cpu().double() - ref).abs().max().item() < 3e-2 + 4e-3 * ref.abs().max().item()
+    if mode == "slab":
+        assert torch.isfinite(got[3]).all()
+        torch.testing.assert_close(got[3].sum(0), want[3].sum(0), rtol=1e-4, atol=3e-2)
+    elif mode == "atomic":
+        torch.testing.assert_close(gx["acc"].double() / 2 ** 22, wx["acc"].double() / 2 ** 22, rtol=1e-4, atol=3e-2)
