@@ -726,7 +726,8 @@ def run_decode(args, torch, dist, sat, wl, dev, rank, world, use_dist, backend):
         with torch.no_grad():
             for i in range(n):
                 if args.lookahead:             # the next batches' stacks run ahead, two batches per program run (eval mode: concatenated)
-                    model.encoder.prefetch_many([batches[j % nb] for j in range(i + 1, i + 1 + depth) if j < n])
+                    model.encoder.prefetch_many([batches[j % nb] for j in range(i + 1, i + 1 + depth) if j < n],
+                                                own_stack=not model.encoder._is_in_flight(batches[i % nb]))      # (the first step runs its own stack beside them)
                 ids = decode(model.encoder(batches[i % nb]))
         return ids
 

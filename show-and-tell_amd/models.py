@@ -281,7 +281,7 @@ class EncoderCNN(nn.Module):
         self._launch([images], slot, 1)
         return True
 
-    def prefetch_many(self, images_list, last=None):
+    def prefetch_many(self, images_list, last=None, own_stack=False):
         """`prefetch` for the next few batches IN ORDER.  With `lookahead_groups` = G > 1 (bf16) G batches that are not in flight
         yet start together as ONE grouped program (every launch of the stack covers G batches; each batch's statistics and
         features are bit for bit those of its own ungrouped run); a batch left over is started alone when it is the very next
@@ -289,15 +289,24 @@ class EncoderCNN(nn.Module):
         end of the data (`DevicePrefetcher.upcoming_images()` sets it on the list it returns); None infers it from a list shorter
         than the look-ahead window -- right for callers that always hand in `lookahead_depth` batches when they have them
         (`bench.py`), wrong for a prefetcher of smaller depth, which would start a single per step and never a group.
-        Returns the number of batches started."""
+        `own_stack`: the caller runs the CURRENT batch's stack itself right after this call (`TrainStep` when that batch was not
+        prefetched: the first step of a loop).  Returns the number of batches started."""
         if last is None:
             last = getattr(images_list, "last", None)
         ims = [im for im in images_list if im is not None and im.dim() == 4]
         G = self.lookahead_groups if self.compute_dtype == "bf16" else 1
         started = 0
         new = [im for im in ims if not self._is_in_flight(im)]
+        # COLD START (nothing in flight, and the caller is about to run the current batch's own stack beside what starts here): that
+        # stack takes one of the pipeline's places, so one grouped run fewer starts now -- the next call starts it, behind the first
+        # hand-over.  With all `n_slots` runs AND the own stack started together, four stacks share the chip, all finish at the same
+        # moment (21 ms into a region, profiles/r05_step_timeline.txt) and the refills then trickle in one decoder step apart: 18.45-18.53
+        # -> 18.72-18.80 k img/s at the contract's 20-step regions (interleaved on one box; one run fewer still: no better than before)
+        cap = max(1, self._n_slots() - 1) if (own_stack and not self._inflight) else None
         if G > 1:
             while len(new) >= G:
+                if cap is not None and started >= cap * G:
+                    return started                                      # (the rest starts with the next call)
                 grp = new[:G]
                 if len({tuple(im.shape) for im in grp}) != 1 or len({id(im) for im in grp}) != G:
                     break                                               # ragged last batch / the same tensor twice: singles below

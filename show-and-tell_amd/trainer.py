@@ -138,7 +138,7 @@ class TrainStep:
                 enc.prefetch_many(nxt, last=last)
             return out
         if nxt:
-            enc.prefetch_many(nxt, last=last)
+            enc.prefetch_many(nxt, last=last, own_stack=True)
         out.copy_(enc._pooled_raw(images))
         return out
 

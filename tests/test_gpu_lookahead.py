@@ -87,6 +87,32 @@ def test_a_prefetcher_shallower_than_the_window_still_runs_grouped_programs():
     assert grouped >= 3 and singles <= 3, (grouped, singles)
 
 
+def test_a_cold_pipeline_starts_one_grouped_run_fewer_beside_the_own_stack():
+    """the first step of a loop runs its batch's stack itself, beside the look-ahead it starts: that stack takes one of the pipeline's
+    places (`prefetch_many(own_stack=True)`: n_slots - 1 grouped runs), the next step starts the rest; losses equal the sequential run"""
+    def run(lookahead):
+        torch.manual_seed(6)
+        model = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().train()
+        if not lookahead:
+            model.encoder.lookahead_depth = 0
+        ts = sat.TrainStep(model, lr=1e-3, grad_clip=0.1)
+        g = torch.Generator().manual_seed(12)
+        caps = torch.randint(1, 120, (8, 9), generator=g).cuda()
+        lengths = [9, 9, 8, 7, 6, 5, 4, 3]
+        ims = [torch.rand(8, 3, 64, 64, generator=g).cuda() for _ in range(10)]
+        depth, losses, runs_after = model.encoder.lookahead_depth, [], []
+        for i, im in enumerate(ims):
+            nxt = ims[i + 1:i + 1 + depth] if lookahead else None
+            losses.append(ts.step(im, caps, lengths, next_images=nxt or None))
+            runs_after.append(len(model.encoder._inflight))
+        torch.cuda.synchronize()
+        return torch.cat(losses).cpu(), runs_after
+    seq, _ = run(False)
+    la, runs = run(True)
+    assert torch.equal(seq, la)
+    assert runs[0] == 2 and runs[1] == 3, runs          # (depth 6, two batches per run: three run slots)
+
+
 def test_lookahead_of_a_different_tensor_is_discarded():
     torch.manual_seed(5)
     model = sat.ShowAndTell(32, 64, 120, 1, compute_dtype="bf16").cuda().train()
