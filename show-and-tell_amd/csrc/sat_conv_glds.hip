@@ -641,6 +641,7 @@ constexpr Variant kVariants[] = {
     {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 1},                                                                       // 3x3 / stride 1 over 32 channels on large maps (Inception stem): weights in registers, whole input rows in LDS (sat_conv_rs.inc)
     {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 2},                                                                       // ... 64 -> 64 channels on 56 x 56 maps (ResNet layer 1): two output rows per step, statistics per workgroup
     {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 3},                                                                       // ... 3 x 3 / stride 2 over the image's padded 8 channels -> 32 (the first conv of the Inception stem)
+    {64, 1, 4, 0, 0, 128, 0, 0, 0, 0, 0, 0, 0, 4},                                                                       // ... ResNet's 7 x 7 stem in the stem kernel's layout
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kVariantPr = 29;
@@ -696,6 +697,7 @@ int launch_variant(int v, ConvArgs& a, int groups, hipStream_t s) {
         case 37: return launch_rs(a, groups, s);
         case 38: return launch_rs64(a, groups, s);
         case 39: return launch_rs8(a, groups, s);
+        case 40: return launch_rs_stem(a, groups, s);
         default: return SAT_ERR_ARG;
     }
 }
@@ -712,7 +714,7 @@ bool signature_matches(int v, int want);
 
 int stat_signature(int v) {
     const Variant& k = kVariants[v];
-    if (k.rs) return k.rs == 2 ? 7001 : 7000;       // (a wave's pixels of a row, then the four waves in order / of a workgroup's whole run of steps)
+    if (k.rs) return k.rs == 2 ? 7001 : (k.rs == 4 ? 7002 : 7000);       // (a wave's pixels of a row, then the four waves in order / of a workgroup's whole run of steps)
     if (k.ap) return 6000;          // (a lane's 64 rows of a tile, the tiles of a worker in order, then the two halves)
     if (k.aw || k.ay) return 5000;          // (a lane's 64 rows, then the two halves: the same for the four- and the eight-wave form)
     if (k.pw) return 4000;
@@ -778,7 +780,7 @@ bool variant_ok(int v, const ConvArgs& a) {
     const Variant& k = kVariants[v];
     if (k.ay) return ay_ok(a, k.ay == 2 ? 8 : 4);
     if (a.in_res) return false;
-    if (k.rs) return k.rs == 2 ? rs64_ok(a) : (k.rs == 3 ? rs8_ok(a) : rs_ok(a));                                      // only conv_ay_kernel builds its operand from two tensors
+    if (k.rs) return k.rs == 2 ? rs64_ok(a) : (k.rs == 3 ? rs8_ok(a) : (k.rs == 4 ? rs_stem_ok(a) : rs_ok(a)));                                      // only conv_ay_kernel builds its operand from two tensors
     if (k.ap) return ap_ok(a);
     if (k.aw) return aw_ok(a, k.aw == 2 ? 8 : 4);
     if (k.pw) return pw_ok(a);

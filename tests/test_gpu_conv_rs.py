@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from test_gpu_kernels import _conv_op, cu, st, sync
+from test_gpu_kernels import _conv_op, _stem_op, cu, st, sync
 
 pytestmark = pytest.mark.gpu
 sat = importlib.import_module("show-and-tell_amd")
@@ -18,6 +18,7 @@ L = sat._lib
 RS = 38
 RS64 = 39
 RS8 = 40
+RS_STEM = 41
 
 
 @pytest.fixture(scope="module")
@@ -203,3 +204,36 @@ def test_conv_rs8_is_bit_identical_to_the_ring_kernel(lib, N, H, W, mode):
         torch.testing.assert_close(got[3].sum(0), want[3].sum(0), rtol=1e-4, atol=3e-2)
     elif mode == "atomic":
         torch.testing.assert_close(gx["acc"].double() / 2 ** 22, wx["acc"].double() / 2 ** 22, rtol=1e-4, atol=3e-2)
+
+
+@pytest.mark.parametrize("N,H,W,groups", [(3, 224, 224, 1), (2, 160, 192, 1), (1, 130, 250, 1), (2, 224, 224, 2)])
+def test_conv_rs_stem_is_bit_identical_to_the_stem_kernel(lib, N, H, W, groups):
+    """conv_rs_stem_kernel (variant 41): ResNet's 7 x 7 / stride 2 stem in the op program's layout as a rolling window of seven input
+    rows, against conv_stem_kernel (variant 31): output bitwise equal, the column sums (per workgroup here, per tile there) equal in total"""
+    g = torch.Generator().manual_seed(N * 7 + W)
+    Hp, Wp = H + 6, (W + 8 + 1) // 2 * 2
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    x = torch.zeros(groups * N, Hp, Wp, 4)
+    x[:, 3:3 + H, 3:3 + W, :3] = torch.randn(groups * N, H, W, 3, generator=g)
+    w = torch.zeros(64, 7, 8, 4)
+    w[:, :, :7, :3] = torch.randn(64, 7, 7, 3, generator=g) / 12.0
+    xd, wd = x.bfloat16().cuda(), w.reshape(64, 224).bfloat16().cuda()
+    res = {}
+    for v in (31, RS_STEM):
+        o, out, part = _stem_op(xd, wd, Ho, Wo, groups)
+        o.variant = v
+        L.check(lib.sat_run_ops(C.pointer(o), 1, st()))
+        sync()
+        res[v] = (out.clone(), part.clone())
+    assert lib.sat_conv_variant_signature(RS_STEM) == 7002
+    assert torch.isfinite(res[RS_STEM][0].float()).all() and torch.isfinite(res[RS_STEM][1]).all()
+    assert torch.equal(res[RS_STEM][0], res[31][0])
+    torch.testing.assert_close(res[RS_STEM][1].sum(1), res[31][1].sum(1), rtol=1e-4, atol=3e-2)
+    if groups == 2:                                      # each group = its own launch
+        for q in range(2):
+            o, out, part = _stem_op(xd[q * N:(q + 1) * N].contiguous(), wd, Ho, Wo, 1)
+            o.variant = RS_STEM
+            L.check(lib.sat_run_ops(C.pointer(o), 1, st()))
+            sync()
+            assert torch.equal(out, res[RS_STEM][0][q * N * Ho * Wo:(q + 1) * N * Ho * Wo])
+            assert torch.equal(part[0], res[RS_STEM][1][q])

@@ -107,7 +107,7 @@ def test_conv_fwd_and_stats(lib, dtype, N, H, W, Cin, Cout, k, stride, pad):
     np.testing.assert_allclose(part[:, 1].sum(0).numpy(), (ref ** 2).sum(0).numpy(), rtol=2e-4, atol=1e-3)
 
 
-NUM_CONV_VARIANTS = 40
+NUM_CONV_VARIANTS = 41
 PLAIN_CONV_VARIANTS = list(range(1, 27))      # ring kernel variants (27..29: conv_xp_kernel, 30: conv_pr_kernel -- their own tests)
 
 
