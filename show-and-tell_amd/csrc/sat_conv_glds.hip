@@ -802,6 +802,7 @@ int heuristic_variant(const ConvArgs& a) {
     if (a.in_affine && !a.linear) return kVariantPr;      // 3x3 with a fused input BatchNorm: the LDS-resident patch (the builder fuses bn1 only where it can run)
     if (stem_ok(a)) return 30;                            // the op program's stem layout: the persistent stem kernel
     if (rs_ok(a)) return 37;                              // 3x3 over 32 channels on a large map (Inception stem): whole input rows in LDS
+    if (rs_stem_ok(a)) return 40;                         // ... the stem layout with an inference epilogue (conv_stem_kernel has none)
     if (rs8_ok(a)) return 39;                             // ... the stem's first conv (stride 2 over the padded image)
     if (rs64_ok(a)) return 38;                            // 3x3 64 -> 64 on ~56-pixel rows (ResNet layer 1): the same, two output rows per step
     const long t128 = (long)sat_cdiv(a.M, 128) * sat_cdiv(a.N, 128);

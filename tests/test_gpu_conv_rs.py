@@ -237,3 +237,47 @@ def test_conv_rs_stem_is_bit_identical_to_the_stem_kernel(lib, N, H, W, groups):
             sync()
             assert torch.equal(out, res[RS_STEM][0][q * N * Ho * Wo:(q + 1) * N * Ho * Wo])
             assert torch.equal(part[0], res[RS_STEM][1][q])
+
+
+@pytest.mark.parametrize("kind", ["rs32", "rs64", "rs8", "stem"])
+def test_rolling_window_kernels_run_the_inference_epilogue(lib, kind):
+    """eval mode: BatchNorm as a fixed affine of the output column + ReLU in the conv's epilogue (scale1 / shift1 / flags bit 0) --
+    bitwise the ring kernel's"""
+    g = torch.Generator().manual_seed(len(kind) * 3)
+    if kind == "stem":
+        N, H, W = 2, 224, 224
+        Hp, Wp, Ho, Wo = H + 6, 232, 112, 112
+        x = torch.zeros(N, Hp, Wp, 4)
+        x[:, 3:3 + H, 3:3 + W, :3] = torch.randn(N, H, W, 3, generator=g)
+        w = torch.zeros(64, 7, 8, 4)
+        w[:, :, :7, :3] = torch.randn(64, 7, 7, 3, generator=g) / 12.0
+        xd, wd = x.bfloat16().cuda(), w.reshape(64, 224).bfloat16().cuda()
+        Cout, variant, base = 64, RS_STEM, 10
+
+        def make():
+            o, out, _ = _stem_op(xd, wd, Ho, Wo)
+            o.stat_partial, o.tiles_m = None, 0
+            return o, out
+    else:
+        N, H, W, Cin, Cout, stride, pad, variant = {"rs32": (2, 20, 149, 32, 32, 1, 0, RS), "rs64": (3, 56, 56, 64, 64, 1, 1, RS64),
+                                                    "rs8": (2, 41, 299, 8, 32, 2, 0, RS8)}[kind]
+        base = 1
+        x = (torch.randn(N, H, W, Cin, generator=g) + 0.1).bfloat16().float()
+        w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (3.0 * Cin ** 0.5)).bfloat16().float()
+
+        def make():
+            o, keep, _ = _conv_op(L.SAT_BF16, x, w, stride, pad, stats=False)
+            make.keep = keep
+            return o, keep[2]
+    sc, sh = cu(torch.rand(Cout, generator=g) + 0.5), cu(torch.randn(Cout, generator=g) * 0.3)
+    outs = {}
+    for v in (base, variant):
+        o, out = make()
+        o.scale1, o.shift1, o.flags, o.variant = sc.data_ptr(), sh.data_ptr(), 1, v
+        if v == variant:
+            assert lib.sat_conv_default_variant(C.byref(o), -1) == variant          # (no table entry: the geometry's default)
+        L.check(lib.sat_run_ops(C.pointer(o), 1, st()))
+        sync()
+        outs[v] = out.clone()
+    assert torch.isfinite(outs[variant].float()).all() and float(outs[variant].float().min()) >= 0.0
+    assert torch.equal(outs[variant], outs[base])
